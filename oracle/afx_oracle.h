@@ -1,0 +1,68 @@
+/* oracle/afx_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the AFEC low-level hot path, used solely as
+ * the parity checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * The product (afec_amd/, libafx_hip.so) never includes, links or calls anything in oracle/.
+ * Parity status: PINNED -- checked against the reference's own compiled objects
+ * (oracle/_ref/ref_driver, see oracle/Makefile) and against tests/golden/ fixtures generated
+ * from them (tests/golden/make_golden.py).
+ */
+#ifndef AFX_ORACLE_H
+#define AFX_ORACLE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* per-frame record layout in doubles (identical to oracle/ref_driver.cpp) */
+enum {
+  AFXO_MAG = 0, AFXO_MFCC = 1024, AFXO_SRMS = 1038, AFXO_CENTROID, AFXO_SPREAD, AFXO_SKEW,
+  AFXO_KURT, AFXO_ROLLOFF, AFXO_FLATNESS, AFXO_FLUX, AFXO_BANDS = 1046, AFXO_SUB_RMS = 1074,
+  AFXO_SUB_FLAT = 1088, AFXO_SUB_FLUX = 1102, AFXO_SUB_CPLX = 1116, AFXO_SUB_CONTRAST = 1130,
+  AFXO_CONTRAST = 1144, AFXO_AMP_PEAK, AFXO_AMP_RMS, AFXO_RECORD
+};
+
+typedef struct afx_oracle afx_oracle;
+
+afx_oracle* afx_oracle_create(int sample_rate, int fft_size, int hop_size);
+void afx_oracle_destroy(afx_oracle*);
+const double* afx_oracle_window(const afx_oracle*);        /* [fft_size]            */
+const double* afx_oracle_mel(const afx_oracle*);           /* [14][fft_size/2]      */
+int afx_oracle_first_bin(const afx_oracle*);
+int afx_oracle_bin_count(const afx_oracle*);
+
+/* frames the reference loop produces for a buffer of n_samples (SampleAnalyser.cpp:760-764, 814) */
+int64_t afx_oracle_num_frames(const afx_oracle*, int64_t n_samples, int apply_cap);
+
+/* run the per-frame loop over one buffer; records = [frames][AFXO_RECORD]; returns frames */
+int64_t afx_oracle_run(const afx_oracle*, const double* x, int64_t n_samples, int apply_cap,
+                       double* records);
+
+/* C2 subset only (window -> FFT -> magnitude -> MFCC), for the bench cpu_baseline leg:
+ * mfcc = [frames][14]; returns frames */
+int64_t afx_oracle_run_mfcc(const afx_oracle*, const double* x, int64_t n_samples, double* mfcc);
+
+/* TStatistics restatements exposed for the reference's own known-answer tests */
+double afx_oracle_sum(const double* x, int n);
+double afx_oracle_mean(const double* x, int n);
+double afx_oracle_variance(const double* x, int n, double mean);
+double afx_oracle_geometric_mean(const double* x, int n);
+double afx_oracle_centroid(const double* x, int n);
+double afx_oracle_spread(const double* x, int n, double centroid);
+double afx_oracle_skewness(const double* x, int n, double centroid, double spread);
+double afx_oracle_kurtosis(const double* x, int n, double centroid, double spread);
+double afx_oracle_flatness(const double* x, int n);
+double afx_oracle_flatness_db(const double* x, int n);
+double afx_oracle_correlation(const double* a, const double* b, int n);
+double afx_oracle_median(const double* x, int n);
+double afx_oracle_min(const double* x, int n);
+double afx_oracle_max(const double* x, int n);
+double afx_oracle_lin_to_db(double v);
+/* TStatistics::Calc: out[13] = min,max,median,mean,gmean,variance,centroid,spread,skewness,
+ * kurtosis,flatness,dmean,dvariance (fields the reference leaves untouched stay as passed in) */
+void afx_oracle_calc_statistics(const double* x, int n, double* out13);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

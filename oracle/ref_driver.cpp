@@ -1,0 +1,283 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+//
+// Drives the *reference's own* compiled objects (LibXtract C sources, OouraFFT8g.cpp,
+// AudioMath.cpp, Statistics.cpp, built where they lie under /root/reference by
+// oracle/Makefile into oracle/_ref/) through the per-frame loop of
+// TSampleAnalyser::AnalyzeLowLevelDescriptors (SampleAnalyser.cpp:814-976) for the
+// descriptors in SURVEY.md section 8(a).  The Calc* member bodies are private and
+// SampleAnalyser.cpp itself does not build here (aubio/Shark/LightGBM/CoreTypes),
+// so this driver restates only their *argument slicing* and calls the real
+// xtract_*/ooura_cdft/TAudioMath/TStatistics functions for every piece of arithmetic
+// that exists as a linkable reference function.  Bodies that are inline in
+// SampleAnalyser.cpp (band loops, contrast) are restated and marked as such.
+//
+// Usage:
+//   ref_driver tables  <out.bin>                 window[2048] + mel[14][1024] doubles
+//   ref_driver frames  <in.bin> <out.bin> [cap]  per-frame records (see kRecord)
+//   ref_driver time    <n_frames> <seed>         C2 subset timing (STFT + MFCC), prints frames/s
+//
+// in.bin : int64 n_bufs ; per buffer: int64 n_samples, double[n_samples]
+// out.bin: int64 n_frames ; double[n_frames][kRecord]
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+#include <algorithm>
+#include <chrono>
+#include <random>
+
+extern "C" {
+#include "xtract/libxtract.h"
+}
+#include "AudioTypes/Source/OouraFFT8g.h"
+#include "AudioTypes/Export/AudioMath.h"
+#include "FeatureExtraction/Export/Statistics.h"
+
+static const int kSampleRate = 44100, kFft = 2048, kHop = 1024;
+static const int kNumCep = 14, kNumBands = 28, kNumSub = 14;
+// record layout (doubles)
+enum {
+  oMag = 0, oMfcc = oMag + 1024, oSRms = oMfcc + 14, oCentroid, oSpread, oSkew, oKurt,
+  oRolloff, oFlatness, oFlux, oBands = oFlux + 1, oSubRms = oBands + 28,
+  oSubFlat = oSubRms + 14, oSubFlux = oSubFlat + 14, oSubCplx = oSubFlux + 14,
+  oSubContrast = oSubCplx + 14, oContrast = oSubContrast + 14, oAmpPeak, oAmpRms,
+  kRecord
+};
+
+struct TRef {
+  int mFirstBin, mLastBin, mBinCount;
+  double* mpWindow;
+  xtract_mel_filter mMel;
+  // TFftTransformComplex state (Fourier.cpp:97-108): ooura work areas
+  std::vector<double> mInterleaved, mW, mRe, mIm;
+  std::vector<int> mIp;
+
+  TRef() : mInterleaved(2 * kFft), mW(kFft), mRe(kFft), mIm(kFft), mIp(kFft) {
+    // SampleAnalyser.cpp:171-175 (note the integer division)
+    const double FrequenciesPerBin = kSampleRate / kFft;
+    mFirstBin = TMath::d2iRound(20.0 / FrequenciesPerBin);
+    mLastBin = TMath::d2iRound(15500.0 / FrequenciesPerBin);
+    mBinCount = mLastBin - mFirstBin + 1;
+    // SampleAnalyser.cpp:178-181
+    mpWindow = xtract_init_window(kFft, XTRACT_HANN);
+    for (int i = 0; i < kFft; ++i) mpWindow[i] *= 2.0;
+    // SampleAnalyser.cpp:184-197
+    mMel.n_filters = kNumCep;
+    mMel.filters = (double**)malloc(kNumCep * sizeof(double*));
+    for (int k = 0; k < kNumCep; ++k) mMel.filters[k] = (double*)malloc((kFft / 2) * sizeof(double));
+    xtract_init_mfcc(kFft / 2, kSampleRate / 2, XTRACT_EQUAL_GAIN, 20.0, 15500.0, kNumCep, mMel.filters);
+    mIp[0] = 0;
+  }
+
+  // TFftTransformComplex::ForwardInplace, generic branch (Fourier.cpp:243-270)
+  void Forward() {
+    for (int i = 0; i < kFft; ++i) { mInterleaved[2*i] = mRe[i]; mInterleaved[2*i+1] = mIm[i]; }
+    mIp[0] = 0;
+    ooura_cdft(2 * kFft, 1, mInterleaved.data(), mIp.data(), mW.data());
+    for (int i = 0; i < kFft; ++i) { mRe[i] = mInterleaved[2*i]; mIm[i] = mInterleaved[2*i+1]; }
+    const double ScaleFactor = 1.0f / kFft;
+    for (int i = 0; i < kFft; ++i) { mRe[i] *= ScaleFactor; mIm[i] *= ScaleFactor; }
+  }
+
+  // SampleAnalyser.cpp:826-845
+  void Stft(const double* frame, double* mag /*[2048]*/) {
+    std::vector<double> windowed(kFft);
+    xtract_windowed(frame, kFft, mpWindow, windowed.data());
+    memcpy(mRe.data(), windowed.data(), kFft * sizeof(double));
+    memset(mIm.data(), 0, kFft * sizeof(double));
+    Forward();
+    TAudioMath::Magnitude(mRe.data(), mIm.data(), mag, kFft / 2);
+    memset(mag + kFft / 2, 0, (kFft / 2) * sizeof(double));
+  }
+};
+
+// SampleAnalyser.cpp:129-133
+static double SFlatnessDb(const double* pX, int Length) {
+  const double Flatness = TStatistics::Flatness(pX, Length);
+  return MMin(TAudioMath::LinToDb(Flatness) / -60.0, 1.0);
+}
+
+static double NanToZero(double v) { return (v != v) ? 0.0 : v; }
+
+static void Frame(TRef& R, const double* x, const double* mag, const double* last, double* out) {
+  memcpy(out + oMag, mag, 1024 * sizeof(double));
+  const double* m = mag + R.mFirstBin;
+  const int n = R.mBinCount;
+  // CalcAmplitudePeak / CalcAmplitudeRms on the hop (SampleAnalyser.cpp:871-872, 1760-1783)
+  {
+    double pk = 0.0;
+    for (int i = 0; i < kHop; ++i) pk = std::max(pk, std::fabs(x[i]));
+    out[oAmpPeak] = pk;
+    double rms = 0.0; xtract_rms_amplitude(x, kHop, NULL, &rms);
+    out[oAmpRms] = NanToZero(rms);
+  }
+  // CalcSpectralRms (1808-1818)
+  { double rms = 0.0; xtract_rms_amplitude(m, n, NULL, &rms); out[oSRms] = NanToZero(rms); }
+  // CalcSpectralCentroidAndSpread (1822-1837), SkewnessAndKurtosis (1858-1883)
+  const double C = TStatistics::Centroid(m, n);
+  const double S = TStatistics::Spread(m, n, C);
+  out[oCentroid] = C; out[oSpread] = S;
+  out[oSkew] = TStatistics::Skewness(m, n, C, S);
+  out[oKurt] = TStatistics::Kurtosis(m, n, C, S);
+  // CalcSpectralRolloff (1887-1901)
+  {
+    double Arguments[4] = { 0 };
+    Arguments[0] = kSampleRate / (kFft / 2);
+    Arguments[1] = 85.0f;
+    double Rolloff = 0.0; xtract_rolloff(m, n, Arguments, &Rolloff);
+    out[oRolloff] = NanToZero(Rolloff);
+  }
+  // CalcSpectralFlatness (1905-1915)
+  out[oFlatness] = NanToZero(SFlatnessDb(m, n));
+  // CalcSpectralFlux (1919-1933)
+  out[oFlux] = TStatistics::Flux(m, last + R.mFirstBin, n);
+
+  // CalcSpectralBandFeatures (2067-2308) -- body is inline in SampleAnalyser.cpp, restated
+  {
+    static const double sBandFrequencies[] = { 50.0, 100.0, 200.0, 400.0, 630.0, 920.0, 1270.0,
+      1720.0, 2320.0, 3150.0, 4400.0, 6400.0, 9500.0, 15500.0 };
+    const double NeighbourRatio = 0.3, Epsilon = 1e-30;
+    const double FrequenciesPerBin = kSampleRate / kFft;
+    const int FirstBin = TMath::d2iRound(20.0 / FrequenciesPerBin);
+    int NumberOfBinsInBands[kNumSub];
+    for (int b = 0; b < kNumSub; ++b) {
+      const int StartBin = (b == 0) ? FirstBin : TMath::d2iRound(sBandFrequencies[b - 1] / FrequenciesPerBin);
+      const int EndBin = TMath::d2iRound(sBandFrequencies[b] / FrequenciesPerBin);
+      NumberOfBinsInBands[b] = EndBin - StartBin + 1;
+    }
+    std::vector<double> Magnitudes(mag, mag + kFft / 2), LastMagnitudes(last, last + kFft / 2);
+    double ContrastSum = 0.0;
+    for (int BandIndex = 0, CurrentBin = FirstBin; BandIndex < kNumSub; ++BandIndex) {
+      const int NumBinsInBand = MMin(NumberOfBinsInBands[BandIndex], (int)Magnitudes.size() - CurrentBin);
+      const double BandMean = TStatistics::Mean(Magnitudes.data() + CurrentBin, NumBinsInBand);
+      double Rms = 0.0;
+      for (int i = 0; i < NumBinsInBand; ++i) Rms += TMathT<double>::Square(Magnitudes[CurrentBin + i]);
+      Rms = ::sqrt(Rms / (double)NumBinsInBand);
+      const double Flatness = SFlatnessDb(Magnitudes.data() + CurrentBin, NumBinsInBand);
+      const double Flux = TStatistics::Flux(Magnitudes.data() + CurrentBin, LastMagnitudes.data() + CurrentBin, NumBinsInBand);
+      double ComplexityThreshold = 0.0;
+      for (int i = 0; i < NumBinsInBand; ++i) ComplexityThreshold = MMax(ComplexityThreshold, Magnitudes[CurrentBin + i]);
+      ComplexityThreshold *= 0.25;
+      double Complexity = 0;
+      if (ComplexityThreshold > 0.0) {
+        for (int i = 0; i < NumBinsInBand; ++i) {
+          const int b = CurrentBin + i;
+          if (mag[b] > ComplexityThreshold) {
+            if (b > 0 && b < (int)Magnitudes.size() - 1 && mag[b] > mag[b - 1] && mag[b] > mag[b + 1]) ++Complexity;
+          }
+        }
+      }
+      std::sort(Magnitudes.begin() + CurrentBin, Magnitudes.begin() + CurrentBin + NumBinsInBand);
+      const int NeighbourBins = MMax(1, (int)(NeighbourRatio * NumBinsInBand));
+      double Sum = 0;
+      for (int i = 0; i < NeighbourBins && i < NumBinsInBand; ++i) Sum += Magnitudes[CurrentBin + i];
+      const double Valley = Sum / NeighbourBins + Epsilon;
+      Sum = 0;
+      for (int i = NumBinsInBand; i > NumBinsInBand - NeighbourBins; --i) Sum += Magnitudes[CurrentBin + i - 1];
+      const double Peak = Sum / NeighbourBins + Epsilon;
+      const double Contrast = -1.0 * ::pow(Peak / Valley, 1.0 / ::log(BandMean + Epsilon));
+      out[oSubRms + BandIndex] = Rms;
+      out[oSubFlat + BandIndex] = Flatness;
+      out[oSubFlux + BandIndex] = Flux;
+      out[oSubCplx + BandIndex] = Complexity;
+      out[oSubContrast + BandIndex] = Contrast;
+      ContrastSum += Contrast;
+      CurrentBin += NumBinsInBand;
+    }
+    out[oContrast] = ContrastSum / kNumSub;
+  }
+
+  // CalcSpectrumBands (2007-2048) -- inline body, restated
+  {
+    static const double sBandFrequencies[] = { 50.0, 100.0, 150.0, 200.0, 300.0, 400.0, 510.0, 630.0,
+      770.0, 920.0, 1080.0, 1270.0, 1480.0, 1720.0, 2000.0, 2320.0, 2700.0, 3150.0, 3700.0, 4400.0,
+      5300.0, 6400.0, 7700.0, 9500.0, 12000.0, 15500.0, 19000.0, 22050.0 };
+    const double FrequenciesPerBin = kSampleRate / kFft;
+    const int FirstBin = TMath::d2iRound(20.0 / FrequenciesPerBin);
+    for (int b = 0; b < kNumBands; ++b) out[oBands + b] = 0.0;
+    for (int b = 0; b < kNumBands; ++b) {
+      int StartBin = TMath::d2iRound((b == 0) ? FirstBin : sBandFrequencies[b - 1] / FrequenciesPerBin);
+      if (StartBin >= kFft / 2) break;
+      int EndBin = TMath::d2iRound(sBandFrequencies[b] / FrequenciesPerBin);
+      EndBin = MMin(kFft / 2, EndBin);
+      for (int s = StartBin; s < EndBin; s++) out[oBands + b] += TMathT<double>::Square(mag[s]);
+    }
+  }
+
+  // CalcCepstrumBands (2052-2063)
+  xtract_mfcc(mag, kFft / 2, &R.mMel, out + oMfcc);
+}
+
+static int CmdTables(const char* path) {
+  TRef R;
+  FILE* f = fopen(path, "wb"); if (!f) return 1;
+  fwrite(R.mpWindow, sizeof(double), kFft, f);
+  for (int k = 0; k < kNumCep; ++k) fwrite(R.mMel.filters[k], sizeof(double), kFft / 2, f);
+  fclose(f);
+  printf("first=%d last=%d count=%d\n", R.mFirstBin, R.mLastBin, R.mBinCount);
+  return 0;
+}
+
+static int CmdFrames(const char* in, const char* outp, bool cap) {
+  TRef R;
+  FILE* fi = fopen(in, "rb"); if (!fi) return 1;
+  int64_t nb = 0; if (fread(&nb, 8, 1, fi) != 1) return 1;
+  std::vector<double> recs;
+  int64_t total = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    int64_t ns = 0; if (fread(&ns, 8, 1, fi) != 1) return 1;
+    std::vector<double> x((size_t)ns);
+    if (ns && fread(x.data(), 8, (size_t)ns, fi) != (size_t)ns) return 1;
+    // SampleAnalyser.cpp:760-764, 814
+    int64_t len = ns;
+    if (cap) len = std::min<int64_t>(len, TAudioMath::MsToSamples(kSampleRate, 1000 * 20));
+    std::vector<double> mag(kFft, 0.0), last(kFft, 0.0);
+    for (int64_t n = 0; (n + kFft - 1) < len; n += kHop) {
+      R.Stft(x.data() + n, mag.data());
+      if (n == 0) last = mag;                    // SampleAnalyser.cpp:937-940
+      recs.resize((size_t)(total + 1) * kRecord);
+      Frame(R, x.data() + n, mag.data(), last.data(), recs.data() + (size_t)total * kRecord);
+      last = mag;                                // SampleAnalyser.cpp:975
+      ++total;
+    }
+  }
+  fclose(fi);
+  FILE* fo = fopen(outp, "wb"); if (!fo) return 1;
+  fwrite(&total, 8, 1, fo);
+  fwrite(recs.data(), 8, recs.size(), fo);
+  fclose(fo);
+  return 0;
+}
+
+// C2 subset timing: window -> FFT -> magnitude -> xtract_mfcc on uniform noise.
+static int CmdTime(int64_t nframes, unsigned seed) {
+  TRef R;
+  std::mt19937 gen(seed);
+  std::uniform_real_distribution<float> U(-1.0f, 1.0f);
+  std::vector<double> x((size_t)(nframes - 1) * kHop + kFft);
+  for (auto& v : x) v = (double)U(gen);
+  std::vector<double> mag(kFft), mf(kNumCep);
+  double acc = 0.0;
+  auto t0 = std::chrono::steady_clock::now();
+  for (int64_t f = 0; f < nframes; ++f) {
+    R.Stft(x.data() + f * kHop, mag.data());
+    xtract_mfcc(mag.data(), kFft / 2, &R.mMel, mf.data());
+    acc += mf[0];
+  }
+  auto t1 = std::chrono::steady_clock::now();
+  const double s = std::chrono::duration<double>(t1 - t0).count();
+  printf("{\"frames\": %lld, \"seconds\": %.6f, \"frames_per_s\": %.3f, \"checksum\": %.9g}\n",
+         (long long)nframes, s, nframes / s, acc);
+  return 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 3 && !strcmp(argv[1], "tables")) return CmdTables(argv[2]);
+  if (argc >= 4 && !strcmp(argv[1], "frames")) return CmdFrames(argv[2], argv[3], argc >= 5 && atoi(argv[4]) != 0);
+  if (argc >= 4 && !strcmp(argv[1], "time")) return CmdTime(atoll(argv[2]), (unsigned)atoi(argv[3]));
+  fprintf(stderr, "usage: ref_driver tables|frames|time ...\n");
+  return 2;
+}

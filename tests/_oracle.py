@@ -1,0 +1,136 @@
+"""ctypes wrapper around oracle/libafx_oracle.so (the CPU parity checker).
+
+Test infrastructure only: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package (afec_amd) never imports this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+RECORD = 1147
+# record layout (oracle/afx_oracle.h)
+FIELDS = {
+    "mag": (0, 1024), "mfcc": (1024, 1038), "spectral_rms": (1038, 1039),
+    "spectral_centroid": (1039, 1040), "spectral_spread": (1040, 1041),
+    "spectral_skewness": (1041, 1042), "spectral_kurtosis": (1042, 1043),
+    "spectral_rolloff": (1043, 1044), "spectral_flatness": (1044, 1045),
+    "spectral_flux": (1045, 1046), "spectrum_bands": (1046, 1074),
+    "sub_rms": (1074, 1088), "sub_flatness": (1088, 1102), "sub_flux": (1102, 1116),
+    "sub_complexity": (1116, 1130), "sub_contrast": (1130, 1144),
+    "spectral_contrast": (1144, 1145), "amplitude_peak": (1145, 1146),
+    "amplitude_rms": (1146, 1147),
+}
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        so = os.path.join(ORACLE_DIR, "libafx_oracle.so")
+        src = os.path.join(ORACLE_DIR, "afx_oracle.c")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "libafx_oracle.so"],
+                                  stdout=subprocess.DEVNULL)
+        L = ctypes.CDLL(so)
+        L.afx_oracle_create.restype = ctypes.c_void_p
+        L.afx_oracle_create.argtypes = [ctypes.c_int] * 3
+        L.afx_oracle_destroy.argtypes = [ctypes.c_void_p]
+        L.afx_oracle_window.restype = ctypes.POINTER(ctypes.c_double)
+        L.afx_oracle_window.argtypes = [ctypes.c_void_p]
+        L.afx_oracle_mel.restype = ctypes.POINTER(ctypes.c_double)
+        L.afx_oracle_mel.argtypes = [ctypes.c_void_p]
+        L.afx_oracle_first_bin.argtypes = [ctypes.c_void_p]
+        L.afx_oracle_bin_count.argtypes = [ctypes.c_void_p]
+        L.afx_oracle_num_frames.restype = ctypes.c_int64
+        L.afx_oracle_num_frames.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+        L.afx_oracle_run.restype = ctypes.c_int64
+        L.afx_oracle_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                     ctypes.c_void_p]
+        L.afx_oracle_run_mfcc.restype = ctypes.c_int64
+        L.afx_oracle_run_mfcc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.c_void_p]
+        dp, ci, cd = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+        for name, args in [("sum", [dp, ci]), ("mean", [dp, ci]), ("variance", [dp, ci, cd]),
+                           ("geometric_mean", [dp, ci]), ("centroid", [dp, ci]),
+                           ("spread", [dp, ci, cd]), ("skewness", [dp, ci, cd, cd]),
+                           ("kurtosis", [dp, ci, cd, cd]), ("flatness", [dp, ci]),
+                           ("flatness_db", [dp, ci]), ("correlation", [dp, dp, ci]),
+                           ("median", [dp, ci]), ("min", [dp, ci]), ("max", [dp, ci]),
+                           ("lin_to_db", [cd])]:
+            fn = getattr(L, "afx_oracle_" + name)
+            fn.restype = ctypes.c_double
+            fn.argtypes = args
+        L.afx_oracle_calc_statistics.argtypes = [dp, ci, dp]
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    def __init__(self, sample_rate=44100, fft=2048, hop=1024):
+        self.L = lib()
+        self.fft, self.hop = fft, hop
+        self.h = ctypes.c_void_p(self.L.afx_oracle_create(sample_rate, fft, hop))
+        assert self.h.value
+
+    def __del__(self):
+        try:
+            self.L.afx_oracle_destroy(self.h)
+        except Exception:
+            pass
+
+    def window(self):
+        return np.ctypeslib.as_array(self.L.afx_oracle_window(self.h), (self.fft,)).copy()
+
+    def mel(self):
+        return np.ctypeslib.as_array(self.L.afx_oracle_mel(self.h), (14 * (self.fft // 2),)).reshape(14, -1).copy()
+
+    def first_bin(self):
+        return self.L.afx_oracle_first_bin(self.h)
+
+    def bin_count(self):
+        return self.L.afx_oracle_bin_count(self.h)
+
+    def num_frames(self, n, cap=False):
+        return int(self.L.afx_oracle_num_frames(self.h, int(n), int(cap)))
+
+    def run(self, x, cap=False):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        nf = self.num_frames(x.size, cap)
+        out = np.zeros((nf, RECORD), dtype=np.float64)
+        if nf:
+            self.L.afx_oracle_run(self.h, x.ctypes.data, x.size, int(cap), out.ctypes.data)
+        return out
+
+    def run_mfcc(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        nf = self.num_frames(x.size, False)
+        out = np.zeros((nf, 14), dtype=np.float64)
+        if nf:
+            self.L.afx_oracle_run_mfcc(self.h, x.ctypes.data, x.size, out.ctypes.data)
+        return out
+
+
+def _vec(x):
+    return np.ascontiguousarray(x, dtype=np.float64)
+
+
+def stat(name, *arrays_and_scalars):
+    """Call afx_oracle_<name>(array..., n, scalars...)."""
+    L = lib()
+    arrs = [_vec(a) for a in arrays_and_scalars if isinstance(a, (list, tuple, np.ndarray))]
+    scal = [a for a in arrays_and_scalars if not isinstance(a, (list, tuple, np.ndarray))]
+    n = arrs[0].size if arrs else 0
+    ptrs = [a.ctypes.data if a.size else None for a in arrs]
+    return getattr(L, "afx_oracle_" + name)(*ptrs, n, *scal)
+
+
+def calc_statistics(x, init=None):
+    x = _vec(x)
+    out = np.zeros(13) if init is None else _vec(init).copy()
+    lib().afx_oracle_calc_statistics(x.ctypes.data if x.size else None, x.size, out.ctypes.data)
+    return out

@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own compiled objects.
+
+Runs only in the build container (needs /root/reference): `make -C oracle ref` compiles the
+reference sources where they lie into oracle/_ref/ref_driver, and this script feeds it the seeded
+signals below.  The fixtures are data (inputs + the reference's outputs); no reference source
+text is stored.  Record layout: oracle/afx_oracle.h (AFXO_*).
+
+    python tests/golden/make_golden.py
+"""
+import os
+import struct
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+SR, FFT, HOP = 44100, 2048, 1024
+NFRAMES = 8
+N = FFT + (NFRAMES - 1) * HOP
+
+
+def signals():
+    """name -> float32 signal (float32 so the GPU path can be fed bit-identical PCM)."""
+    rng = np.random.default_rng(20261003)
+    t = np.arange(N, dtype=np.float64)
+    s = {}
+    s["sine1k"] = np.sin(2 * np.pi * 1000.0 * t / SR)
+    s["sinebin64"] = 0.8 * np.sin(2 * np.pi * 64.0 * t / FFT)
+    s["silence"] = np.zeros(N)
+    imp = np.zeros(N); imp[1500] = 1.0; imp[6000] = -0.5
+    s["impulse"] = imp
+    s["noise"] = rng.uniform(-1.0, 1.0, N)
+    dur = N / SR
+    s["chirp"] = 0.9 * np.sin(2 * np.pi * (20.0 * t / SR + 0.5 * (20000.0 - 20.0) / dur * (t / SR) ** 2))
+    s["square220"] = np.sign(np.sin(2 * np.pi * 220.0 * t / SR + 0.1))
+    s["quiet"] = 1e-5 * rng.uniform(-1.0, 1.0, N)
+    s["dc"] = np.full(N, 0.5)
+    env = np.exp(-t / (0.05 * SR))
+    s["mix"] = (0.4 * np.sin(2 * np.pi * 110.0 * t / SR) + 0.3 * np.sin(2 * np.pi * 1760.0 * t / SR)
+                + 0.25 * env * rng.uniform(-1.0, 1.0, N))
+    lead = np.concatenate([np.zeros(2205), 0.7 * np.sin(2 * np.pi * 440.0 * t[:N - 2205] / SR)])
+    s["lead_silence"] = lead
+    return {k: v.astype(np.float32) for k, v in s.items()}
+
+
+def run_ref(bufs, cap=0):
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<q", len(bufs)))
+            for b in bufs:
+                b = np.asarray(b, dtype=np.float64)
+                f.write(struct.pack("<q", b.size))
+                f.write(b.tobytes())
+        subprocess.check_call([REF, "frames", fin, fout, str(int(cap))])
+        raw = open(fout, "rb").read()
+    n = struct.unpack("<q", raw[:8])[0]
+    return np.frombuffer(raw[8:], dtype=np.float64).reshape(n, 1147).copy()
+
+
+def main():
+    if not os.path.exists(REF):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
+    out = {}
+    for name, x in signals().items():
+        rec = run_ref([x.astype(np.float64)])
+        assert rec.shape == (NFRAMES, 1147), rec.shape
+        out["in_" + name] = x
+        out["ref_" + name] = rec
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "frames.npz"), **out)
+
+    # tables
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "t.bin")
+        subprocess.check_call([REF, "tables", p], stdout=subprocess.DEVNULL)
+        tab = np.fromfile(p, dtype=np.float64)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "tables.npz"),
+                        window=tab[:FFT], mel=tab[FFT:].reshape(14, FFT // 2))
+
+    # frame-count rule incl. the 20 s cap (SampleAnalyser.cpp:760-764, 814)
+    rows = []
+    for n, cap in [(0, 0), (1, 0), (2047, 0), (2048, 0), (2049, 0), (3071, 0), (3072, 0), (4096, 0),
+                   (882000, 1), (882001, 1), (900000, 1), (900000, 0), (883712, 1)]:
+        rec = run_ref([np.zeros(n)], cap)
+        rows.append((n, cap, rec.shape[0]))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "framecount.npz"),
+                        rows=np.array(rows, dtype=np.int64))
+    print("wrote tests/golden/{frames,tables,framecount}.npz")
+
+
+if __name__ == "__main__":
+    sys.exit(main())

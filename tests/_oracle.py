@@ -124,9 +124,12 @@ def stat(name, *arrays_and_scalars):
     L = lib()
     arrs = [_vec(a) for a in arrays_and_scalars if isinstance(a, (list, tuple, np.ndarray))]
     scal = [a for a in arrays_and_scalars if not isinstance(a, (list, tuple, np.ndarray))]
-    n = arrs[0].size if arrs else 0
+    fn = getattr(L, "afx_oracle_" + name)
+    if not arrs:
+        return fn(*scal)
+    n = arrs[0].size
     ptrs = [a.ctypes.data if a.size else None for a in arrs]
-    return getattr(L, "afx_oracle_" + name)(*ptrs, n, *scal)
+    return fn(*ptrs, n, *scal)
 
 
 def calc_statistics(x, init=None):

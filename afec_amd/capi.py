@@ -1,0 +1,276 @@
+"""ctypes binding of include/afx.h (libafx_hip.so).
+
+The library is the only compute path: if it is missing or fails to load this module raises --
+there is no Python or CPU fallback.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "lib", "libafx_hip.so")
+
+D_MFCC = 1 << 0
+D_SPECTRAL_RMS = 1 << 1
+D_SPECTRAL_CENTROID = 1 << 2
+D_SPECTRAL_SPREAD = 1 << 3
+D_SPECTRAL_SKEWNESS = 1 << 4
+D_SPECTRAL_KURTOSIS = 1 << 5
+D_SPECTRAL_ROLLOFF = 1 << 6
+D_SPECTRAL_FLATNESS = 1 << 7
+D_SPECTRAL_FLUX = 1 << 8
+D_SPECTRUM_BANDS = 1 << 9
+D_BAND_FEATURES = 1 << 10
+D_AMPLITUDE_PEAK = 1 << 11
+D_AMPLITUDE_RMS = 1 << 12
+D_MAGNITUDE = 1 << 13
+D_C2 = D_MFCC
+D_SPECTRAL_STATS = 0x1FE
+D_ALL_LOW_LEVEL = 0x1FFF
+PRECISION_F64, PRECISION_F32 = 0, 1
+PCM_F32, PCM_F64 = 0, 1
+
+# every symbol include/afx.h declares (tests check the library exports exactly these)
+EXPORTS = [
+    "afx_status_str", "afx_last_error", "afx_plan_create", "afx_plan_destroy",
+    "afx_plan_get_window", "afx_plan_get_mel_table", "afx_plan_get_bin_range", "afx_num_frames",
+    "afx_extract_batch", "afx_batch_create", "afx_batch_total_frames", "afx_batch_run",
+    "afx_batch_sync", "afx_batch_run_timed", "afx_batch_fetch", "afx_batch_destroy",
+    "afx_algorithmic_bytes_per_frame",
+]
+
+# afx_out fields: name -> width per frame, in declaration order
+OUT_FIELDS = [
+    ("mfcc", 14), ("spectral_rms", 1), ("spectral_centroid", 1), ("spectral_spread", 1),
+    ("spectral_skewness", 1), ("spectral_kurtosis", 1), ("spectral_rolloff", 1),
+    ("spectral_flatness", 1), ("spectral_flux", 1), ("spectrum_bands", 28), ("sub_rms", 14),
+    ("sub_flatness", 14), ("sub_flux", 14), ("sub_complexity", 14), ("sub_contrast", 14),
+    ("spectral_contrast", 1), ("amplitude_peak", 1), ("amplitude_rms", 1), ("magnitude", 1024),
+]
+FIELD_MASK = {
+    "mfcc": D_MFCC, "spectral_rms": D_SPECTRAL_RMS, "spectral_centroid": D_SPECTRAL_CENTROID,
+    "spectral_spread": D_SPECTRAL_SPREAD, "spectral_skewness": D_SPECTRAL_SKEWNESS,
+    "spectral_kurtosis": D_SPECTRAL_KURTOSIS, "spectral_rolloff": D_SPECTRAL_ROLLOFF,
+    "spectral_flatness": D_SPECTRAL_FLATNESS, "spectral_flux": D_SPECTRAL_FLUX,
+    "spectrum_bands": D_SPECTRUM_BANDS, "sub_rms": D_BAND_FEATURES, "sub_flatness": D_BAND_FEATURES,
+    "sub_flux": D_BAND_FEATURES, "sub_complexity": D_BAND_FEATURES, "sub_contrast": D_BAND_FEATURES,
+    "spectral_contrast": D_BAND_FEATURES, "amplitude_peak": D_AMPLITUDE_PEAK,
+    "amplitude_rms": D_AMPLITUDE_RMS, "magnitude": D_MAGNITUDE,
+}
+
+
+class AfxError(RuntimeError):
+    def __init__(self, status, text):
+        super().__init__(f"afx status {status}: {text}")
+        self.status = status
+
+
+class _PlanDesc(ctypes.Structure):
+    _fields_ = [("sample_rate", ctypes.c_int32), ("fft_size", ctypes.c_int32),
+                ("hop_size", ctypes.c_int32), ("device", ctypes.c_int32),
+                ("precision", ctypes.c_int32), ("max_analysis_ms", ctypes.c_int32)]
+
+
+class _Buf(ctypes.Structure):
+    _fields_ = [("pcm", ctypes.c_void_p), ("dtype", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("n_samples", ctypes.c_int64)]
+
+
+class _Out(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n, _ in OUT_FIELDS] + [
+        ("frame_offset", ctypes.c_void_p), ("buf_status", ctypes.c_void_p)]
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def build_library(force=False):
+    """Compile libafx_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    src_dir = os.path.join(_HERE, "csrc")
+    args = ["make", "-C", src_dir]
+    if force:
+        args.append("-B")
+    subprocess.check_call(args, stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise ImportError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is the only compute path; there is no fallback)")
+    L = ctypes.CDLL(_LIB_PATH)
+    vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
+    L.afx_status_str.restype = ctypes.c_char_p
+    L.afx_status_str.argtypes = [ctypes.c_int]
+    L.afx_last_error.restype = ctypes.c_char_p
+    L.afx_plan_create.argtypes = [ctypes.POINTER(_PlanDesc), ctypes.POINTER(vp)]
+    L.afx_plan_destroy.argtypes = [vp]
+    L.afx_plan_destroy.restype = None
+    L.afx_plan_get_window.argtypes = [vp, vp]
+    L.afx_plan_get_mel_table.argtypes = [vp, vp]
+    L.afx_plan_get_bin_range.argtypes = [vp, ctypes.POINTER(i32), ctypes.POINTER(i32)]
+    L.afx_num_frames.restype = i64
+    L.afx_num_frames.argtypes = [vp, i64]
+    L.afx_extract_batch.argtypes = [vp, ctypes.POINTER(_Buf), i32, u32, ctypes.POINTER(_Out)]
+    L.afx_batch_create.argtypes = [vp, ctypes.POINTER(_Buf), i32, u32, ctypes.POINTER(vp)]
+    L.afx_batch_total_frames.restype = i64
+    L.afx_batch_total_frames.argtypes = [vp]
+    L.afx_batch_run.argtypes = [vp]
+    L.afx_batch_sync.argtypes = [vp]
+    L.afx_batch_run_timed.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
+    L.afx_batch_fetch.argtypes = [vp, ctypes.POINTER(_Out)]
+    L.afx_batch_destroy.argtypes = [vp]
+    L.afx_batch_destroy.restype = None
+    L.afx_algorithmic_bytes_per_frame.restype = i64
+    L.afx_algorithmic_bytes_per_frame.argtypes = [vp, u32, i32]
+    _lib = L
+    return L
+
+
+def _check(L, st):
+    if st != 0:
+        raise AfxError(st, (L.afx_status_str(st) or b"").decode() + ": " + (L.afx_last_error() or b"").decode())
+
+
+def _pack_bufs(bufs):
+    """list of 1-D float32/float64 arrays -> (ctypes array of afx_buf, keep-alive list)."""
+    keep = []
+    arr = (_Buf * max(1, len(bufs)))()
+    for i, b in enumerate(bufs):
+        b = np.asarray(b)
+        if b.dtype == np.float32:
+            dt = PCM_F32
+        elif b.dtype == np.float64:
+            dt = PCM_F64
+        else:
+            raise TypeError("PCM buffers must be float32 or float64")
+        b = np.ascontiguousarray(b.reshape(-1))
+        keep.append(b)
+        arr[i].pcm = b.ctypes.data if b.size else None
+        arr[i].dtype = dt
+        arr[i].n_samples = b.size
+    return arr, keep
+
+
+def _alloc_out(mask, total_frames, n_bufs):
+    out = _Out()
+    res = {}
+    for name, width in OUT_FIELDS:
+        if mask & FIELD_MASK[name]:
+            a = np.zeros((total_frames, width) if width > 1 else (total_frames,), dtype=np.float64)
+            res[name] = a
+            setattr(out, name, a.ctypes.data if a.size else None)
+    fo = np.zeros(n_bufs + 1, dtype=np.int64)
+    bs = np.zeros(max(1, n_bufs), dtype=np.int32)
+    out.frame_offset = fo.ctypes.data
+    out.buf_status = bs.ctypes.data
+    res["frame_offset"] = fo
+    res["buf_status"] = bs[:n_bufs]
+    return out, res
+
+
+class Plan:
+    """afx_plan: the analogue of constructing TSampleAnalyser(44100, 2048, 1024)."""
+
+    def __init__(self, sample_rate=44100, fft_size=2048, hop_size=1024, device=0,
+                 precision=PRECISION_F64, max_analysis_ms=20000):
+        self.L = load_library()
+        d = _PlanDesc(sample_rate, fft_size, hop_size, device, precision, max_analysis_ms)
+        h = ctypes.c_void_p()
+        _check(self.L, self.L.afx_plan_create(ctypes.byref(d), ctypes.byref(h)))
+        self.h = h
+        self.fft_size, self.hop_size, self.precision = fft_size, hop_size, precision
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.afx_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def window(self):
+        a = np.zeros(self.fft_size)
+        _check(self.L, self.L.afx_plan_get_window(self.h, a.ctypes.data))
+        return a
+
+    def mel_table(self):
+        a = np.zeros((14, self.fft_size // 2))
+        _check(self.L, self.L.afx_plan_get_mel_table(self.h, a.ctypes.data))
+        return a
+
+    def bin_range(self):
+        f, c = ctypes.c_int32(), ctypes.c_int32()
+        _check(self.L, self.L.afx_plan_get_bin_range(self.h, ctypes.byref(f), ctypes.byref(c)))
+        return f.value, c.value
+
+    def num_frames(self, n_samples):
+        return int(self.L.afx_num_frames(self.h, int(n_samples)))
+
+    def bytes_per_frame(self, mask, pcm_dtype=PCM_F32):
+        return int(self.L.afx_algorithmic_bytes_per_frame(self.h, mask, pcm_dtype))
+
+    def extract(self, bufs, mask=D_ALL_LOW_LEVEL):
+        """One-shot afx_extract_batch on host buffers; returns dict of numpy arrays."""
+        arr, keep = _pack_bufs(bufs)
+        total = sum(self.num_frames(b.size) for b in keep)
+        out, res = _alloc_out(mask, total, len(keep))
+        _check(self.L, self.L.afx_extract_batch(self.h, arr, len(keep), mask, ctypes.byref(out)))
+        del keep
+        return res
+
+    def batch(self, bufs, mask=D_ALL_LOW_LEVEL):
+        return Batch(self, bufs, mask)
+
+
+class Batch:
+    """afx_batch: PCM resident in HBM, re-runnable."""
+
+    def __init__(self, plan, bufs, mask):
+        self.plan, self.L, self.mask = plan, plan.L, mask
+        arr, keep = _pack_bufs(bufs)
+        self.n_bufs = len(keep)
+        h = ctypes.c_void_p()
+        _check(self.L, self.L.afx_batch_create(plan.h, arr, self.n_bufs, mask, ctypes.byref(h)))
+        self.h = h
+        self.total_frames = int(self.L.afx_batch_total_frames(h))
+
+    def run(self):
+        _check(self.L, self.L.afx_batch_run(self.h))
+
+    def sync(self):
+        _check(self.L, self.L.afx_batch_sync(self.h))
+
+    def run_timed(self, steps):
+        """steps launches bracketed by HIP events on the batch stream -> elapsed ms."""
+        ms = ctypes.c_float()
+        _check(self.L, self.L.afx_batch_run_timed(self.h, steps, ctypes.byref(ms)))
+        return ms.value
+
+    def fetch(self):
+        out, res = _alloc_out(self.mask, self.total_frames, self.n_bufs)
+        _check(self.L, self.L.afx_batch_fetch(self.h, ctypes.byref(out)))
+        return res
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.afx_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,583 @@
+// afec_amd/csrc/afx_capi.cpp -- host side of libafx_hip.so: plans, batches and the C-ABI of
+// include/afx.h.  Everything that computes a descriptor runs in afx_kernels.hip on the GPU; this
+// file only builds the constant tables (the analogue of the TSampleAnalyser constructor,
+// SampleAnalyser.cpp:162-198), packs buffers into an HBM arena, cuts the frame loop
+// (SampleAnalyser.cpp:760-764, 814) into per-wave chunks and moves results.
+
+#include "../../include/afx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "afx_internal.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int status, const std::string& msg) {
+  g_last_error = msg;
+  return status;
+}
+int hip_fail(hipError_t e, const char* what) {
+  return fail(AFX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr)                                  \
+  do {                                                 \
+    hipError_t e_ = (expr);                            \
+    if (e_ != hipSuccess) return hip_fail(e_, #expr);  \
+  } while (0)
+
+// TMath::d2iRound (CoreTypes/Export/InlineMath.inl:823-826): truncate(x + sign(x)/2)
+int d2i_round(double v) { return (int)(v + ((v < 0.0) ? -0.5 : 0.5)); }
+// TAudioMath::MsToSamples (AudioTypes/Export/AudioMath.inl:125-128), float arithmetic
+int ms_to_samples(int rate, float ms) {
+  const float v = (float)rate / 1000.0f * ms;
+  return (int)(v + ((v < 0.0f) ? -0.5f : 0.5f));
+}
+
+// Hann window of LibXtract (window.c:67-76: denominator N-1), times 2 (SampleAnalyser.cpp:178-181)
+std::vector<double> build_window(int n) {
+  std::vector<double> w(n);
+  const double M = n - 1;
+  for (int i = 0; i < n; ++i) w[i] = 0.5 * (1.0 - std::cos(2.0 * M_PI * (double)i / M));
+  for (int i = 0; i < n; ++i) w[i] *= 2.0;
+  return w;
+}
+
+// Mel filter bank exactly as xtract_init_mfcc builds it for XTRACT_EQUAL_GAIN (LibXtract
+// init.c:237-382), called with N = fft/2 and nyquist = sample_rate/2 (SampleAnalyser.cpp:195-197):
+// peaks are placed with M = N >> 1 and truncated to int, the first rise divides by fft_peak[0] == 0
+// and the bin cursor runs on from one filter into the next.
+std::vector<double> build_mel(int N, double nyquist, double fmin, double fmax, int nb) {
+  std::vector<double> tab((size_t)nb * N, 0.0);
+  const double mel_hi = 1127 * std::log(1 + fmax / 700);
+  const double mel_lo = 1127 * std::log(1 + fmin / 700);
+  const double step = (mel_hi - mel_lo) / nb;
+  std::vector<double> mel(nb + 2), lin(nb + 2);
+  std::vector<int> peak(nb + 2);
+  const int M = N >> 1;
+  mel[0] = mel_lo;
+  lin[0] = fmin;
+  peak[0] = (int)(lin[0] / nyquist * M);
+  for (int n = 1; n < nb + 2; ++n) {
+    mel[n] = mel[n - 1] + step;
+    lin[n] = 700 * (std::exp(mel[n] / 1127) - 1);
+    peak[n] = (int)(lin[n] / nyquist * M);
+  }
+  int cursor = 0;
+  for (int n = 0; n < nb; ++n) {
+    double* row = tab.data() + (size_t)n * N;
+    const double height = 1.0;
+    double inc = (n == 0) ? height / peak[n] : height / (peak[n] - peak[n - 1]);
+    double val = 0;
+    for (int k = 0; k < cursor; ++k) row[k] = 0.0;
+    for (; cursor <= peak[n]; ++cursor) {
+      row[cursor] = val;
+      val += inc;
+    }
+    inc = height / (peak[n + 1] - peak[n]);
+    val = 0;
+    for (cursor = peak[n + 1]; cursor > peak[n]; --cursor) {
+      row[cursor] = val;
+      val += inc;
+    }
+    for (int k = peak[n + 1] + 1; k < N; ++k) row[k] = 0.0;
+  }
+  return tab;
+}
+
+template <typename T>
+struct cpx {
+  T re, im;
+};
+
+// e^{-2 pi i e / n}, evaluated in long double and reduced to the first octant for accuracy
+template <typename T>
+cpx<T> twiddle(long long e, long long n) {
+  e %= n;
+  if (e < 0) e += n;
+  const long double ang = -2.0L * 3.14159265358979323846264338327950288L * (long double)e / (long double)n;
+  return {(T)std::cos(ang), (T)std::sin(ang)};
+}
+
+struct DeviceTables {
+  void* win = nullptr;
+  void* t1 = nullptr;
+  void* t2 = nullptr;
+  void* post = nullptr;
+  double* melw = nullptr;
+  double* dct = nullptr;
+};
+
+}  // namespace
+
+struct afx_plan {
+  afx_plan_desc desc;
+  int first_bin, last_bin, bin_count;
+  std::vector<double> window;  // [fft]
+  std::vector<double> mel;     // [14][fft/2]
+  DeviceTables dev;
+  int cu_count = 256;
+};
+
+struct afx_batch {
+  afx_plan* plan = nullptr;
+  uint32_t mask = 0;
+  int pcm_dtype = AFX_PCM_F32;
+  int32_t n_bufs = 0;
+  std::vector<int64_t> frame_offset;  // [n_bufs+1]
+  std::vector<int32_t> buf_status;    // [n_bufs]
+  int64_t total_frames = 0;
+  int n_chunks = 0;
+  int grid_blocks = 0;
+  afx::RecordLayout lay{};
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  void* d_pcm = nullptr;
+  afx::Chunk* d_chunks = nullptr;
+  double* d_rec = nullptr;
+  double* d_mag = nullptr;
+  int32_t* d_prev = nullptr;
+  bool mag_wanted = false;
+};
+
+namespace {
+
+template <typename T>
+int upload_tables_typed(afx_plan* p) {
+  using C = cpx<T>;
+  const int fft = p->desc.fft_size;
+  std::vector<C> win(1024), t1(64), t2(1024), post(1024);
+  for (int r = 0; r < 16; ++r)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int n = 64 * r + lane;
+      // 1/fft: kDivFwdByN (Fourier.cpp:265-270); 1/2: even/odd untangle of the half-size FFT
+      win[n] = {(T)(p->window[2 * n] / (2.0 * fft)), (T)(p->window[2 * n + 1] / (2.0 * fft))};
+      post[n] = twiddle<T>(lane + 64 * r, 2048);
+    }
+  for (int j1 = 0; j1 < 16; ++j1)
+    for (int m2 = 0; m2 < 4; ++m2) t1[4 * j1 + m2] = twiddle<T>((long long)m2 * j1, 64);
+  for (int g = 0; g < 16; ++g)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int j2 = g >> 2, q = g & 3, j1 = lane >> 2, h = lane & 3;
+      t2[64 * g + lane] = twiddle<T>((long long)(4 * h + q) * (j1 + 16 * j2), 1024);
+    }
+  auto up = [](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  HIP_TRY(up(&p->dev.win, win.data(), win.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.t1, t1.data(), t1.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.t2, t2.data(), t2.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.post, post.data(), post.size() * sizeof(C)));
+  return AFX_OK;
+}
+
+int upload_tables(afx_plan* p) {
+  int st = (p->desc.precision == AFX_PRECISION_F64) ? upload_tables_typed<double>(p)
+                                                    : upload_tables_typed<float>(p);
+  if (st != AFX_OK) return st;
+  // packed mel rows: one 64-lane row per (r, f) pair the static cover lists
+  std::vector<double> melw((size_t)afx::kMelPairs * 64, 0.0);
+  int idx = 0;
+  for (int r = 0; r < afx::kMelRows; ++r)
+    for (int f = 0; f < afx::kNumCep; ++f)
+      if (afx::mel_touches(f, r)) {
+        for (int lane = 0; lane < 64; ++lane)
+          melw[(size_t)idx * 64 + lane] = p->mel[(size_t)f * afx::kHalf + 64 * r + lane];
+        ++idx;
+      }
+  // DCT-II basis exactly as xtract_dct evaluates it (vector.c:381-385)
+  std::vector<double> dct(14 * 16, 0.0);
+  for (int n = 0; n < 14; ++n)
+    for (int m = 1; m <= 14; ++m) dct[16 * n + (m - 1)] = std::cos(M_PI * (n / (double)14) * (m - 0.5));
+  HIP_TRY(hipMalloc((void**)&p->dev.melw, melw.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(p->dev.melw, melw.data(), melw.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(hipMalloc((void**)&p->dev.dct, dct.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(p->dev.dct, dct.data(), dct.size() * sizeof(double), hipMemcpyHostToDevice));
+  return AFX_OK;
+}
+
+void free_tables(afx_plan* p) {
+  hipFree(p->dev.win); hipFree(p->dev.t1); hipFree(p->dev.t2); hipFree(p->dev.post);
+  hipFree(p->dev.melw); hipFree(p->dev.dct);
+  p->dev = DeviceTables{};
+}
+
+afx::RecordLayout make_layout(uint32_t mask) {
+  afx::RecordLayout l;
+  int32_t* f = &l.mfcc;
+  for (int i = 0; i < 18; ++i) f[i] = -1;
+  int off = 0;
+  auto take = [&](bool on, int32_t& field, int width) {
+    if (on) { field = off; off += width; }
+  };
+  take(mask & AFX_D_MFCC, l.mfcc, 14);
+  take(mask & AFX_D_SPECTRAL_RMS, l.srms, 1);
+  take(mask & AFX_D_SPECTRAL_CENTROID, l.centroid, 1);
+  take(mask & AFX_D_SPECTRAL_SPREAD, l.spread, 1);
+  take(mask & AFX_D_SPECTRAL_SKEWNESS, l.skew, 1);
+  take(mask & AFX_D_SPECTRAL_KURTOSIS, l.kurt, 1);
+  take(mask & AFX_D_SPECTRAL_ROLLOFF, l.rolloff, 1);
+  take(mask & AFX_D_SPECTRAL_FLATNESS, l.flatness, 1);
+  take(mask & AFX_D_SPECTRAL_FLUX, l.flux, 1);
+  take(mask & AFX_D_SPECTRUM_BANDS, l.bands, 28);
+  take(mask & AFX_D_AMPLITUDE_PEAK, l.amp_peak, 1);
+  take(mask & AFX_D_AMPLITUDE_RMS, l.amp_rms, 1);
+  const bool bf = (mask & AFX_D_BAND_FEATURES) != 0;
+  take(bf, l.sub_rms, 14);
+  take(bf, l.sub_flat, 14);
+  take(bf, l.sub_flux, 14);
+  take(bf, l.sub_cplx, 14);
+  take(bf, l.sub_contrast, 14);
+  take(bf, l.contrast, 1);
+  l.stride = off;
+  return l;
+}
+
+int64_t num_frames(const afx_plan* p, int64_t n_samples) {
+  int64_t len = n_samples;
+  if (p->desc.max_analysis_ms > 0) {
+    const int64_t cap = ms_to_samples(p->desc.sample_rate, (float)p->desc.max_analysis_ms);
+    len = std::min(len, cap);
+  }
+  if (len < p->desc.fft_size) return 0;
+  return (len - p->desc.fft_size) / p->desc.hop_size + 1;  // SampleAnalyser.cpp:814
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* afx_status_str(int status) {
+  switch (status) {
+    case AFX_OK: return "ok";
+    case AFX_ERR_INVALID_ARG: return "invalid argument";
+    case AFX_ERR_UNSUPPORTED: return "unsupported plan geometry";
+    case AFX_ERR_NO_DEVICE: return "no HIP device";
+    case AFX_ERR_OUT_OF_MEMORY: return "out of memory";
+    case AFX_ERR_HIP: return "HIP runtime error";
+    case AFX_ERR_BAD_BUFFER: return "bad buffer";
+    default: return "unknown status";
+  }
+}
+
+const char* afx_last_error(void) { return g_last_error.c_str(); }
+
+int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
+  if (!desc || !out_plan) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  *out_plan = nullptr;
+  if (desc->sample_rate <= 0 || desc->fft_size <= 0 || desc->hop_size <= 0 ||
+      (desc->fft_size & (desc->fft_size - 1)) || desc->max_analysis_ms < 0 ||
+      (desc->precision != AFX_PRECISION_F64 && desc->precision != AFX_PRECISION_F32))
+    return fail(AFX_ERR_INVALID_ARG, "bad plan descriptor");
+  if (desc->sample_rate != afx::kSampleRate || desc->fft_size != afx::kFft || desc->hop_size != afx::kHop)
+    return fail(AFX_ERR_UNSUPPORTED,
+                "the HIP kernels are specialised for 44100 Hz / 2048 / 1024 (Crawler.cpp:41-43)");
+  int n_dev = 0;
+  if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+    return fail(AFX_ERR_NO_DEVICE, "no HIP device visible (this library has no CPU path)");
+  if (desc->device < 0 || desc->device >= n_dev) return fail(AFX_ERR_NO_DEVICE, "device ordinal out of range");
+
+  afx_plan* p = new (std::nothrow) afx_plan();
+  if (!p) return fail(AFX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  p->desc = *desc;
+  // SampleAnalyser.cpp:171-175: (int / int) stored in a double
+  const double fpb = (double)(desc->sample_rate / desc->fft_size);
+  p->first_bin = d2i_round(20.0 / fpb);
+  p->last_bin = d2i_round(15500.0 / fpb);
+  p->bin_count = p->last_bin - p->first_bin + 1;
+  p->window = build_window(desc->fft_size);
+  p->mel = build_mel(desc->fft_size / 2, (double)(desc->sample_rate / 2), 20.0, 15500.0, afx::kNumCep);
+
+  // the kernels' static structure must cover the tables just built
+  bool ok = (p->first_bin == afx::kFirstBin && p->last_bin == afx::kLastBin);
+  for (int f = 0; f < afx::kNumCep && ok; ++f)
+    for (int k = 0; k < afx::kHalf; ++k)
+      if (p->mel[(size_t)f * afx::kHalf + k] != 0.0 && (k < afx::kMelLo[f] || k > afx::kMelHi[f])) ok = false;
+  if (!ok) {
+    delete p;
+    return fail(AFX_ERR_UNSUPPORTED, "mel table / bin range outside the kernels' static cover");
+  }
+
+  hipError_t e = hipSetDevice(desc->device);
+  if (e != hipSuccess) { delete p; return hip_fail(e, "hipSetDevice"); }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess) p->cu_count = prop.multiProcessorCount;
+  const int st = upload_tables(p);
+  if (st != AFX_OK) { free_tables(p); delete p; return st; }
+  *out_plan = p;
+  return AFX_OK;
+}
+
+void afx_plan_destroy(afx_plan* plan) {
+  if (!plan) return;
+  hipSetDevice(plan->desc.device);
+  free_tables(plan);
+  delete plan;
+}
+
+int afx_plan_get_window(const afx_plan* plan, double* out) {
+  if (!plan || !out) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  std::memcpy(out, plan->window.data(), plan->window.size() * sizeof(double));
+  return AFX_OK;
+}
+int afx_plan_get_mel_table(const afx_plan* plan, double* out) {
+  if (!plan || !out) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  std::memcpy(out, plan->mel.data(), plan->mel.size() * sizeof(double));
+  return AFX_OK;
+}
+int afx_plan_get_bin_range(const afx_plan* plan, int32_t* first_bin, int32_t* bin_count) {
+  if (!plan) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  if (first_bin) *first_bin = plan->first_bin;
+  if (bin_count) *bin_count = plan->bin_count;
+  return AFX_OK;
+}
+
+int64_t afx_num_frames(const afx_plan* plan, int64_t n_samples) {
+  if (!plan || n_samples < 0) return 0;
+  return num_frames(plan, n_samples);
+}
+
+int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int32_t pcm_dtype) {
+  if (!plan) return 0;
+  const int64_t in = (int64_t)plan->desc.hop_size * (pcm_dtype == AFX_PCM_F64 ? 8 : 4);
+  int64_t out = (int64_t)make_layout(mask).stride * 8;
+  if (mask & AFX_D_MAGNITUDE) out += (int64_t)afx::kHalf * 8;
+  return in + out;
+}
+
+int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask,
+                     afx_batch** out_batch) {
+  if (!plan || !out_batch || n_bufs < 0 || (n_bufs > 0 && !bufs))
+    return fail(AFX_ERR_INVALID_ARG, "null argument");
+  *out_batch = nullptr;
+  if (mask == 0 || (mask & ~(uint32_t)(AFX_D_ALL_LOW_LEVEL | AFX_D_MAGNITUDE)))
+    return fail(AFX_ERR_INVALID_ARG, "bad descriptor mask");
+  HIP_TRY(hipSetDevice(plan->desc.device));
+
+  afx_batch* b = new (std::nothrow) afx_batch();
+  if (!b) return fail(AFX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  b->plan = plan;
+  b->mask = mask;
+  b->n_bufs = n_bufs;
+  b->lay = make_layout(mask);
+  b->mag_wanted = (mask & (AFX_D_MAGNITUDE | AFX_D_BAND_FEATURES)) != 0;
+  b->frame_offset.assign((size_t)n_bufs + 1, 0);
+  b->buf_status.assign((size_t)n_bufs, AFX_OK);
+
+  // one PCM dtype per batch (the arena is homogeneous); first valid buffer decides
+  int dtype = -1;
+  for (int i = 0; i < n_bufs; ++i) {
+    const afx_buf& s = bufs[i];
+    const bool good = s.n_samples >= 0 && (s.n_samples == 0 || s.pcm) &&
+                      (s.dtype == AFX_PCM_F32 || s.dtype == AFX_PCM_F64);
+    if (!good) { b->buf_status[i] = AFX_ERR_BAD_BUFFER; continue; }
+    if (dtype < 0) dtype = s.dtype;
+    if (s.dtype != dtype) b->buf_status[i] = AFX_ERR_BAD_BUFFER;
+  }
+  if (dtype < 0) dtype = AFX_PCM_F32;
+  b->pcm_dtype = dtype;
+  const size_t esz = (dtype == AFX_PCM_F64) ? 8 : 4;
+
+  // arena offsets: every buffer starts on a 16-byte boundary and only the analysed prefix
+  // (SampleAnalyser.cpp:760-764) of buffers that yield at least one frame is uploaded
+  std::vector<int64_t> arena_off((size_t)n_bufs, 0), used((size_t)n_bufs, 0);
+  int64_t arena = 0, frames = 0;
+  for (int i = 0; i < n_bufs; ++i) {
+    b->frame_offset[i] = frames;
+    if (b->buf_status[i] != AFX_OK) continue;
+    const int64_t f = num_frames(plan, bufs[i].n_samples);
+    if (f > 0) {
+      used[i] = (f - 1) * plan->desc.hop_size + plan->desc.fft_size;
+      arena_off[i] = arena;
+      arena += (used[i] + 3) & ~(int64_t)3;
+      frames += f;
+    }
+  }
+  b->frame_offset[n_bufs] = frames;
+  b->total_frames = frames;
+  if (frames > 0x7FFFFF00LL) { delete b; return fail(AFX_ERR_INVALID_ARG, "more than 2^31 frames in one batch"); }
+
+  // chunking: K consecutive frames per wave; enough chunks to fill the chip, long enough to
+  // amortise the 2048-sample lead-in of each chunk
+  const int64_t target_waves = (int64_t)plan->cu_count * 16;
+  int K = (int)std::min<int64_t>(32, std::max<int64_t>(4, frames / std::max<int64_t>(1, target_waves)));
+  const bool need_prev = (mask & AFX_D_SPECTRAL_FLUX) != 0;
+  std::vector<afx::Chunk> chunks;
+  for (int i = 0; i < n_bufs; ++i) {
+    const int64_t f = b->frame_offset[i + 1] - b->frame_offset[i];
+    for (int64_t f0 = 0; f0 < f; f0 += K) {
+      afx::Chunk c;
+      const bool first = (f0 == 0);
+      const bool preroll = need_prev && !first;
+      c.sample_off = arena_off[i] + (f0 - (preroll ? 1 : 0)) * plan->desc.hop_size;
+      c.frame0 = (int32_t)(b->frame_offset[i] + f0);
+      c.nframes = (int16_t)std::min<int64_t>(K, f - f0);
+      c.flags = (int16_t)((first ? afx::kChunkFirstOfBuffer : 0) | (preroll ? afx::kChunkPreroll : 0));
+      chunks.push_back(c);
+    }
+  }
+  b->n_chunks = (int)chunks.size();
+  const int waves_per_block = afx::frames_block_threads() / 64;
+  b->grid_blocks = (int)std::min<int64_t>((b->n_chunks + waves_per_block - 1) / waves_per_block,
+                                          (int64_t)plan->cu_count * 8);
+  if (b->grid_blocks < 1) b->grid_blocks = 1;
+
+  auto cleanup = [&](int st) { afx_batch_destroy(b); return st; };
+  hipError_t e;
+  if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamCreate"));
+  if ((e = hipEventCreate(&b->ev0)) != hipSuccess) return cleanup(hip_fail(e, "hipEventCreate"));
+  if ((e = hipEventCreate(&b->ev1)) != hipSuccess) return cleanup(hip_fail(e, "hipEventCreate"));
+  if (arena > 0) {
+    // +16 KiB tail so the unconditional next-hop prefetch of the last frame stays inside the arena
+    if ((e = hipMalloc(&b->d_pcm, (size_t)arena * esz + 16384)) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(pcm)"));
+    if ((e = hipMemsetAsync(b->d_pcm, 0, (size_t)arena * esz + 16384, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemset"));
+    for (int i = 0; i < n_bufs; ++i)
+      if (used[i] > 0) {
+        e = hipMemcpyAsync((char*)b->d_pcm + (size_t)arena_off[i] * esz, bufs[i].pcm, (size_t)used[i] * esz,
+                           hipMemcpyHostToDevice, b->stream);
+        if (e != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(pcm)"));
+      }
+  }
+  if (b->n_chunks > 0) {
+    if ((e = hipMalloc((void**)&b->d_chunks, chunks.size() * sizeof(afx::Chunk))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(chunks)"));
+    if ((e = hipMemcpyAsync(b->d_chunks, chunks.data(), chunks.size() * sizeof(afx::Chunk), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(chunks)"));
+  }
+  if (frames > 0 && b->lay.stride > 0) {
+    if ((e = hipMalloc((void**)&b->d_rec, (size_t)frames * b->lay.stride * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rec)"));
+  }
+  if (frames > 0 && b->mag_wanted) {
+    if ((e = hipMalloc((void**)&b->d_mag, (size_t)frames * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(mag)"));
+  }
+  if (frames > 0 && (mask & AFX_D_BAND_FEATURES)) {
+    std::vector<int32_t> prev((size_t)frames);
+    for (int i = 0; i < n_bufs; ++i)
+      for (int64_t f = b->frame_offset[i]; f < b->frame_offset[i + 1]; ++f)
+        prev[(size_t)f] = (int32_t)((f == b->frame_offset[i]) ? f : f - 1);  // SampleAnalyser.cpp:937-940
+    if ((e = hipMalloc((void**)&b->d_prev, prev.size() * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(prev)"));
+    if ((e = hipMemcpyAsync(b->d_prev, prev.data(), prev.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(prev)"));
+  }
+  if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
+  *out_batch = b;
+  return AFX_OK;
+}
+
+int64_t afx_batch_total_frames(const afx_batch* batch) { return batch ? batch->total_frames : 0; }
+
+int afx_batch_run(afx_batch* b) {
+  if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
+  if (b->total_frames == 0) return AFX_OK;
+  HIP_TRY(hipSetDevice(b->plan->desc.device));
+  afx::FrameArgs a{};
+  a.pcm = b->d_pcm;
+  a.chunks = b->d_chunks;
+  a.n_chunks = b->n_chunks;
+  a.mask = b->mask;
+  a.rec = b->d_rec;
+  a.lay = b->lay;
+  a.mag_out = b->d_mag;
+  const DeviceTables& t = b->plan->dev;
+  a.win = t.win; a.t1 = t.t1; a.t2 = t.t2; a.post = t.post; a.melw = t.melw; a.dct = t.dct;
+  HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
+  if (b->mask & AFX_D_BAND_FEATURES) {
+    afx::BandArgs ba{};
+    ba.mag = b->d_mag; ba.prev = b->d_prev; ba.n_frames = b->total_frames; ba.rec = b->d_rec; ba.lay = b->lay;
+    HIP_TRY(afx::launch_bands(ba, b->stream));
+  }
+  return AFX_OK;
+}
+
+int afx_batch_sync(afx_batch* b) {
+  if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return AFX_OK;
+}
+
+int afx_batch_run_timed(afx_batch* b, int32_t steps, float* elapsed_ms) {
+  if (!b || steps < 1 || !elapsed_ms) return fail(AFX_ERR_INVALID_ARG, "bad argument");
+  HIP_TRY(hipSetDevice(b->plan->desc.device));
+  HIP_TRY(hipEventRecord(b->ev0, b->stream));
+  for (int i = 0; i < steps; ++i) {
+    const int st = afx_batch_run(b);
+    if (st != AFX_OK) return st;
+  }
+  HIP_TRY(hipEventRecord(b->ev1, b->stream));
+  HIP_TRY(hipEventSynchronize(b->ev1));
+  HIP_TRY(hipEventElapsedTime(elapsed_ms, b->ev0, b->ev1));
+  return AFX_OK;
+}
+
+int afx_batch_fetch(afx_batch* b, afx_out* out) {
+  if (!b || !out) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  HIP_TRY(hipSetDevice(b->plan->desc.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (out->frame_offset) std::memcpy(out->frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t));
+  if (out->buf_status) std::memcpy(out->buf_status, b->buf_status.data(), b->buf_status.size() * sizeof(int32_t));
+  const int64_t F = b->total_frames;
+  if (F == 0) return AFX_OK;
+  const afx::RecordLayout& l = b->lay;
+  struct Field { double* dst; int32_t off; int width; };
+  const Field fields[] = {
+      {out->mfcc, l.mfcc, 14}, {out->spectral_rms, l.srms, 1}, {out->spectral_centroid, l.centroid, 1},
+      {out->spectral_spread, l.spread, 1}, {out->spectral_skewness, l.skew, 1},
+      {out->spectral_kurtosis, l.kurt, 1}, {out->spectral_rolloff, l.rolloff, 1},
+      {out->spectral_flatness, l.flatness, 1}, {out->spectral_flux, l.flux, 1},
+      {out->spectrum_bands, l.bands, 28}, {out->amplitude_peak, l.amp_peak, 1},
+      {out->amplitude_rms, l.amp_rms, 1}, {out->sub_rms, l.sub_rms, 14}, {out->sub_flatness, l.sub_flat, 14},
+      {out->sub_flux, l.sub_flux, 14}, {out->sub_complexity, l.sub_cplx, 14},
+      {out->sub_contrast, l.sub_contrast, 14}, {out->spectral_contrast, l.contrast, 1}};
+  for (const Field& f : fields)
+    if (f.dst && f.off < 0) return fail(AFX_ERR_INVALID_ARG, "output requested that is not in the batch mask");
+  if (out->magnitude && !(b->mask & AFX_D_MAGNITUDE)) return fail(AFX_ERR_INVALID_ARG, "magnitude not in the batch mask");
+  if (l.stride > 0) {
+    std::vector<double> rec((size_t)F * l.stride);
+    HIP_TRY(hipMemcpy(rec.data(), b->d_rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (const Field& f : fields) {
+      if (!f.dst) continue;
+      for (int64_t i = 0; i < F; ++i)
+        std::memcpy(f.dst + i * f.width, rec.data() + i * l.stride + f.off, (size_t)f.width * sizeof(double));
+    }
+  }
+  if (out->magnitude)
+    HIP_TRY(hipMemcpy(out->magnitude, b->d_mag, (size_t)F * afx::kHalf * sizeof(double), hipMemcpyDeviceToHost));
+  return AFX_OK;
+}
+
+void afx_batch_destroy(afx_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->plan->desc.device);
+  if (b->stream) hipStreamSynchronize(b->stream);
+  hipFree(b->d_pcm); hipFree(b->d_chunks); hipFree(b->d_rec); hipFree(b->d_mag); hipFree(b->d_prev);
+  if (b->ev0) hipEventDestroy(b->ev0);
+  if (b->ev1) hipEventDestroy(b->ev1);
+  if (b->stream) hipStreamDestroy(b->stream);
+  delete b;
+}
+
+int afx_extract_batch(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask, afx_out* out) {
+  if (!out) return fail(AFX_ERR_INVALID_ARG, "null output");
+  afx_batch* b = nullptr;
+  int st = afx_batch_create(plan, bufs, n_bufs, mask, &b);
+  if (st != AFX_OK) return st;
+  st = afx_batch_run(b);
+  if (st == AFX_OK) st = afx_batch_fetch(b, out);
+  afx_batch_destroy(b);
+  return st;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+// afec_amd/csrc/afx_internal.h -- shared between the C-ABI host code and the HIP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace afx {
+
+// Geometry the kernels are specialised for: the only one the reference ever instantiates
+// (Crawler.cpp:41-43, 599-600): 44.1 kHz, 2048-sample frame, 1024 hop.
+constexpr int kSampleRate = 44100;
+constexpr int kFft = 2048;
+constexpr int kHop = 1024;
+constexpr int kHalf = kFft / 2;   // magnitude bins used (SampleAnalyser.cpp:837-838)
+constexpr int kNumCep = 14;       // SampleDescriptors.h:464
+constexpr int kNumBands = 28;
+constexpr int kNumSub = 14;
+// SampleAnalyser.cpp:171-175 with integer division 44100/2048 = 21
+constexpr int kFirstBin = 1;
+constexpr int kLastBin = 738;
+constexpr int kBinCount = 738;
+
+// mel filter support on the 1024-bin grid (LibXtract init.c:237-382 with M = N>>1, measured from
+// the table the plan builds; afx_plan_create re-verifies the runtime table against this cover)
+constexpr int kMelLo[kNumCep] = {1, 1, 5, 10, 17, 25, 35, 48, 64, 83, 108, 139, 177, 225};
+constexpr int kMelHi[kNumCep] = {3, 8, 15, 23, 33, 46, 62, 81, 106, 137, 175, 223, 283, 358};
+constexpr int kMelRows = 6;       // bins 0..383 = rows r = 0..5 of the [r][lane] layout
+
+// does mel filter f touch row r (bins 64r .. 64r+63)?
+constexpr bool mel_touches(int f, int r) { return kMelLo[f] <= 64 * r + 63 && kMelHi[f] >= 64 * r; }
+constexpr int mel_pair_count() {
+  int n = 0;
+  for (int r = 0; r < kMelRows; ++r)
+    for (int f = 0; f < kNumCep; ++f) n += mel_touches(f, r) ? 1 : 0;
+  return n;
+}
+constexpr int kMelPairs = mel_pair_count();  // 22
+// index of pair (r, f) in the packed weight table
+constexpr int mel_pair_index(int r, int f) {
+  int n = 0;
+  for (int rr = 0; rr < kMelRows; ++rr)
+    for (int ff = 0; ff < kNumCep; ++ff) {
+      if (rr == r && ff == f) return n;
+      n += mel_touches(ff, rr) ? 1 : 0;
+    }
+  return -1;
+}
+
+// 28 "frequency_bands" edges in bins: round(f/21) of SampleAnalyser.cpp:2015-2019, first start =
+// bin 1, last end clamped to 1024 (SampleAnalyser.cpp:2029-2040)
+constexpr int kBandEdge[kNumBands + 1] = {1, 2, 5, 7, 10, 14, 19, 24, 30, 37, 44, 51, 60, 70, 82,
+                                          95, 110, 129, 150, 176, 210, 252, 305, 367, 452, 571, 738,
+                                          905, 1024};
+constexpr bool band_touches(int b, int r) {
+  return kBandEdge[b] <= 64 * r + 63 && kBandEdge[b + 1] - 1 >= 64 * r;
+}
+
+// chunk = a run of consecutive frames of one buffer processed by one wave
+struct Chunk {
+  int64_t sample_off;  // offset of the first processed frame's first sample in the PCM arena
+  int32_t frame0;      // global output row of the first *emitted* frame
+  int16_t nframes;     // emitted frames
+  int16_t flags;
+};
+enum { kChunkFirstOfBuffer = 1, kChunkPreroll = 2 };
+
+// per-frame output record: offsets in doubles, -1 = not selected
+struct RecordLayout {
+  int32_t stride;
+  int32_t mfcc, srms, centroid, spread, skew, kurt, rolloff, flatness, flux, bands, amp_peak,
+      amp_rms, sub_rms, sub_flat, sub_flux, sub_cplx, sub_contrast, contrast;
+};
+
+struct FrameArgs {
+  const void* pcm;
+  const Chunk* chunks;
+  int32_t n_chunks;
+  uint32_t mask;
+  double* rec;
+  RecordLayout lay;
+  double* mag_out;   // [F][1024] or nullptr
+  const void* win;   // [16][64] pairs (w[2n], w[2n+1]) / 4096, n = 64 r + lane      (T)
+  const void* t1;    // [16][4] complex  w64^(m2*j1)                                  (T)
+  const void* t2;    // [16][64] complex w1024^((4h+q)*(j1+16*j2)), reg=4*j2+q, lane=4*j1+h (T)
+  const void* post;  // [16][64] complex w2048^(lane+64r)                             (T)
+  const double* melw;  // [kMelPairs][64]
+  const double* dct;   // [14][16]: cos(pi * (n/14) * (m + 0.5)), m < 14
+};
+
+// launchers (afx_kernels.hip).  precision: 0 = f64, 1 = f32; pcm_dtype: AFX_PCM_*
+hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int grid_blocks,
+                         hipStream_t stream);
+int frames_block_threads();
+int frames_lds_bytes(int precision);
+
+// band-feature kernel (SampleAnalyser.cpp:2067-2308) working from stored magnitudes
+struct BandArgs {
+  const double* mag;    // [F][1024]
+  const int32_t* prev;  // [F] row of the previous frame of the same buffer (own row for frame 0)
+  int64_t n_frames;
+  double* rec;          // same per-frame records the frame kernel writes
+  RecordLayout lay;
+};
+hipError_t launch_bands(const BandArgs& a, hipStream_t stream);
+
+}  // namespace afx

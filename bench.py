@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- audio frames/s of the low-level spectral hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "C2"): 2048/1024 STFT + 14-coefficient MFCC on synthetic
+44.1 kHz mono float32 PCM, U(-1,1) from MT19937(1234 + rank): `--buffers` buffers of exactly
+10 000 frames each per GPU.  One *step* = one pass of the HIP path over that whole batch, PCM
+already resident in HBM.  N>1: one process per GPU (torchrun), every rank owns its own batch
+(files are sharded, no data-path collective) -> weak scaling; value = frames all ranks processed
+/ max-over-ranks time.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+import afec_amd as afx  # noqa: E402  (loads nothing GPU-side until a Plan is created)
+
+FRAMES_PER_BUFFER = 10000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s achievable
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--buffers", type=int, default=64, help="10k-frame buffers per GPU per step")
+    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--mask", default="c2", choices=["c2", "stats", "all"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-frames", type=int, default=30000, help="frames per CPU worker for the baseline")
+    return ap.parse_args()
+
+
+def make_buffers(n_buffers, seed):
+    n = (FRAMES_PER_BUFFER - 1) * 1024 + 2048
+    rng = np.random.Generator(np.random.MT19937(seed))
+    bufs = []
+    for _ in range(n_buffers):
+        x = rng.random(n, dtype=np.float32)
+        x *= 2.0
+        x -= 1.0
+        bufs.append(x)
+    return bufs
+
+
+def dist_setup(n_gpus):
+    """Returns (rank, world, local_rank, dist or None).  N>1 runs under torchrun."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world <= 1:
+        return 0, 1, 0, None
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    # replicas only: the collective is a barrier and a max over ranks of one float on the host
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    return rank, world, local, dist
+
+
+def reduce_max_sum(dist, seconds, frames):
+    if dist is None:
+        return seconds, frames
+    import torch
+    t = torch.tensor([seconds], dtype=torch.float64)
+    f = torch.tensor([float(frames)], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(f, op=dist.ReduceOp.SUM)
+    return float(t.item()), float(f.item())
+
+
+def cpu_baseline(frames_per_worker):
+    """The reference CPU path timed on this host: oracle/_ref/ref_driver (the reference's own
+    objects, kind "reference") when present, else the oracle restatement (kind "port").  One
+    worker process per host core, the analogue of the crawler's one-file-per-task thread pool
+    (Crawler.cpp:706-728)."""
+    cores = max(1, min(os.cpu_count() or 1, 64))
+    ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
+    t0 = time.perf_counter()
+    if os.path.exists(ref) and os.access(ref, os.X_OK):
+        procs = [subprocess.Popen([ref, "time", str(frames_per_worker), str(1234 + i)],
+                                  stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for i in range(cores)]
+        outs = [p.communicate()[0] for p in procs]
+        ok = all(p.returncode == 0 for p in procs)
+        dt = time.perf_counter() - t0
+        if ok:
+            per = [json.loads(o.decode())["frames_per_s"] for o in outs]
+            return {"value": cores * frames_per_worker / dt, "unit": "frames/s", "cores": cores, "kind": "reference",
+                    "sample": f"{cores} processes x {frames_per_worker} frames of U(-1,1), window+FFT+magnitude+xtract_mfcc "
+                              f"via the reference's own objects (oracle/_ref/ref_driver time)",
+                    "single_thread_frames_per_s": float(np.median(per))}
+    # port: the oracle restatement through ctypes in worker processes
+    import multiprocessing as mp
+    t0 = time.perf_counter()
+    with mp.get_context("spawn").Pool(cores) as pool:
+        pool.map(_oracle_worker, [(frames_per_worker, 1234 + i) for i in range(cores)])
+    dt = time.perf_counter() - t0
+    return {"value": cores * frames_per_worker / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes x {frames_per_worker} frames of U(-1,1), STFT+MFCC via oracle/afx_oracle.c"}
+
+
+def _oracle_worker(arg):
+    frames, seed = arg
+    from tests._oracle import Oracle
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, (frames - 1) * 1024 + 2048)
+    return float(Oracle().run_mfcc(x)[0, 0])
+
+
+def measured_traffic(precision, mask_name):
+    """HBM bytes per launch from the committed PMC profile, when one matches this config."""
+    p = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(p):
+        return None
+    try:
+        t = json.load(open(p))
+        return t.get(f"{mask_name}_{precision}")
+    except Exception:
+        return None
+
+
+def main():
+    args = parse_args()
+    rank, world, local, dist = dist_setup(args.gpus)
+    if world != max(1, args.gpus) and rank == 0:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+
+    mask = {"c2": afx.D_C2, "stats": afx.D_MFCC | afx.D_SPECTRAL_STATS,
+            "all": afx.D_ALL_LOW_LEVEL & ~afx.D_BAND_FEATURES}[args.mask]
+    precision = afx.PRECISION_F64 if args.precision == "f64" else afx.PRECISION_F32
+    plan = afx.Plan(device=local, precision=precision, max_analysis_ms=0)
+    bufs = make_buffers(args.buffers, 1234 + rank)
+    batch = plan.batch(bufs, mask)
+    del bufs
+    frames = batch.total_frames
+    bytes_per_frame = plan.bytes_per_frame(mask, afx.PCM_F32)
+
+    for _ in range(args.warmup):
+        batch.run()
+    batch.sync()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ev_ms = batch.run_timed(args.steps)   # K launches bracketed by HIP events on the launch stream; syncs
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    seconds, frames_all = reduce_max_sum(dist, t1 - t0, frames)
+
+    if rank == 0:
+        launch_ms = ev_ms / args.steps
+        achieved = bytes_per_frame * frames / (launch_ms * 1e-3) / 1e9
+        out = {
+            "metric": "audio frames/sec low-level crawl, 44.1kHz 1024-hop",
+            "value": frames_all * args.steps / seconds,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": seconds / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.precision,
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2 x{args.buffers}: 2048/1024 STFT + 14-coef MFCC, {args.buffers} mono float32 "
+                            f"buffers of {FRAMES_PER_BUFFER} frames per GPU, U(-1,1) MT19937"
+                            if args.mask == "c2" else f"{args.mask} descriptor set, {args.buffers} x {FRAMES_PER_BUFFER} frames",
+                "frames_per_gpu_per_step": frames,
+                "pcm": "f32 resident in HBM",
+                "parallelism": f"replicas x{world} (buffers sharded, no collective)",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": measured_traffic(args.precision, args.mask),
+                "kernel": "frames_kernel",
+                "algorithmic_bytes_per_frame": bytes_per_frame,
+                "launch_ms": launch_ms,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+        print(json.dumps(out))
+    batch.close()
+    plan.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,166 @@
+/* include/afx.h -- C-ABI of the MI355X low-level audio feature extractor (libafx_hip.so).
+ *
+ * This is the drop-in boundary for the per-frame spectral loop of AFEC's
+ * TSampleAnalyser::AnalyzeLowLevelDescriptors
+ * (Source/Crawler/FeatureExtraction/Source/SampleAnalyser.cpp:814-976).  The reference has no FFI
+ * for this path (the loop body is private member code, Export/SampleAnalyser.h:65-211); the entry
+ * points below are what a maintainer binds from that function -- see INTEGRATION.md for the
+ * reference-side stub.  Plain C types only: no torch, no C++ types, no exceptions cross this ABI.
+ *
+ * Every entry point runs on the GPU (HIP, gfx950).  There is no CPU fallback: if no HIP device is
+ * present afx_plan_create fails with AFX_ERR_NO_DEVICE.
+ */
+#ifndef AFX_H
+#define AFX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFX_VERSION 1
+
+/* ---- status codes (replace TReadableException on this path, SampleAnalyser.cpp:397-408) ---- */
+enum {
+  AFX_OK = 0,
+  AFX_ERR_INVALID_ARG = -1,
+  AFX_ERR_UNSUPPORTED = -2, /* plan geometry the HIP kernels are not specialised for        */
+  AFX_ERR_NO_DEVICE = -3,   /* no HIP device / device ordinal out of range                  */
+  AFX_ERR_OUT_OF_MEMORY = -4,
+  AFX_ERR_HIP = -5,         /* a HIP runtime call failed; afx_last_error() has the text      */
+  AFX_ERR_BAD_BUFFER = -6   /* per-buffer status: NULL pcm / negative length / unknown dtype */
+};
+const char* afx_status_str(int status);
+const char* afx_last_error(void); /* thread-local detail text of the last failing call */
+
+/* ---- PCM sample types of afx_buf.dtype ---- */
+enum {
+  AFX_PCM_F32 = 0, /* float, nominal range [-1, 1]  */
+  AFX_PCM_F64 = 1  /* double, as TSampleData::mData (Export/SampleAnalyser.h:86-88) */
+};
+
+/* ---- internal arithmetic of the STFT ---- */
+enum {
+  AFX_PRECISION_F64 = 0, /* default: IEEE double end to end, like the reference             */
+  AFX_PRECISION_F32 = 1  /* float butterflies, double descriptor accumulation (see DESIGN.md
+                            for the input class on which this meets the 1e-4 bar)           */
+};
+
+/* ---- descriptor selection (bit mask) ---- *
+ * Names follow TSampleDescriptors (Export/SampleDescriptors.h:407-465).                      */
+enum {
+  AFX_D_MFCC = 1u << 0,              /* cepstrum_bands      [F][14]  SampleAnalyser.cpp:2052-2063 */
+  AFX_D_SPECTRAL_RMS = 1u << 1,      /* spectral_rms        [F]      :1808-1818 */
+  AFX_D_SPECTRAL_CENTROID = 1u << 2, /* spectral_centroid   [F]      :1822-1837 */
+  AFX_D_SPECTRAL_SPREAD = 1u << 3,   /* spectral_spread     [F]      :1822-1837 */
+  AFX_D_SPECTRAL_SKEWNESS = 1u << 4, /* spectral_skewness   [F]      :1858-1883 */
+  AFX_D_SPECTRAL_KURTOSIS = 1u << 5, /* spectral_kurtosis   [F]      :1858-1883 */
+  AFX_D_SPECTRAL_ROLLOFF = 1u << 6,  /* spectral_rolloff    [F]      :1887-1901 */
+  AFX_D_SPECTRAL_FLATNESS = 1u << 7, /* spectral_flatness   [F]      :1905-1915 */
+  AFX_D_SPECTRAL_FLUX = 1u << 8,     /* spectral_flux       [F]      :1919-1933 */
+  AFX_D_SPECTRUM_BANDS = 1u << 9,    /* frequency_bands     [F][28]  :2007-2048 */
+  AFX_D_BAND_FEATURES = 1u << 10,    /* spectral_{rms,flatness,flux,complexity,contrast}_bands
+                                        [F][14] each + spectral_contrast [F]  :2067-2308 */
+  AFX_D_AMPLITUDE_PEAK = 1u << 11,   /* amplitude_peak      [F]      :1760-1770 */
+  AFX_D_AMPLITUDE_RMS = 1u << 12,    /* amplitude_rms       [F]      :1774-1783 */
+  AFX_D_MAGNITUDE = 1u << 13,        /* magnitude spectrum  [F][1024] for CPU-resident consumers
+                                        (whitening, pitch; SampleAnalyser.cpp:850-927)        */
+  AFX_D_C2 = AFX_D_MFCC,
+  AFX_D_SPECTRAL_STATS = 0x1FEu,     /* bits 1..8 */
+  AFX_D_ALL_LOW_LEVEL = 0x1FFFu      /* everything except the raw magnitudes */
+};
+#define AFX_NUM_CEPSTRUM 14 /* kNumberOfCepstrumCoefficients, SampleDescriptors.h:464 */
+#define AFX_NUM_BANDS 28    /* kNumberOfSpectrumBands                                  */
+#define AFX_NUM_SUBBANDS 14 /* kNumberOfSpectrumSubBands                               */
+
+/* ---- plan: immutable analyser state, the analogue of the TSampleAnalyser ctor ---- *
+ * (SampleAnalyser.cpp:162-198: analysis bin range, 2x Hann window, LibXtract mel table).
+ * Safe to share between threads; every batch carries its own stream and workspace.        */
+typedef struct afx_plan afx_plan;
+
+typedef struct {
+  int32_t sample_rate;     /* 44100 (Crawler.cpp:41)                                          */
+  int32_t fft_size;        /* 2048  (Crawler.cpp:42)                                          */
+  int32_t hop_size;        /* 1024  (Crawler.cpp:43)                                          */
+  int32_t device;          /* HIP device ordinal                                              */
+  int32_t precision;       /* AFX_PRECISION_*                                                 */
+  int32_t max_analysis_ms; /* MAnalyzationDurationMaxInMs = 20000 (SampleAnalyser.cpp:37);
+                              0 disables the cap (synthetic benchmarks)                       */
+} afx_plan_desc;
+
+int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan);
+void afx_plan_destroy(afx_plan* plan);
+
+/* introspection used by the parity tests (tables must equal LibXtract's bit for bit) */
+int afx_plan_get_window(const afx_plan* plan, double* out /* [fft_size] */);
+int afx_plan_get_mel_table(const afx_plan* plan, double* out /* [14][fft_size/2] */);
+int afx_plan_get_bin_range(const afx_plan* plan, int32_t* first_bin, int32_t* bin_count);
+
+/* frames the reference loop produces for n_samples (SampleAnalyser.cpp:760-764, 814) */
+int64_t afx_num_frames(const afx_plan* plan, int64_t n_samples);
+
+/* ---- input / output ---- */
+typedef struct {
+  const void* pcm;   /* host pointer, mono, AFX_PCM_* */
+  int32_t dtype;
+  int32_t reserved;
+  int64_t n_samples;
+} afx_buf;
+
+/* Caller-allocated host arrays of doubles, row-major by frame over the whole batch (frames of
+ * buffer i occupy rows frame_offset[i] .. frame_offset[i+1]-1), the layout of
+ * TFramedScalarData::mValues / TFramedVectorData<W>::mValues (SampleDescriptors.h:152-356).
+ * Any pointer may be NULL (not wanted); non-NULL pointers must be selected in the mask.     */
+typedef struct {
+  double* mfcc;              /* [F][14]   */
+  double* spectral_rms;      /* [F]       */
+  double* spectral_centroid; /* [F]       */
+  double* spectral_spread;
+  double* spectral_skewness;
+  double* spectral_kurtosis;
+  double* spectral_rolloff;
+  double* spectral_flatness;
+  double* spectral_flux;
+  double* spectrum_bands;    /* [F][28]   */
+  double* sub_rms;           /* [F][14]   */
+  double* sub_flatness;      /* [F][14]   */
+  double* sub_flux;          /* [F][14]   */
+  double* sub_complexity;    /* [F][14]   */
+  double* sub_contrast;      /* [F][14]   */
+  double* spectral_contrast; /* [F]       */
+  double* amplitude_peak;    /* [F]       */
+  double* amplitude_rms;     /* [F]       */
+  double* magnitude;         /* [F][1024] */
+  int64_t* frame_offset;     /* [n_bufs+1], optional */
+  int32_t* buf_status;       /* [n_bufs], optional: AFX_OK or AFX_ERR_BAD_BUFFER (one bad buffer
+                                does not fail the batch, cf. SampleAnalyser.cpp:368-408)      */
+} afx_out;
+
+/* One-shot: upload n_bufs host buffers, run the HIP path, download the selected descriptors.
+ * This is the call TSampleAnalyser::AnalyzeLowLevelDescriptors would make (n_bufs = 1 per file,
+ * or many files per call from a batching crawler).  Thread-safe on a shared plan.            */
+int afx_extract_batch(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask,
+                      afx_out* out);
+
+/* ---- resident batches: PCM stays in HBM across runs (pipelines, benchmarks) ---- */
+typedef struct afx_batch afx_batch;
+
+int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask,
+                     afx_batch** out_batch);            /* allocates + uploads, synchronous   */
+int64_t afx_batch_total_frames(const afx_batch* batch);
+int afx_batch_run(afx_batch* batch);                    /* enqueue one pass on the batch stream */
+int afx_batch_sync(afx_batch* batch);                   /* wait for the batch stream            */
+/* enqueue `steps` passes bracketed by HIP events on the batch stream; returns the elapsed
+ * device time of the bracket in milliseconds (the stream is idle on return)                   */
+int afx_batch_run_timed(afx_batch* batch, int32_t steps, float* elapsed_ms);
+int afx_batch_fetch(afx_batch* batch, afx_out* out);    /* D2H + unpack, synchronous            */
+void afx_batch_destroy(afx_batch* batch);
+
+/* static facts for roofline accounting (bytes the algorithm must move per frame for `mask`) */
+int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int32_t pcm_dtype);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFX_H */

@@ -1,0 +1,134 @@
+#!/usr/bin/env python3
+"""numpy model of the per-wave STFT dataflow used by afec_amd/csrc/afx_kernels.hip.
+
+One wave (64 lanes x 16 registers) computes the 2048-point real FFT of one frame as a
+1024-point complex FFT (z[n] = x[2n] + i x[2n+1]) in three in-register passes (16 x 4 x 16)
+with two LDS exchanges, then un-tangles even/odd spectra with the (k, 1024-k) partner fetched
+cross-lane.  This script checks the index algebra and the LDS swizzles (bank-conflict rules
+from MI355X_MICROARCH.md) against numpy.fft; it is a design aid, not part of the product.
+"""
+import numpy as np
+
+NL, NR = 64, 16
+N = 1024
+
+
+def w(n, e):  # e^{-2 pi i e / n}
+    return np.exp(-2j * np.pi * (np.asarray(e) % n) / n)
+
+
+def e1_index(j1, m2, h, q):
+    """8-byte slot index for exchange 1 (write: fixed j1, lane=(m2,h,q); read: fixed (m2,q), lane=(j1,h))."""
+    return 4 * j1 + h + 68 * q + 272 * m2   # separable: lane part + static register part
+
+
+def e2_index(j1, j2, h, q):
+    """exchange 2 (write: fixed (j2,q), lane=(j1,h)=4*j1+h; read: fixed (h,q), lane=j1+16*j2)."""
+    return j1 + 16 * j2 + 68 * h + 272 * q
+
+
+def check_conflicts(name, slots, group):
+    """slots[64]: 8-byte slot index per lane for one instruction; group = lanes per LDS cycle."""
+    for g in range(0, 64, group):
+        s = slots[g:g + group] % group
+        assert len(set(s.tolist())) == group, (name, g, sorted(s.tolist()))
+
+
+def fft_wave(z):
+    lane = np.arange(NL)
+    A = np.zeros((NR, NL), complex)
+    for r in range(NR):
+        A[r] = z[64 * r + lane]
+    # P1: 16-point DFT over r
+    B = np.zeros_like(A)
+    for j1 in range(16):
+        for r in range(16):
+            B[j1] += A[r] * w(16, r * j1)
+    m2, n2 = lane >> 4, lane & 15
+    h, q = n2 >> 2, n2 & 3
+    for j1 in range(16):
+        B[j1] *= w(64, m2 * j1)
+    # E1
+    lds = np.zeros(1088, complex)
+    seen = np.zeros(1088, bool)
+    for j1 in range(16):
+        idx = e1_index(j1, m2, h, q)
+        check_conflicts("e1 write", idx, 16)
+        assert not seen[idx].any(); seen[idx] = True
+        lds[idx] = B[j1]
+    assert seen.sum() == 1024
+    lj1, lh = lane >> 2, lane & 3
+    C = np.zeros_like(A)
+    for mm in range(4):
+        for qq in range(4):
+            idx = e1_index(lj1, mm, lh, qq)
+            check_conflicts("e1 read", idx, 32)
+            C[4 * mm + qq] = lds[idx]
+    # P2: 4-point DFT over m2, then twiddle w1024^(n2*k1)
+    D = np.zeros_like(A)
+    for j2 in range(4):
+        for qq in range(4):
+            for mm in range(4):
+                D[4 * j2 + qq] += C[4 * mm + qq] * w(4, mm * j2)
+            k1 = lj1 + 16 * j2
+            nn2 = 4 * lh + qq
+            D[4 * j2 + qq] *= w(1024, nn2 * k1)
+    # E2
+    lds[:] = 0; seen[:] = False
+    for j2 in range(4):
+        for qq in range(4):
+            idx = e2_index(lj1, j2, lh, qq)
+            check_conflicts("e2 write", idx, 16)
+            assert not seen[idx].any(); seen[idx] = True
+            lds[idx] = D[4 * j2 + qq]
+    assert seen.sum() == 1024
+    kj1, kj2 = lane & 15, lane >> 4
+    F = np.zeros_like(A)
+    for hh in range(4):
+        for qq in range(4):
+            idx = e2_index(kj1, kj2, hh, qq)
+            check_conflicts("e2 read", idx, 32)
+            F[4 * hh + qq] = lds[idx]
+    # P3: 16-point DFT over n2 -> Z[lane + 64*k2]
+    G = np.zeros_like(A)
+    for k2 in range(16):
+        for nn2 in range(16):
+            G[k2] += F[nn2] * w(16, nn2 * k2)
+    return G
+
+
+def real_post(G):
+    """X[k] for k = lane + 64 r, with the partner Z[1024-k] fetched cross-lane (E3)."""
+    lane = np.arange(NL)
+    src = (64 - lane) & 63
+    X = np.zeros_like(G)
+    for r in range(NR):
+        P = G[15 - r][src]
+        P[0] = G[(16 - r) & 15][0]
+        Z = G[r]
+        k = lane + 64 * r
+        E = Z + np.conj(P)
+        O = -1j * (Z - np.conj(P))
+        X[r] = E + w(2048, k) * O
+    return X
+
+
+def main():
+    rng = np.random.default_rng(1)
+    z = rng.standard_normal(N) + 1j * rng.standard_normal(N)
+    G = fft_wave(z)
+    ref = np.fft.fft(z)
+    lane = np.arange(NL)
+    for r in range(NR):
+        assert np.allclose(G[r], ref[lane + 64 * r], atol=1e-9), r
+    x = rng.standard_normal(2048)
+    zz = x[0::2] + 1j * x[1::2]
+    X = real_post(fft_wave(zz)) / 2
+    refx = np.fft.fft(x)
+    for r in range(NR):
+        assert np.allclose(X[r], refx[lane + 64 * r], atol=1e-9), r
+    print("dataflow model OK: complex FFT, real post-processing and LDS swizzles verified")
+
+
+if __name__ == "__main__":
+    main()

@@ -415,7 +415,7 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
 
   // chunking: K consecutive frames per wave; enough chunks to fill the chip, long enough to
   // amortise the 2048-sample lead-in of each chunk
-  const int64_t target_waves = (int64_t)plan->cu_count * 16;
+  const int64_t target_waves = (int64_t)plan->cu_count * 64;
   int K = (int)std::min<int64_t>(32, std::max<int64_t>(4, frames / std::max<int64_t>(1, target_waves)));
   const bool need_prev = (mask & AFX_D_SPECTRAL_FLUX) != 0;
   std::vector<afx::Chunk> chunks;
@@ -433,9 +433,11 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
     }
   }
   b->n_chunks = (int)chunks.size();
-  const int waves_per_block = afx::frames_block_threads() / 64;
+  // one workgroup per CU (its LDS holds the shared tables plus one exchange plane per wave);
+  // waves walk the chunk list with a grid stride
+  const int waves_per_block = afx::frames_waves_per_block(plan->desc.precision);
   b->grid_blocks = (int)std::min<int64_t>((b->n_chunks + waves_per_block - 1) / waves_per_block,
-                                          (int64_t)plan->cu_count * 8);
+                                          (int64_t)plan->cu_count);
   if (b->grid_blocks < 1) b->grid_blocks = 1;
 
   auto cleanup = [&](int st) { afx_batch_destroy(b); return st; };

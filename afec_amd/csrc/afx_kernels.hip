@@ -14,9 +14,13 @@
 //   P3        16-point DFT over n2 = 4h+q            -> Z[lane + 64 k2]
 //   E3        partner Z[1024-k] by cross-lane read, even/odd untangle, |X[k]| for k = lane + 64 r
 //
-// then the descriptors straight from the 16 magnitudes per lane.  The index algebra and the LDS
+// then the descriptors straight from the magnitudes in registers.  The index algebra and the LDS
 // maps (conflict-free for ds_write_b64 / ds_read_b64, address = lane part + immediate) are
 // modelled and checked in tools/fft_dataflow_model.py.
+//
+// A workgroup is kWaves independent waves that share the constant tables (window, twiddles, mel
+// rows, DCT basis) in LDS; each wave has a private 8.5 KiB exchange plane.  Waves never
+// synchronise with each other after the table load.
 //
 // What each stage replaces in the reference (SampleAnalyser.cpp = SA):
 //   window+FFT+magnitude  SA:826-845 (xtract_windowed, TFftTransformComplex, TAudioMath::Magnitude)
@@ -32,9 +36,12 @@
 namespace afx {
 namespace {
 
-constexpr int kWavesPerBlock = 4;
-constexpr int kThreads = 64 * kWavesPerBlock;
-constexpr int kLdsSlots = 1088;  // 1024 complex values + padding of the separable swizzle
+constexpr int kLdsSlots = 1088;  // 1024 values + padding of the separable swizzle (8-byte slots)
+
+// feature classes the kernel is specialised for (the host picks the smallest that covers the mask)
+constexpr int kFeatC2 = 0;     // MFCC only: magnitudes of bins 0..383
+constexpr int kFeatStats = 1;  // + rms/centroid/spread/skew/kurt/rolloff/flatness, amplitude: bins 0..767
+constexpr int kFeatFull = 2;   // + flux, 28 bands, magnitude output: all 1024 bins, previous frame kept
 
 template <typename T>
 struct cx {
@@ -86,28 +93,6 @@ __device__ __forceinline__ void dft16(cx<T> (&v)[16]) {
   for (int i = 0; i < 16; ++i) v[i] = t[i];
 }
 
-// LDS view of one wave: complex<float> packs into one 8-byte slot, complex<double> uses two planes
-template <typename T>
-struct Lds;
-template <>
-struct Lds<float> {
-  float2* p;
-  __device__ __forceinline__ void put(int slot, cx<float> v) const { p[slot] = make_float2(v.re, v.im); }
-  __device__ __forceinline__ cx<float> get(int slot) const {
-    const float2 t = p[slot];
-    return {t.x, t.y};
-  }
-};
-template <>
-struct Lds<double> {
-  double* p;
-  __device__ __forceinline__ void put(int slot, cx<double> v) const {
-    p[slot] = v.re;
-    p[kLdsSlots + slot] = v.im;
-  }
-  __device__ __forceinline__ cx<double> get(int slot) const { return {p[slot], p[kLdsSlots + slot]}; }
-};
-
 // orders this wave's LDS traffic for the compiler; the DS unit executes a wave's ops in order
 __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -115,14 +100,79 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ double wave_sum(double v) {
+// ---- cross-lane helpers on doubles: DPP inside a 16-lane row, permlane swaps across rows ----
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
+constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141; // i -> 7 - i inside groups of 8
+constexpr int kDppMirror = 0x140;     // i -> 15 - i inside the row
+constexpr int kDppRor8 = 0x128;       // i -> i ^ 8 inside the row
+
+// x' = (x.lanes[0:32), y.lanes[0:32)), y' = (x.lanes[32:64), y.lanes[32:64))
+__device__ __forceinline__ void swap32(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+  x = __hiloint2double(hi[0], lo[0]);
+  y = __hiloint2double(hi[1], lo[1]);
+}
+// rows of 16: x' = (x0, y0, x2, y2), y' = (x1, y1, x3, y3)
+__device__ __forceinline__ void swap16(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+  x = __hiloint2double(hi[0], lo[0]);
+  y = __hiloint2double(hi[1], lo[1]);
+}
+
+// Sum 16 per-lane values over the wave at once ("transposed" butterfly): on return lane L holds
+// the wave total of a[(L >> 2) & 15].  15 adds + 24 swaps + a few DPP moves instead of 16 x 6 steps.
+__device__ __forceinline__ double wave_sum16(double (&a)[16], int lane) {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  for (int i = 0; i < 8; ++i) {
+    swap32(a[i], a[i + 8]);
+    a[i] += a[i + 8];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    swap16(a[i], a[i + 4]);
+    a[i] += a[i + 4];
+  }
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double keep = b3 ? a[i + 2] : a[i];
+    const double send = b3 ? a[i] : a[i + 2];
+    a[i] = keep + dpp_mov<kDppRor8>(send);
+  }
+  const double keep = b2 ? a[1] : a[0];
+  const double send = b2 ? a[0] : a[1];
+  double z = keep + dpp_mov<kDppHalfMirror>(send);
+  z += dpp_mov<kDppXor2>(z);
+  z += dpp_mov<kDppXor1>(z);
+  return z;
+}
+
+// full-wave sum, result in every lane
+__device__ __forceinline__ double wave_sum(double v) {
+  v += dpp_mov<kDppXor1>(v);
+  v += dpp_mov<kDppXor2>(v);
+  v += dpp_mov<kDppHalfMirror>(v);
+  v += dpp_mov<kDppMirror>(v);
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
   return v;
 }
 __device__ __forceinline__ double wave_max(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+  v = fmax(v, dpp_mov<kDppXor1>(v));
+  v = fmax(v, dpp_mov<kDppXor2>(v));
+  v = fmax(v, dpp_mov<kDppHalfMirror>(v));
+  v = fmax(v, dpp_mov<kDppMirror>(v));
+  v = fmax(v, __shfl_xor(v, 16));
+  v = fmax(v, __shfl_xor(v, 32));
   return v;
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
@@ -160,15 +210,105 @@ __device__ __forceinline__ double lin_to_db(double v) {
   return -200.0;
 }
 
-template <typename T, typename TIn>
-__global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) {
+// ---- LDS layout: shared tables, then one exchange plane per wave ----
+template <typename T>
+struct LdsMap {
+  static constexpr int win = 0;                                    // [16][64] cx<T>
+  static constexpr int t2 = win + 1024 * (int)sizeof(cx<T>);       // [16][64] cx<T>
+  static constexpr int post = t2 + 1024 * (int)sizeof(cx<T>);      // [16][64] cx<T>
+  static constexpr int t1 = post + 1024 * (int)sizeof(cx<T>);      // [16][4]  cx<T>
+  static constexpr int melw = t1 + 64 * (int)sizeof(cx<T>);        // [22][64] double
+  static constexpr int dct = melw + kMelPairs * 64 * 8;            // [14][16] double
+  static constexpr int xchg = dct + 14 * 16 * 8;                   // kWaves x [1088] 8-byte slots
+  static constexpr int plane_bytes = kLdsSlots * 8;
+  static constexpr int total(int waves) { return xchg + waves * plane_bytes; }
+};
+
+__device__ __forceinline__ void copy_to_lds(unsigned char* dst, const void* src, int bytes, int tid, int nthreads) {
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  for (int i = tid; i < bytes / 16; i += nthreads) d[i] = s[i];
+}
+
+// E1/E2 through the wave's plane.  complex<float> is one 8-byte slot; complex<double> goes in two
+// passes (real parts, then imaginary parts) through the same plane.
+template <typename T>
+struct Xchg;
+template <>
+struct Xchg<float> {
+  template <typename WIdx, typename RIdx>
+  static __device__ __forceinline__ void run(unsigned char* plane, cx<float> (&v)[16], WIdx widx, RIdx ridx) {
+    float2* p = reinterpret_cast<float2*>(plane);
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) p[widx(g)] = make_float2(v[g].re, v[g].im);
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) {
+      const float2 t = p[ridx(g)];
+      v[g] = {t.x, t.y};
+    }
+  }
+};
+template <>
+struct Xchg<double> {
+  template <typename WIdx, typename RIdx>
+  static __device__ __forceinline__ void run(unsigned char* plane, cx<double> (&v)[16], WIdx widx, RIdx ridx) {
+    double* p = reinterpret_cast<double*>(plane);
+    double re[16];
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) p[widx(g)] = v[g].re;
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) re[g] = p[ridx(g)];
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) p[widx(g)] = v[g].im;
+    wave_lds_fence();
+#pragma unroll
+    for (int g = 0; g < 16; ++g) v[g] = {re[g], p[ridx(g)]};
+  }
+};
+
+// log + 14-point DCT-II + store for up to four frames whose mel sums sit in lanes 4 f + slot
+__device__ __forceinline__ void finish_mfcc(double acc, int nslots, int64_t row0, const FrameArgs& a,
+                                            const double* dct, int lane) {
+  const double lg = log(acc < 2e-42 ? 2e-42 : acc);  // XTRACT_LOG_LIMIT, vector.c:364
+  const int n = (lane >> 2) & 15, s = lane & 3;
+  const double* drow = dct + 16 * (n < kNumCep ? n : 0);
+  double c = 0.0;
+#pragma unroll
+  for (int m = 0; m < kNumCep; ++m) c += __shfl(lg, 4 * m + s) * drow[m];
+  if (n < kNumCep && s < nslots) a.rec[(row0 + s) * a.lay.stride + a.lay.mfcc + n] = c;
+}
+
+template <typename T, typename TIn, int FEAT, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   using Pair = typename InPair<TIn>::type;
+  using Map = LdsMap<T>;
+  constexpr int MR = (FEAT == kFeatC2) ? kMelRows : (FEAT == kFeatStats ? 12 : 16);
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  Lds<T> lds;
-  lds.p = reinterpret_cast<decltype(lds.p)>(lds_raw + (size_t)wave * kLdsSlots * sizeof(cx<T>));
-  double* const lds_mag = reinterpret_cast<double*>(lds_raw + (size_t)wave * kLdsSlots * sizeof(cx<T>));
+
+  // ---- shared tables ----
+  copy_to_lds(lds_raw + Map::win, a.win, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
+  copy_to_lds(lds_raw + Map::t2, a.t2, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
+  copy_to_lds(lds_raw + Map::post, a.post, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
+  copy_to_lds(lds_raw + Map::t1, a.t1, 64 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
+  copy_to_lds(lds_raw + Map::melw, a.melw, kMelPairs * 64 * 8, threadIdx.x, WAVES * 64);
+  copy_to_lds(lds_raw + Map::dct, a.dct, 14 * 16 * 8, threadIdx.x, WAVES * 64);
+  __syncthreads();
+
+  const cx<T>* const win = reinterpret_cast<const cx<T>*>(lds_raw + Map::win) + lane;
+  const cx<T>* const t2 = reinterpret_cast<const cx<T>*>(lds_raw + Map::t2) + lane;
+  const cx<T>* const post = reinterpret_cast<const cx<T>*>(lds_raw + Map::post) + lane;
+  const cx<T>* const t1 = reinterpret_cast<const cx<T>*>(lds_raw + Map::t1) + (lane >> 4);
+  const double* const melw = reinterpret_cast<const double*>(lds_raw + Map::melw) + lane;
+  const double* const dct = reinterpret_cast<const double*>(lds_raw + Map::dct);
+  unsigned char* const plane = lds_raw + Map::xchg + wave * Map::plane_bytes;
+  double* const lds_mag = reinterpret_cast<double*>(plane);
 
   // lane coordinates of the three layouts
   const int m2 = lane >> 4, h = (lane >> 2) & 3, q = lane & 3;  // P1 layout: lane = 16 m2 + 4 h + q
@@ -179,39 +319,36 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
   const int e2r = lane;                    // + 68 h + 272 q
   const int partner = (64 - lane) & 63;
 
-  const cx<T>* const win = reinterpret_cast<const cx<T>*>(a.win);
-  const cx<T>* const t1 = reinterpret_cast<const cx<T>*>(a.t1);
-  const cx<T>* const t2 = reinterpret_cast<const cx<T>*>(a.t2);
-  const cx<T>* const post = reinterpret_cast<const cx<T>*>(a.post);
   const TIn* const pcm = reinterpret_cast<const TIn*>(a.pcm);
-
-  const int wave_global = blockIdx.x * kWavesPerBlock + wave;
-  const int wave_stride = gridDim.x * kWavesPerBlock;
+  const int wave_global = blockIdx.x * WAVES + wave;
+  const int wave_stride = gridDim.x * WAVES;
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];
-    const TIn* src = pcm + ch.sample_off;
+    const Pair* src = reinterpret_cast<const Pair*>(pcm + ch.sample_off) + lane;
     const bool preroll = (ch.flags & kChunkPreroll) != 0;
     const int total = ch.nframes + (preroll ? 1 : 0);
 
-    Pair raw[16];
+    Pair lo[8], nxt[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) raw[r] = reinterpret_cast<const Pair*>(src)[64 * r + lane];
-    double prev_mag[16];
+    for (int r = 0; r < 8; ++r) lo[r] = src[64 * r];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) prev_mag[r] = 0.0;
+    for (int r = 0; r < 8; ++r) nxt[r] = src[64 * (r + 8)];
+
+    double prev_mag[FEAT == kFeatFull ? 16 : 1];
+#pragma unroll
+    for (int r = 0; r < (FEAT == kFeatFull ? 16 : 1); ++r) prev_mag[r] = 0.0;
+    double mel_acc = 0.0;  // mel sums of up to four finished frames: lane 4 f + slot
+    int pending = 0;
+    int64_t pending_row0 = 0;
 
     for (int fi = 0; fi < total; ++fi) {
-      const TIn* fsrc = src + (size_t)fi * kHop;
-#pragma unroll
-      for (int r = 8; r < 16; ++r) raw[r] = reinterpret_cast<const Pair*>(fsrc)[64 * r + lane];
-
       // ---- time-domain descriptors on the hop = rows 0..7 (SA:871-872) ----
       double amp_peak = 0.0, amp_sq = 0.0;
-      if (a.mask & ((1u << 11) | (1u << 12))) {
+      if (FEAT != kFeatC2 && (a.mask & ((1u << 11) | (1u << 12)))) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          const double x0 = (double)raw[r].x, x1 = (double)raw[r].y;
+          const double x0 = (double)lo[r].x, x1 = (double)lo[r].y;
           amp_peak = fmax(amp_peak, fmax(fabs(x0), fabs(x1)));
           amp_sq += x0 * x0 + x1 * x1;
         }
@@ -219,61 +356,53 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
         amp_sq = wave_sum(amp_sq);
       }
 
-      // ---- window (table already carries the 1/2048 of kDivFwdByN and the 1/2 of the untangle) ----
+      // ---- window (table carries the 1/2048 of kDivFwdByN and the 1/2 of the untangle) ----
       cx<T> v[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const cx<T> w = win[64 * r + lane];
-        v[r] = {(T)raw[r].x * w.re, (T)raw[r].y * w.im};
+      for (int r = 0; r < 8; ++r) {
+        const cx<T> w0 = win[64 * r], w1 = win[64 * (r + 8)];
+        v[r] = {(T)lo[r].x * w0.re, (T)lo[r].y * w0.im};
+        v[r + 8] = {(T)nxt[r].x * w1.re, (T)nxt[r].y * w1.im};
+        lo[r] = nxt[r];
       }
+      // prefetch the next frame's new hop (rows 8..15 of frame fi + 1)
+      if (fi + 1 < total) {
+        const Pair* nsrc = src + (size_t)(fi + 1) * (kHop / 2);
 #pragma unroll
-      for (int r = 0; r < 8; ++r) raw[r] = raw[r + 8];
+        for (int r = 0; r < 8; ++r) nxt[r] = nsrc[64 * (r + 8)];
+      }
 
       // ---- P1 + T1 + E1 ----
       dft16(v);
 #pragma unroll
-      for (int j1 = 1; j1 < 16; ++j1) v[j1] = cmul(v[j1], t1[4 * j1 + m2]);
-      wave_lds_fence();
-#pragma unroll
-      for (int j1 = 0; j1 < 16; ++j1) lds.put(e1w + 4 * j1, v[j1]);
-      wave_lds_fence();
-#pragma unroll
-      for (int mm = 0; mm < 4; ++mm)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) v[4 * mm + qq] = lds.get(e1r + 68 * qq + 272 * mm);
+      for (int j1 = 1; j1 < 16; ++j1) v[j1] = cmul(v[j1], t1[4 * j1]);
+      Xchg<T>::run(plane, v, [&](int j1) { return e1w + 4 * j1; },
+                   [&](int g) { return e1r + 68 * (g & 3) + 272 * (g >> 2); });
 
       // ---- P2 + T2 + E2 ----
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) radix4(v[qq], v[4 + qq], v[8 + qq], v[12 + qq]);
 #pragma unroll
-      for (int g = 0; g < 16; ++g) v[g] = cmul(v[g], t2[64 * g + lane]);
-      wave_lds_fence();
-#pragma unroll
-      for (int j2 = 0; j2 < 4; ++j2)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) lds.put(e2w + 16 * j2 + 272 * qq, v[4 * j2 + qq]);
-      wave_lds_fence();
-#pragma unroll
-      for (int hh = 0; hh < 4; ++hh)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) v[4 * hh + qq] = lds.get(e2r + 68 * hh + 272 * qq);
+      for (int g = 0; g < 16; ++g) v[g] = cmul(v[g], t2[64 * g]);
+      Xchg<T>::run(plane, v, [&](int g) { return e2w + 16 * (g >> 2) + 272 * (g & 3); },
+                   [&](int g) { return e2r + 68 * (g >> 2) + 272 * (g & 3); });
 
       // ---- P3: v[k2] = Z[lane + 64 k2] ----
       dft16(v);
 
       // ---- E3 + untangle + magnitude: mag[r] = |X[lane + 64 r]| ----
-      double mag[16];
+      T mag[MR];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
+      for (int r = 0; r < MR; ++r) {
         cx<T> p{__shfl(v[15 - r].re, partner), __shfl(v[15 - r].im, partner)};
         if (lane == 0) p = v[(16 - r) & 15];
         const cx<T> z = v[r];
-        const cx<T> w = post[64 * r + lane];
+        const cx<T> w = post[64 * r];
         const T er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
         const T orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
         const T xr = er + (w.re * orr - w.im * oi);
         const T xi = ei + (w.re * oi + w.im * orr);
-        mag[r] = (double)sqrt(xr * xr + xi * xi);
+        mag[r] = sqrt(xr * xr + xi * xi);
       }
 
       const bool emit = !(preroll && fi == 0);
@@ -281,37 +410,32 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
       double* const rec = a.rec + row * a.lay.stride;
 
       if (emit) {
-        if (a.mag_out) {
+        if (FEAT == kFeatFull && a.mag_out) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) a.mag_out[row * kHalf + 64 * r + lane] = mag[r];
+          for (int r = 0; r < MR; ++r) a.mag_out[row * kHalf + 64 * r + lane] = (double)mag[r];
         }
 
-        // ---- MFCC: sparse mel rows, log, 14-point DCT-II (vector.c:350-391) ----
-        if (a.mask & 1u) {
-          double e[kNumCep];
+        // ---- MFCC: sparse mel rows now; log + DCT once per four frames (vector.c:350-391) ----
+        if (FEAT == kFeatC2 || (a.mask & 1u)) {
+          double e[16];
 #pragma unroll
-          for (int f = 0; f < kNumCep; ++f) e[f] = 0.0;
+          for (int f = 0; f < 16; ++f) e[f] = 0.0;
 #pragma unroll
           for (int r = 0; r < kMelRows; ++r)
 #pragma unroll
             for (int f = 0; f < kNumCep; ++f)
-              if (mel_touches(f, r)) e[f] += mag[r] * a.melw[64 * mel_pair_index(r, f) + lane];
-          double mine = 0.0;  // lane f keeps log e[f]
-#pragma unroll
-          for (int f = 0; f < kNumCep; ++f) {
-            const double s = wave_sum(e[f]);
-            if ((lane & 15) == f) mine = s;
+              if (mel_touches(f, r)) e[f] += (double)mag[r] * melw[64 * mel_pair_index(r, f)];
+          const double tot = wave_sum16(e, lane);  // lane L: filter (L >> 2) & 15
+          if (pending == 0) pending_row0 = row;
+          if ((lane & 3) == pending) mel_acc = tot;
+          if (++pending == 4) {
+            finish_mfcc(mel_acc, 4, pending_row0, a, dct, lane);
+            pending = 0;
           }
-          mine = log(mine < 2e-42 ? 2e-42 : mine);
-          double c = 0.0;
-          const int n = lane & 15;
-#pragma unroll
-          for (int m = 0; m < kNumCep; ++m) c += __shfl(mine, m) * a.dct[16 * (n < kNumCep ? n : 0) + m];
-          if (lane < kNumCep) rec[a.lay.mfcc + lane] = c;
         }
 
         // ---- spectral statistics over bins 1..738, j = bin - 1 (SA:1808-1933) ----
-        if (a.mask & 0x1FEu) {
+        if (FEAT != kFeatC2 && (a.mask & 0x1FEu)) {
           double s1 = 0.0, s2 = 0.0, sj = 0.0, prod = 1.0;
           double fa = 0.0, fb = 0.0, faa = 0.0, fbb = 0.0, fab = 0.0;
           const bool first = (fi == 0) && !preroll;  // SA:937-940: frame 0 is compared with itself
@@ -319,13 +443,15 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
           for (int r = 0; r < 12; ++r) {
             const int k = 64 * r + lane;
             const bool ok = (r == 0) ? (lane >= kFirstBin) : (r == 11 ? (k <= kLastBin) : true);
-            const double m = ok ? mag[r] : 0.0;
+            const double m = ok ? (double)mag[r] : 0.0;
             s1 += m;
             s2 += m * m;
             sj += (double)(k - kFirstBin) * m;
             prod *= ok ? (m + 1e-20) : 1.0;
-            const double b = first ? m : (ok ? prev_mag[r] : 0.0);
-            fa += m; fb += b; faa += m * m; fbb += b * b; fab += m * b;
+            if (FEAT == kFeatFull) {
+              const double b = first ? m : (ok ? prev_mag[r] : 0.0);
+              fa += m; fb += b; faa += m * m; fbb += b * b; fab += m * b;
+            }
           }
           s1 = wave_sum(s1);
           const double n = (double)kBinCount;
@@ -344,7 +470,7 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
                 const int k = 64 * r + lane;
                 const bool ok = (r == 0) ? (lane >= kFirstBin) : (r == 11 ? (k <= kLastBin) : true);
                 const double t = (double)(k - kFirstBin) - cen;
-                sv += ok ? t * t * mag[r] : 0.0;
+                sv += ok ? t * t * (double)mag[r] : 0.0;
               }
               spr = wave_sum(sv) / s1;
             }
@@ -355,11 +481,12 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
             if (a.mask & 0x30u) {
               double sk = 0.0, ku = 0.0;
               if (fabs(spr) > (double)1e-12f) {
+                const double inv = 1.0 / spr;
 #pragma unroll
                 for (int r = 0; r < 12; ++r) {
                   const int k = 64 * r + lane;
                   const bool ok = (r == 0) ? (lane >= kFirstBin) : (r == 11 ? (k <= kLastBin) : true);
-                  const double t = (mag[r] - cen) / spr;
+                  const double t = ((double)mag[r] - cen) * inv;
                   const double tt = t * t;
                   sk += ok ? tt * t : 0.0;
                   ku += ok ? tt * tt : 0.0;
@@ -381,7 +508,7 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
             const double d = lin_to_db(fl) / -60.0;
             if (lane == 0) rec[a.lay.flatness] = nan_to_zero(d < 1.0 ? d : 1.0);
           }
-          if (a.mask & (1u << 8)) {  // flux = Pearson correlation with the previous frame
+          if (FEAT == kFeatFull && (a.mask & (1u << 8))) {  // flux = Pearson r with the previous frame
             fa = wave_sum(fa); fb = wave_sum(fb); faa = wave_sum(faa); fbb = wave_sum(fbb);
             fab = wave_sum(fab);
             const double ma = fa / n, mb = fb / n;
@@ -394,7 +521,7 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
             // natural-order copy in LDS, then each lane walks 12 consecutive bins
             wave_lds_fence();
 #pragma unroll
-            for (int r = 0; r < 12; ++r) lds_mag[64 * r + lane] = mag[r];
+            for (int r = 0; r < 12; ++r) lds_mag[64 * r + lane] = (double)mag[r];
             wave_lds_fence();
             double seg[12];
             double segsum = 0.0;
@@ -422,58 +549,99 @@ __global__ __launch_bounds__(kThreads, 2) void frames_kernel(const FrameArgs a) 
         }
 
         // ---- 28 spectrum bands: sum of squared magnitudes (SA:2007-2048) ----
-        if (a.mask & (1u << 9)) {
+        if (FEAT == kFeatFull && (a.mask & (1u << 9))) {
           double mine = 0.0;
 #pragma unroll
-          for (int b = 0; b < kNumBands; ++b) {
-            double acc = 0.0;
+          for (int half = 0; half < 2; ++half) {
+            double acc[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-              if (band_touches(b, r)) {
-                const int k = 64 * r + lane;
-                acc += (k >= kBandEdge[b] && k < kBandEdge[b + 1]) ? mag[r] * mag[r] : 0.0;
+            for (int i = 0; i < 16; ++i) {
+              const int b = 16 * half + i;
+              acc[i] = 0.0;
+              if (b < kNumBands) {
+#pragma unroll
+                for (int r = 0; r < MR; ++r)
+                  if (band_touches(b, r)) {
+                    const int k = 64 * r + lane;
+                    const double m = (double)mag[r];
+                    acc[i] += (k >= kBandEdge[b] && k < kBandEdge[b + 1]) ? m * m : 0.0;
+                  }
               }
-            acc = wave_sum(acc);
-            if (lane == b) mine = acc;
+            }
+            const double tot = wave_sum16(acc, lane);  // lane L: band 16 half + ((L >> 2) & 15)
+            if (((lane >> 6) == 0) && ((lane & 3) == half)) mine = tot;
           }
-          if (lane < kNumBands) rec[a.lay.bands + lane] = mine;
+          // lanes with (lane & 3) == half hold band 16 half + (lane >> 2)
+          const int b = 16 * (lane & 3) + (lane >> 2);
+          if ((lane & 3) < 2 && b < kNumBands) rec[a.lay.bands + b] = mine;
         }
 
-        if (lane == 0) {
+        if (FEAT != kFeatC2 && lane == 0) {
           if (a.mask & (1u << 11)) rec[a.lay.amp_peak] = amp_peak;
           if (a.mask & (1u << 12)) rec[a.lay.amp_rms] = nan_to_zero(sqrt(amp_sq / (double)kHop));
         }
       }
+      if (FEAT == kFeatFull) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) prev_mag[r] = mag[r];
+        for (int r = 0; r < 16; ++r) prev_mag[r] = (double)mag[r];
+      }
+    }
+    if (pending > 0) finish_mfcc(mel_acc, pending, pending_row0, a, dct, lane);
+  }
+}
+
+constexpr int kWavesF64 = 8;
+constexpr int kWavesF32 = 8;
+
+template <typename T, typename TIn, int WAVES>
+hipError_t launch_typed(const FrameArgs& a, int feat, int grid_blocks, hipStream_t stream) {
+  const dim3 grid(grid_blocks), block(WAVES * 64);
+  const size_t lds = (size_t)LdsMap<T>::total(WAVES);
+  hipError_t e = hipSuccess;
+  switch (feat) {
+    case kFeatC2: {
+      auto k = frames_kernel<T, TIn, kFeatC2, WAVES>;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+      break;
+    }
+    case kFeatStats: {
+      auto k = frames_kernel<T, TIn, kFeatStats, WAVES>;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+      break;
+    }
+    default: {
+      auto k = frames_kernel<T, TIn, kFeatFull, WAVES>;
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, lds, stream, a);
+      break;
     }
   }
+  if (e != hipSuccess) return e;
+  return hipGetLastError();
 }
 
 }  // namespace
 
-int frames_block_threads() { return kThreads; }
-int frames_lds_bytes(int precision) {
-  return kWavesPerBlock * kLdsSlots * (precision == 0 ? (int)sizeof(cx<double>) : (int)sizeof(cx<float>));
+int frames_waves_per_block(int precision) { return precision == 0 ? kWavesF64 : kWavesF32; }
+
+int frames_feature_class(uint32_t mask) {
+  if (mask == 1u) return kFeatC2;
+  if (mask & ((1u << 8) | (1u << 9) | (1u << 10) | (1u << 13))) return kFeatFull;
+  return kFeatStats;
 }
 
 hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int grid_blocks,
                          hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
-  const dim3 grid(grid_blocks), block(kThreads);
-  const size_t lds = (size_t)frames_lds_bytes(precision);
+  const int feat = frames_feature_class(a.mask);
   if (precision == 0) {
-    if (pcm_dtype == 0)
-      hipLaunchKernelGGL((frames_kernel<double, float>), grid, block, lds, stream, a);
-    else
-      hipLaunchKernelGGL((frames_kernel<double, double>), grid, block, lds, stream, a);
-  } else {
-    if (pcm_dtype == 0)
-      hipLaunchKernelGGL((frames_kernel<float, float>), grid, block, lds, stream, a);
-    else
-      hipLaunchKernelGGL((frames_kernel<float, double>), grid, block, lds, stream, a);
+    return pcm_dtype == 0 ? launch_typed<double, float, kWavesF64>(a, feat, grid_blocks, stream)
+                          : launch_typed<double, double, kWavesF64>(a, feat, grid_blocks, stream);
   }
-  return hipGetLastError();
+  return pcm_dtype == 0 ? launch_typed<float, float, kWavesF32>(a, feat, grid_blocks, stream)
+                        : launch_typed<float, double, kWavesF32>(a, feat, grid_blocks, stream);
 }
 
 hipError_t launch_bands(const BandArgs&, hipStream_t) { return hipErrorNotSupported; }

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "lib", "libafx_hip.so")
+# AFX_LIBRARY selects an alternative build of the same library (kernel tuning experiments)
+_LIB_PATH = os.environ.get("AFX_LIBRARY") or os.path.join(_HERE, "lib", "libafx_hip.so")
 
 D_MFCC = 1 << 0
 D_SPECTRAL_RMS = 1 << 1

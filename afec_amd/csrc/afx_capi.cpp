@@ -435,7 +435,7 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
   b->n_chunks = (int)chunks.size();
   // one workgroup per CU (its LDS holds the shared tables plus one exchange plane per wave);
   // waves walk the chunk list with a grid stride
-  const int waves_per_block = afx::frames_waves_per_block(plan->desc.precision);
+  const int waves_per_block = afx::frames_waves_per_block(mask);
   b->grid_blocks = (int)std::min<int64_t>((b->n_chunks + waves_per_block - 1) / waves_per_block,
                                           (int64_t)plan->cu_count);
   if (b->grid_blocks < 1) b->grid_blocks = 1;

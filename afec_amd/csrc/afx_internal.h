@@ -90,7 +90,7 @@ struct FrameArgs {
 // launchers (afx_kernels.hip).  precision: 0 = f64, 1 = f32; pcm_dtype: AFX_PCM_*
 hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int grid_blocks,
                          hipStream_t stream);
-int frames_waves_per_block(int precision);   // waves (of 64 lanes) per workgroup
+int frames_waves_per_block(uint32_t mask);    // waves (of 64 lanes) per workgroup
 int frames_feature_class(uint32_t mask);     // 0 = MFCC only, 1 = + statistics, 2 = everything
 
 // band-feature kernel (SampleAnalyser.cpp:2067-2308) working from stored magnitudes

@@ -36,6 +36,10 @@
 namespace afx {
 namespace {
 
+#ifndef AFX_WAVES_C2
+#define AFX_WAVES_C2 8
+#endif
+
 constexpr int kLdsSlots = 1088;  // 1024 values + padding of the separable swizzle (8-byte slots)
 
 // feature classes the kernel is specialised for (the host picks the smallest that covers the mask)
@@ -203,6 +207,24 @@ struct InPair<double> {
 
 __device__ __forceinline__ double nan_to_zero(double v) { return (v != v) ? 0.0 : v; }
 
+// sqrt for magnitudes: x >= 0 and far from overflow, so the range scaling of the generic
+// expansion is dropped: one v_rsq_f64 seed, one Goldschmidt step, one residual correction
+// (<= 1 ulp).  Inputs below 1e-290 (|X| < 1e-145) are flushed to 0, like the reference's FTZ/DAZ
+// FFT (AudioMath.cpp:27-36) would long before.
+__device__ __forceinline__ double mag_sqrt(double x) {
+  const double xs = x > 1e-290 ? x : 1e-290;
+  const double r = __builtin_amdgcn_rsq(xs);
+  double g = xs * r;
+  double h = 0.5 * r;
+  const double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  const double d = fma(-g, g, xs);
+  g = fma(d, h, g);
+  return x > 1e-290 ? g : 0.0;
+}
+__device__ __forceinline__ float mag_sqrt(float x) { return sqrtf(x); }
+
 // TAudioMath::LinToDb(double), AudioMath.inl:55-70 (MEpsilon is the float literal 1e-12f)
 __device__ __forceinline__ double lin_to_db(double v) {
   if (v == 1.0) return 0.0;
@@ -211,12 +233,12 @@ __device__ __forceinline__ double lin_to_db(double v) {
 }
 
 // ---- LDS layout: shared tables, then one exchange plane per wave ----
-template <typename T>
+template <typename T, int POST_ROWS>
 struct LdsMap {
   static constexpr int win = 0;                                    // [16][64] cx<T>
   static constexpr int t2 = win + 1024 * (int)sizeof(cx<T>);       // [16][64] cx<T>
-  static constexpr int post = t2 + 1024 * (int)sizeof(cx<T>);      // [16][64] cx<T>
-  static constexpr int t1 = post + 1024 * (int)sizeof(cx<T>);      // [16][4]  cx<T>
+  static constexpr int post = t2 + 1024 * (int)sizeof(cx<T>);      // [POST_ROWS][64] cx<T>
+  static constexpr int t1 = post + POST_ROWS * 64 * (int)sizeof(cx<T>);  // [16][4]  cx<T>
   static constexpr int melw = t1 + 64 * (int)sizeof(cx<T>);        // [22][64] double
   static constexpr int dct = melw + kMelPairs * 64 * 8;            // [14][16] double
   static constexpr int xchg = dct + 14 * 16 * 8;                   // kWaves x [1088] 8-byte slots
@@ -232,42 +254,74 @@ __device__ __forceinline__ void copy_to_lds(unsigned char* dst, const void* src,
 
 // E1/E2 through the wave's plane.  complex<float> is one 8-byte slot; complex<double> goes in two
 // passes (real parts, then imaginary parts) through the same plane.
+// ds_read_b64 with the register part of the address as an immediate.  Written as asm so that the
+// load/store optimizer cannot fuse neighbours into ds_read2_b64 (half the LDS rate per byte on
+// gfx950); the caller waits with lds_wait16 before using the values.
+template <int BYTE_OFF>
+__device__ __forceinline__ double lds_read_b64(unsigned addr) {
+  double d;
+  asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(BYTE_OFF));
+  return d;
+}
+__device__ __forceinline__ void lds_wait16(double (&d)[16]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
+                 "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
+}
+// the two read patterns: E1 reads slot e1r + 68 q + 272 m2 (g = 4 m2 + q), E2 reads e2r + 68 h + 272 q (g = 4 h + q)
+template <int KIND, int G>
+constexpr int read_slot() { return KIND == 1 ? 68 * (G & 3) + 272 * (G >> 2) : 68 * (G >> 2) + 272 * (G & 3); }
+template <int KIND>
+__device__ __forceinline__ void lds_read16(unsigned addr, double (&d)[16]) {
+  d[0] = lds_read_b64<8 * read_slot<KIND, 0>()>(addr);   d[1] = lds_read_b64<8 * read_slot<KIND, 1>()>(addr);
+  d[2] = lds_read_b64<8 * read_slot<KIND, 2>()>(addr);   d[3] = lds_read_b64<8 * read_slot<KIND, 3>()>(addr);
+  d[4] = lds_read_b64<8 * read_slot<KIND, 4>()>(addr);   d[5] = lds_read_b64<8 * read_slot<KIND, 5>()>(addr);
+  d[6] = lds_read_b64<8 * read_slot<KIND, 6>()>(addr);   d[7] = lds_read_b64<8 * read_slot<KIND, 7>()>(addr);
+  d[8] = lds_read_b64<8 * read_slot<KIND, 8>()>(addr);   d[9] = lds_read_b64<8 * read_slot<KIND, 9>()>(addr);
+  d[10] = lds_read_b64<8 * read_slot<KIND, 10>()>(addr); d[11] = lds_read_b64<8 * read_slot<KIND, 11>()>(addr);
+  d[12] = lds_read_b64<8 * read_slot<KIND, 12>()>(addr); d[13] = lds_read_b64<8 * read_slot<KIND, 13>()>(addr);
+  d[14] = lds_read_b64<8 * read_slot<KIND, 14>()>(addr); d[15] = lds_read_b64<8 * read_slot<KIND, 15>()>(addr);
+  lds_wait16(d);
+}
+
 template <typename T>
 struct Xchg;
 template <>
 struct Xchg<float> {
-  template <typename WIdx, typename RIdx>
-  static __device__ __forceinline__ void run(unsigned char* plane, cx<float> (&v)[16], WIdx widx, RIdx ridx) {
+  template <int KIND, typename WIdx>
+  static __device__ __forceinline__ void run(unsigned char* plane, unsigned rd_addr, cx<float> (&v)[16], WIdx widx) {
     float2* p = reinterpret_cast<float2*>(plane);
     wave_lds_fence();
 #pragma unroll
     for (int g = 0; g < 16; ++g) p[widx(g)] = make_float2(v[g].re, v[g].im);
     wave_lds_fence();
+    double d[16];
+    lds_read16<KIND>(rd_addr, d);
+    wave_lds_fence();
 #pragma unroll
-    for (int g = 0; g < 16; ++g) {
-      const float2 t = p[ridx(g)];
-      v[g] = {t.x, t.y};
-    }
+    for (int g = 0; g < 16; ++g)
+      v[g] = {__int_as_float(__double2loint(d[g])), __int_as_float(__double2hiint(d[g]))};
   }
 };
 template <>
 struct Xchg<double> {
-  template <typename WIdx, typename RIdx>
-  static __device__ __forceinline__ void run(unsigned char* plane, cx<double> (&v)[16], WIdx widx, RIdx ridx) {
+  template <int KIND, typename WIdx>
+  static __device__ __forceinline__ void run(unsigned char* plane, unsigned rd_addr, cx<double> (&v)[16], WIdx widx) {
     double* p = reinterpret_cast<double*>(plane);
-    double re[16];
+    double re[16], im[16];
     wave_lds_fence();
 #pragma unroll
     for (int g = 0; g < 16; ++g) p[widx(g)] = v[g].re;
     wave_lds_fence();
-#pragma unroll
-    for (int g = 0; g < 16; ++g) re[g] = p[ridx(g)];
+    lds_read16<KIND>(rd_addr, re);
     wave_lds_fence();
 #pragma unroll
     for (int g = 0; g < 16; ++g) p[widx(g)] = v[g].im;
     wave_lds_fence();
+    lds_read16<KIND>(rd_addr, im);
+    wave_lds_fence();
 #pragma unroll
-    for (int g = 0; g < 16; ++g) v[g] = {re[g], p[ridx(g)]};
+    for (int g = 0; g < 16; ++g) v[g] = {re[g], im[g]};
   }
 };
 
@@ -286,8 +340,8 @@ __device__ __forceinline__ void finish_mfcc(double acc, int nslots, int64_t row0
 template <typename T, typename TIn, int FEAT, int WAVES>
 __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   using Pair = typename InPair<TIn>::type;
-  using Map = LdsMap<T>;
   constexpr int MR = (FEAT == kFeatC2) ? kMelRows : (FEAT == kFeatStats ? 12 : 16);
+  using Map = LdsMap<T, MR>;
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
@@ -295,7 +349,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   // ---- shared tables ----
   copy_to_lds(lds_raw + Map::win, a.win, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::t2, a.t2, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
-  copy_to_lds(lds_raw + Map::post, a.post, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
+  copy_to_lds(lds_raw + Map::post, a.post, MR * 64 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::t1, a.t1, 64 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::melw, a.melw, kMelPairs * 64 * 8, threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::dct, a.dct, 14 * 16 * 8, threadIdx.x, WAVES * 64);
@@ -309,6 +363,9 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   const double* const dct = reinterpret_cast<const double*>(lds_raw + Map::dct);
   unsigned char* const plane = lds_raw + Map::xchg + wave * Map::plane_bytes;
   double* const lds_mag = reinterpret_cast<double*>(plane);
+  // 32-bit LDS byte address of the plane for the asm reads
+  const unsigned plane_addr =
+      (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw + Map::xchg + wave * Map::plane_bytes;
 
   // lane coordinates of the three layouts
   const int m2 = lane >> 4, h = (lane >> 2) & 3, q = lane & 3;  // P1 layout: lane = 16 m2 + 4 h + q
@@ -376,16 +433,14 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
       dft16(v);
 #pragma unroll
       for (int j1 = 1; j1 < 16; ++j1) v[j1] = cmul(v[j1], t1[4 * j1]);
-      Xchg<T>::run(plane, v, [&](int j1) { return e1w + 4 * j1; },
-                   [&](int g) { return e1r + 68 * (g & 3) + 272 * (g >> 2); });
+      Xchg<T>::template run<1>(plane, plane_addr + 8u * e1r, v, [&](int j1) { return e1w + 4 * j1; });
 
       // ---- P2 + T2 + E2 ----
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) radix4(v[qq], v[4 + qq], v[8 + qq], v[12 + qq]);
 #pragma unroll
       for (int g = 0; g < 16; ++g) v[g] = cmul(v[g], t2[64 * g]);
-      Xchg<T>::run(plane, v, [&](int g) { return e2w + 16 * (g >> 2) + 272 * (g & 3); },
-                   [&](int g) { return e2r + 68 * (g >> 2) + 272 * (g & 3); });
+      Xchg<T>::template run<2>(plane, plane_addr + 8u * e2r, v, [&](int g) { return e2w + 16 * (g >> 2) + 272 * (g & 3); });
 
       // ---- P3: v[k2] = Z[lane + 64 k2] ----
       dft16(v);
@@ -402,7 +457,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         const T orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
         const T xr = er + (w.re * orr - w.im * oi);
         const T xi = ei + (w.re * oi + w.im * orr);
-        mag[r] = sqrt(xr * xr + xi * xi);
+        mag[r] = mag_sqrt(xr * xr + xi * xi);
       }
 
       const bool emit = !(preroll && fi == 0);
@@ -590,41 +645,32 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   }
 }
 
-constexpr int kWavesF64 = 8;
-constexpr int kWavesF32 = 8;
+// waves per workgroup (one workgroup per CU): limited by LDS (tables + 8.5 KiB per wave <= 160 KiB)
+// and by the VGPR budget that many waves per SIMD leave
+constexpr int kWavesC2 = AFX_WAVES_C2;
+constexpr int kWavesOther = 8;
 
-template <typename T, typename TIn, int WAVES>
-hipError_t launch_typed(const FrameArgs& a, int feat, int grid_blocks, hipStream_t stream) {
-  const dim3 grid(grid_blocks), block(WAVES * 64);
-  const size_t lds = (size_t)LdsMap<T>::total(WAVES);
-  hipError_t e = hipSuccess;
-  switch (feat) {
-    case kFeatC2: {
-      auto k = frames_kernel<T, TIn, kFeatC2, WAVES>;
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, lds, stream, a);
-      break;
-    }
-    case kFeatStats: {
-      auto k = frames_kernel<T, TIn, kFeatStats, WAVES>;
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, lds, stream, a);
-      break;
-    }
-    default: {
-      auto k = frames_kernel<T, TIn, kFeatFull, WAVES>;
-      e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e == hipSuccess) hipLaunchKernelGGL(k, grid, block, lds, stream, a);
-      break;
-    }
-  }
+template <typename T, typename TIn, int FEAT, int WAVES>
+hipError_t launch_one(const FrameArgs& a, int grid_blocks, hipStream_t stream) {
+  constexpr int MR = (FEAT == kFeatC2) ? kMelRows : (FEAT == kFeatStats ? 12 : 16);
+  const size_t lds = (size_t)LdsMap<T, MR>::total(WAVES);
+  auto k = frames_kernel<T, TIn, FEAT, WAVES>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(WAVES * 64), lds, stream, a);
   return hipGetLastError();
 }
 
-}  // namespace
+template <typename T, typename TIn>
+hipError_t launch_typed(const FrameArgs& a, int feat, int grid_blocks, hipStream_t stream) {
+  switch (feat) {
+    case kFeatC2: return launch_one<T, TIn, kFeatC2, kWavesC2>(a, grid_blocks, stream);
+    case kFeatStats: return launch_one<T, TIn, kFeatStats, kWavesOther>(a, grid_blocks, stream);
+    default: return launch_one<T, TIn, kFeatFull, kWavesOther>(a, grid_blocks, stream);
+  }
+}
 
-int frames_waves_per_block(int precision) { return precision == 0 ? kWavesF64 : kWavesF32; }
+}  // namespace
 
 int frames_feature_class(uint32_t mask) {
   if (mask == 1u) return kFeatC2;
@@ -632,16 +678,18 @@ int frames_feature_class(uint32_t mask) {
   return kFeatStats;
 }
 
+int frames_waves_per_block(uint32_t mask) { return frames_feature_class(mask) == kFeatC2 ? kWavesC2 : kWavesOther; }
+
 hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int grid_blocks,
                          hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
   const int feat = frames_feature_class(a.mask);
   if (precision == 0) {
-    return pcm_dtype == 0 ? launch_typed<double, float, kWavesF64>(a, feat, grid_blocks, stream)
-                          : launch_typed<double, double, kWavesF64>(a, feat, grid_blocks, stream);
+    return pcm_dtype == 0 ? launch_typed<double, float>(a, feat, grid_blocks, stream)
+                          : launch_typed<double, double>(a, feat, grid_blocks, stream);
   }
-  return pcm_dtype == 0 ? launch_typed<float, float, kWavesF32>(a, feat, grid_blocks, stream)
-                        : launch_typed<float, double, kWavesF32>(a, feat, grid_blocks, stream);
+  return pcm_dtype == 0 ? launch_typed<float, float>(a, feat, grid_blocks, stream)
+                        : launch_typed<float, double>(a, feat, grid_blocks, stream);
 }
 
 hipError_t launch_bands(const BandArgs&, hipStream_t) { return hipErrorNotSupported; }

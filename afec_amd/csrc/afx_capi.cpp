@@ -309,9 +309,20 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   for (int f = 0; f < afx::kNumCep && ok; ++f)
     for (int k = 0; k < afx::kHalf; ++k)
       if (p->mel[(size_t)f * afx::kHalf + k] != 0.0 && (k < afx::kMelLo[f] || k > afx::kMelHi[f])) ok = false;
+  {
+    // sub-band bin counts exactly as SampleAnalyser.cpp:2087-2100 derives them
+    static const double sub_edges[afx::kNumSub] = {50.0, 100.0, 200.0, 400.0, 630.0, 920.0, 1270.0, 1720.0,
+                                                   2320.0, 3150.0, 4400.0, 6400.0, 9500.0, 15500.0};
+    const int first = d2i_round(20.0 / fpb);
+    for (int b = 0; b < afx::kNumSub && ok; ++b) {
+      const int start = (b == 0) ? first : d2i_round(sub_edges[b - 1] / fpb);
+      const int end = d2i_round(sub_edges[b] / fpb);
+      if (end - start + 1 != afx::kSubN[b]) ok = false;
+    }
+  }
   if (!ok) {
     delete p;
-    return fail(AFX_ERR_UNSUPPORTED, "mel table / bin range outside the kernels' static cover");
+    return fail(AFX_ERR_UNSUPPORTED, "mel table / bin ranges outside the kernels' static cover");
   }
 
   hipError_t e = hipSetDevice(desc->device);

@@ -55,6 +55,10 @@ constexpr bool band_touches(int b, int r) {
   return kBandEdge[b] <= 64 * r + 63 && kBandEdge[b + 1] - 1 >= 64 * r;
 }
 
+// 14 sub-bands of CalcSpectralBandFeatures: bin counts EndBin - StartBin + 1 of the nominal edges
+// 50..15500 Hz at 21 Hz/bin (SampleAnalyser.cpp:2077-2100), laid out contiguously from bin 1
+constexpr int kSubN[kNumSub] = {2, 4, 6, 10, 12, 15, 17, 23, 29, 41, 61, 96, 148, 287};
+
 // chunk = a run of consecutive frames of one buffer processed by one wave
 struct Chunk {
   int64_t sample_off;  // offset of the first processed frame's first sample in the PCM arena

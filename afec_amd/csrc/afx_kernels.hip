@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #include "afx_internal.h"
+#include "afx_device.h"
 
 namespace afx {
 namespace {
@@ -97,103 +98,6 @@ __device__ __forceinline__ void dft16(cx<T> (&v)[16]) {
   for (int i = 0; i < 16; ++i) v[i] = t[i];
 }
 
-// orders this wave's LDS traffic for the compiler; the DS unit executes a wave's ops in order
-__device__ __forceinline__ void wave_lds_fence() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// ---- cross-lane helpers on doubles: DPP inside a 16-lane row, permlane swaps across rows ----
-template <int CTRL>
-__device__ __forceinline__ double dpp_mov(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
-  return __hiloint2double(hi, lo);
-}
-constexpr int kDppXor1 = 0xB1;        // quad_perm [1,0,3,2]
-constexpr int kDppXor2 = 0x4E;        // quad_perm [2,3,0,1]
-constexpr int kDppHalfMirror = 0x141; // i -> 7 - i inside groups of 8
-constexpr int kDppMirror = 0x140;     // i -> 15 - i inside the row
-constexpr int kDppRor8 = 0x128;       // i -> i ^ 8 inside the row
-
-// x' = (x.lanes[0:32), y.lanes[0:32)), y' = (x.lanes[32:64), y.lanes[32:64))
-__device__ __forceinline__ void swap32(double& x, double& y) {
-  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
-  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
-  x = __hiloint2double(hi[0], lo[0]);
-  y = __hiloint2double(hi[1], lo[1]);
-}
-// rows of 16: x' = (x0, y0, x2, y2), y' = (x1, y1, x3, y3)
-__device__ __forceinline__ void swap16(double& x, double& y) {
-  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
-  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
-  x = __hiloint2double(hi[0], lo[0]);
-  y = __hiloint2double(hi[1], lo[1]);
-}
-
-// Sum 16 per-lane values over the wave at once ("transposed" butterfly): on return lane L holds
-// the wave total of a[(L >> 2) & 15].  15 adds + 24 swaps + a few DPP moves instead of 16 x 6 steps.
-__device__ __forceinline__ double wave_sum16(double (&a)[16], int lane) {
-#pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    swap32(a[i], a[i + 8]);
-    a[i] += a[i + 8];
-  }
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    swap16(a[i], a[i + 4]);
-    a[i] += a[i + 4];
-  }
-  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const double keep = b3 ? a[i + 2] : a[i];
-    const double send = b3 ? a[i] : a[i + 2];
-    a[i] = keep + dpp_mov<kDppRor8>(send);
-  }
-  const double keep = b2 ? a[1] : a[0];
-  const double send = b2 ? a[0] : a[1];
-  double z = keep + dpp_mov<kDppHalfMirror>(send);
-  z += dpp_mov<kDppXor2>(z);
-  z += dpp_mov<kDppXor1>(z);
-  return z;
-}
-
-// full-wave sum, result in every lane
-__device__ __forceinline__ double wave_sum(double v) {
-  v += dpp_mov<kDppXor1>(v);
-  v += dpp_mov<kDppXor2>(v);
-  v += dpp_mov<kDppHalfMirror>(v);
-  v += dpp_mov<kDppMirror>(v);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
-}
-__device__ __forceinline__ double wave_max(double v) {
-  v = fmax(v, dpp_mov<kDppXor1>(v));
-  v = fmax(v, dpp_mov<kDppXor2>(v));
-  v = fmax(v, dpp_mov<kDppHalfMirror>(v));
-  v = fmax(v, dpp_mov<kDppMirror>(v));
-  v = fmax(v, __shfl_xor(v, 16));
-  v = fmax(v, __shfl_xor(v, 32));
-  return v;
-}
-__device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-  return v;
-}
-// inclusive prefix sum across the 64 lanes
-__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double t = __shfl_up(v, o);
-    if (lane >= o) v += t;
-  }
-  return v;
-}
-
 template <typename TIn>
 struct InPair;
 template <>
@@ -204,33 +108,6 @@ template <>
 struct InPair<double> {
   using type = double2;
 };
-
-__device__ __forceinline__ double nan_to_zero(double v) { return (v != v) ? 0.0 : v; }
-
-// sqrt for magnitudes: x >= 0 and far from overflow, so the range scaling of the generic
-// expansion is dropped: one v_rsq_f64 seed, one Goldschmidt step, one residual correction
-// (<= 1 ulp).  Inputs below 1e-290 (|X| < 1e-145) are flushed to 0, like the reference's FTZ/DAZ
-// FFT (AudioMath.cpp:27-36) would long before.
-__device__ __forceinline__ double mag_sqrt(double x) {
-  const double xs = x > 1e-290 ? x : 1e-290;
-  const double r = __builtin_amdgcn_rsq(xs);
-  double g = xs * r;
-  double h = 0.5 * r;
-  const double e = fma(-h, g, 0.5);
-  g = fma(g, e, g);
-  h = fma(h, e, h);
-  const double d = fma(-g, g, xs);
-  g = fma(d, h, g);
-  return x > 1e-290 ? g : 0.0;
-}
-__device__ __forceinline__ float mag_sqrt(float x) { return sqrtf(x); }
-
-// TAudioMath::LinToDb(double), AudioMath.inl:55-70 (MEpsilon is the float literal 1e-12f)
-__device__ __forceinline__ double lin_to_db(double v) {
-  if (v == 1.0) return 0.0;
-  if (v > (double)1e-12f) return log(v) * 8.685889638065035;  // 20 / ln 10
-  return -200.0;
-}
 
 // ---- LDS layout: shared tables, then one exchange plane per wave ----
 template <typename T, int POST_ROWS>
@@ -691,7 +568,5 @@ hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int g
   return pcm_dtype == 0 ? launch_typed<float, float>(a, feat, grid_blocks, stream)
                         : launch_typed<float, double>(a, feat, grid_blocks, stream);
 }
-
-hipError_t launch_bands(const BandArgs&, hipStream_t) { return hipErrorNotSupported; }
 
 }  // namespace afx

@@ -136,7 +136,7 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     mask = {"c2": afx.D_C2, "stats": afx.D_MFCC | afx.D_SPECTRAL_STATS,
-            "all": afx.D_ALL_LOW_LEVEL & ~afx.D_BAND_FEATURES}[args.mask]
+            "all": afx.D_ALL_LOW_LEVEL}[args.mask]
     precision = afx.PRECISION_F64 if args.precision == "f64" else afx.PRECISION_F32
     plan = afx.Plan(device=local, precision=precision, max_analysis_ms=0)
     bufs = make_buffers(args.buffers, 1234 + rank)

@@ -13,7 +13,7 @@ from tests._oracle import FIELDS, Oracle
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
-MASK_FRAMES = afx.D_ALL_LOW_LEVEL & ~afx.D_BAND_FEATURES
+MASK_FRAMES = afx.D_ALL_LOW_LEVEL
 ILL_CONDITIONED = {("impulse", "sub_complexity"), ("impulse", "sub_flux"), ("impulse", "spectral_flux")}
 
 

@@ -168,12 +168,16 @@ int upload_tables_typed(afx_plan* p) {
       win[n] = {(T)(p->window[2 * n] / (2.0 * fft)), (T)(p->window[2 * n + 1] / (2.0 * fft))};
       post[n] = twiddle<T>(lane + 64 * r, 2048);
     }
-  for (int j1 = 0; j1 < 16; ++j1)
-    for (int m2 = 0; m2 < 4; ++m2) t1[4 * j1 + m2] = twiddle<T>((long long)m2 * j1, 64);
+  // T1[jh][m2][jl] = w64^(m2 (4 jh + jl)): after the register transpose the lane row is jh and
+  // the register is 4 m2 + jl
+  for (int jh = 0; jh < 4; ++jh)
+    for (int m2 = 0; m2 < 4; ++m2)
+      for (int jl = 0; jl < 4; ++jl) t1[16 * jh + 4 * m2 + jl] = twiddle<T>((long long)m2 * (4 * jh + jl), 64);
+  // T2[4 j2 + jl][16 jh + n2] = w1024^(n2 (4 jh + jl + 16 j2))
   for (int g = 0; g < 16; ++g)
     for (int lane = 0; lane < 64; ++lane) {
-      const int j2 = g >> 2, q = g & 3, j1 = lane >> 2, h = lane & 3;
-      t2[64 * g + lane] = twiddle<T>((long long)(4 * h + q) * (j1 + 16 * j2), 1024);
+      const int j2 = g >> 2, jl = g & 3, jh = lane >> 4, n2 = lane & 15;
+      t2[64 * g + lane] = twiddle<T>((long long)n2 * (4 * jh + jl + 16 * j2), 1024);
     }
   auto up = [](void** dst, const void* src, size_t bytes) -> hipError_t {
     hipError_t e = hipMalloc(dst, bytes);

@@ -84,8 +84,8 @@ struct FrameArgs {
   RecordLayout lay;
   double* mag_out;   // [F][1024] or nullptr
   const void* win;   // [16][64] pairs (w[2n], w[2n+1]) / 4096, n = 64 r + lane      (T)
-  const void* t1;    // [16][4] complex  w64^(m2*j1)                                  (T)
-  const void* t2;    // [16][64] complex w1024^((4h+q)*(j1+16*j2)), reg=4*j2+q, lane=4*j1+h (T)
+  const void* t1;    // [4][4][4] complex w64^(m2*(4*jh+jl)), index 16*jh + 4*m2 + jl        (T)
+  const void* t2;    // [16][64] complex w1024^(n2*(4*jh+jl+16*j2)), reg=4*j2+jl, lane=16*jh+n2 (T)
   const void* post;  // [16][64] complex w2048^(lane+64r)                             (T)
   const double* melw;  // [kMelPairs][64]
   const double* dct;   // [14][16]: cos(pi * (n/14) * (m + 0.5)), m < 14

@@ -5,22 +5,26 @@
 // z[n] = x[2n] + i x[2n+1] held as 16 complex values per lane:
 //
 //   load      v[r]  = z[64 r + lane]                 (hop reuse: rows 0..7 are last frame's 8..15)
-//   P1        16-point DFT over r, in registers      -> j1        lane = 16 m2 + 4 h + q
+//   P1        16-point DFT over r, in registers      -> j1        lane = 16 m2 + n2
+//   E1        register transpose with v_permlane32_swap / v_permlane16_swap: lane bits 5,4 (m2)
+//             trade places with register bits 3,2 of j1 -> lane = 16 jh + n2, reg = 4 m2 + jl
+//             (j1 = 4 jh + jl).  No LDS traffic.
 //   T1        * w64^(m2 j1)
-//   E1        LDS exchange  (lane,(j1)) -> (lane'=4 j1 + h, reg = 4 m2 + q)
-//   P2        4-point DFT over m2, in registers      -> j2
-//   T2        * w1024^((4h+q)(j1 + 16 j2))
-//   E2        LDS exchange  -> (lane''= j1 + 16 j2, reg = 4 h + q)
-//   P3        16-point DFT over n2 = 4h+q            -> Z[lane + 64 k2]
+//   P2        4-point DFT over m2, in registers      -> j2        reg = 4 j2 + jl
+//   T2        * w1024^(n2 (j1 + 16 j2))
+//   E2        LDS exchange  -> (lane''= k1 = 16 j2 + j1, reg = n2), slot = k1 + 65 n2
+//   P3        16-point DFT over n2                   -> Z[lane + 64 k2]
 //   E3        partner Z[1024-k] by cross-lane read, even/odd untangle, |X[k]| for k = lane + 64 r
 //
 // then the descriptors straight from the magnitudes in registers.  The index algebra and the LDS
-// maps (conflict-free for ds_write_b64 / ds_read_b64, address = lane part + immediate) are
+// map (conflict-free for ds_write_b64 / ds_read_b64, address = lane part + immediate) are
 // modelled and checked in tools/fft_dataflow_model.py.
 //
-// A workgroup is kWaves independent waves that share the constant tables (window, twiddles, mel
-// rows, DCT basis) in LDS; each wave has a private 8.5 KiB exchange plane.  Waves never
-// synchronise with each other after the table load.
+// A workgroup is kWaves independent waves that share the constant tables (twiddles, mel rows, DCT
+// basis) in LDS; each wave has a private 8.1 KiB exchange plane.  Waves never synchronise with
+// each other after the table load.  The kernel is bound by the CU's LDS instruction issue
+// (profiles/r01), which is why E1 lives in the VALU and the double kernels read the window from
+// global memory (L1/L2-resident) rather than from LDS.
 //
 // What each stage replaces in the reference (SampleAnalyser.cpp = SA):
 //   window+FFT+magnitude  SA:826-845 (xtract_windowed, TFftTransformComplex, TAudioMath::Magnitude)
@@ -37,11 +41,17 @@
 namespace afx {
 namespace {
 
+#ifndef AFX_ABL
+#define AFX_ABL 0   // timing experiments only (outputs wrong): bit0 no LDS exchange, bit1 no table reads,
+#endif              // bit2 no descriptor epilogue, bit3 no butterflies
 #ifndef AFX_WAVES_C2
 #define AFX_WAVES_C2 8
 #endif
 
-constexpr int kLdsSlots = 1088;  // 1024 values + padding of the separable swizzle (8-byte slots)
+// E2 plane: 8-byte slots, slot = k1 + 65 n2 (k1 < 64, n2 < 16): write = lane part (4 jh + 65 n2)
+// + immediate (16 j2 + jl), read = lane + immediate 65 n2.  complex<float> is one slot;
+// complex<double> goes through the same plane twice (real parts, then imaginary parts).
+constexpr int kPlaneSlots = 1040;
 
 // feature classes the kernel is specialised for (the host picks the smallest that covers the mask)
 constexpr int kFeatC2 = 0;     // MFCC only: magnitudes of bins 0..383
@@ -110,16 +120,19 @@ struct InPair<double> {
 };
 
 // ---- LDS layout: shared tables, then one exchange plane per wave ----
+// LDS layout: shared tables, then one exchange plane per wave.  The double kernels read the
+// window from global memory (16 KiB, L1/L2-resident, coalesced 16 B per lane): the kernel is bound by
+// LDS instruction issue, the vector-memory path is otherwise idle.
 template <typename T, int POST_ROWS>
 struct LdsMap {
-  static constexpr int win = 0;                                    // [16][64] cx<T>
-  static constexpr int t2 = win + 1024 * (int)sizeof(cx<T>);       // [16][64] cx<T>
-  static constexpr int post = t2 + 1024 * (int)sizeof(cx<T>);      // [POST_ROWS][64] cx<T>
-  static constexpr int t1 = post + POST_ROWS * 64 * (int)sizeof(cx<T>);  // [16][4]  cx<T>
-  static constexpr int melw = t1 + 64 * (int)sizeof(cx<T>);        // [22][64] double
-  static constexpr int dct = melw + kMelPairs * 64 * 8;            // [14][16] double
-  static constexpr int xchg = dct + 14 * 16 * 8;                   // kWaves x [1088] 8-byte slots
-  static constexpr int plane_bytes = kLdsSlots * 8;
+  static constexpr bool win_global = sizeof(T) == 8;
+  static constexpr int win = 0;                                                     // [16][64] cx<T>
+  static constexpr int t2 = win + (win_global ? 0 : 1024 * (int)sizeof(cx<T>));     // [16][64] cx<T>
+  static constexpr int post = t2 + 1024 * (int)sizeof(cx<T>);                       // [POST_ROWS][64] cx<T>
+  static constexpr int melw = post + POST_ROWS * 64 * (int)sizeof(cx<T>);           // [22][64] double
+  static constexpr int dct = melw + kMelPairs * 64 * 8;                             // [14][16] double
+  static constexpr int xchg = dct + 14 * 16 * 8;                                    // kWaves planes
+  static constexpr int plane_bytes = kPlaneSlots * 8;
   static constexpr int total(int waves) { return xchg + waves * plane_bytes; }
 };
 
@@ -145,35 +158,31 @@ __device__ __forceinline__ void lds_wait16(double (&d)[16]) {
                : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4]), "+v"(d[5]), "+v"(d[6]), "+v"(d[7]),
                  "+v"(d[8]), "+v"(d[9]), "+v"(d[10]), "+v"(d[11]), "+v"(d[12]), "+v"(d[13]), "+v"(d[14]), "+v"(d[15]));
 }
-// the two read patterns: E1 reads slot e1r + 68 q + 272 m2 (g = 4 m2 + q), E2 reads e2r + 68 h + 272 q (g = 4 h + q)
-template <int KIND, int G>
-constexpr int read_slot() { return KIND == 1 ? 68 * (G & 3) + 272 * (G >> 2) : 68 * (G >> 2) + 272 * (G & 3); }
-template <int KIND>
+template <int G>
+__device__ __forceinline__ void lds_read16_step(unsigned addr, double (&d)[16]) {
+  d[G] = lds_read_b64<8 * 65 * G>(addr);
+  if constexpr (G + 1 < 16) lds_read16_step<G + 1>(addr, d);
+}
+// d[n2] = plane[lane + 65 n2], n2 = 0..15
 __device__ __forceinline__ void lds_read16(unsigned addr, double (&d)[16]) {
-  d[0] = lds_read_b64<8 * read_slot<KIND, 0>()>(addr);   d[1] = lds_read_b64<8 * read_slot<KIND, 1>()>(addr);
-  d[2] = lds_read_b64<8 * read_slot<KIND, 2>()>(addr);   d[3] = lds_read_b64<8 * read_slot<KIND, 3>()>(addr);
-  d[4] = lds_read_b64<8 * read_slot<KIND, 4>()>(addr);   d[5] = lds_read_b64<8 * read_slot<KIND, 5>()>(addr);
-  d[6] = lds_read_b64<8 * read_slot<KIND, 6>()>(addr);   d[7] = lds_read_b64<8 * read_slot<KIND, 7>()>(addr);
-  d[8] = lds_read_b64<8 * read_slot<KIND, 8>()>(addr);   d[9] = lds_read_b64<8 * read_slot<KIND, 9>()>(addr);
-  d[10] = lds_read_b64<8 * read_slot<KIND, 10>()>(addr); d[11] = lds_read_b64<8 * read_slot<KIND, 11>()>(addr);
-  d[12] = lds_read_b64<8 * read_slot<KIND, 12>()>(addr); d[13] = lds_read_b64<8 * read_slot<KIND, 13>()>(addr);
-  d[14] = lds_read_b64<8 * read_slot<KIND, 14>()>(addr); d[15] = lds_read_b64<8 * read_slot<KIND, 15>()>(addr);
+  lds_read16_step<0>(addr, d);
   lds_wait16(d);
 }
 
+// E2: v[4 j2 + jl] of lane (jh, n2)  ->  v[n2] of lane k1 = 16 j2 + 4 jh + jl
 template <typename T>
 struct Xchg;
 template <>
 struct Xchg<float> {
-  template <int KIND, typename WIdx>
-  static __device__ __forceinline__ void run(unsigned char* plane, unsigned rd_addr, cx<float> (&v)[16], WIdx widx) {
-    float2* p = reinterpret_cast<float2*>(plane);
+  static __device__ __forceinline__ void run(unsigned char* plane, unsigned rd_addr, int wlane, cx<float> (&v)[16]) {
+    if (AFX_ABL & 1) return;
+    float2* p = reinterpret_cast<float2*>(plane) + wlane;
     wave_lds_fence();
 #pragma unroll
-    for (int g = 0; g < 16; ++g) p[widx(g)] = make_float2(v[g].re, v[g].im);
+    for (int g = 0; g < 16; ++g) p[16 * (g >> 2) + (g & 3)] = make_float2(v[g].re, v[g].im);
     wave_lds_fence();
     double d[16];
-    lds_read16<KIND>(rd_addr, d);
+    lds_read16(rd_addr, d);
     wave_lds_fence();
 #pragma unroll
     for (int g = 0; g < 16; ++g)
@@ -182,25 +191,54 @@ struct Xchg<float> {
 };
 template <>
 struct Xchg<double> {
-  template <int KIND, typename WIdx>
-  static __device__ __forceinline__ void run(unsigned char* plane, unsigned rd_addr, cx<double> (&v)[16], WIdx widx) {
-    double* p = reinterpret_cast<double*>(plane);
+  static __device__ __forceinline__ void run(unsigned char* plane, unsigned rd_addr, int wlane, cx<double> (&v)[16]) {
+    if (AFX_ABL & 1) return;
+    double* p = reinterpret_cast<double*>(plane) + wlane;
     double re[16], im[16];
     wave_lds_fence();
 #pragma unroll
-    for (int g = 0; g < 16; ++g) p[widx(g)] = v[g].re;
+    for (int g = 0; g < 16; ++g) p[16 * (g >> 2) + (g & 3)] = v[g].re;
     wave_lds_fence();
-    lds_read16<KIND>(rd_addr, re);
+    lds_read16(rd_addr, re);
     wave_lds_fence();
 #pragma unroll
-    for (int g = 0; g < 16; ++g) p[widx(g)] = v[g].im;
+    for (int g = 0; g < 16; ++g) p[16 * (g >> 2) + (g & 3)] = v[g].im;
     wave_lds_fence();
-    lds_read16<KIND>(rd_addr, im);
+    lds_read16(rd_addr, im);
     wave_lds_fence();
 #pragma unroll
     for (int g = 0; g < 16; ++g) v[g] = {re[g], im[g]};
   }
 };
+
+// E1 in registers: 2x2 block transposes between a lane bit and a register bit.
+//   swap32(v[g], v[g+8]):  lane bit 5 <-> register bit 3      swap16(v[g], v[g+4]):  lane bit 4 <-> register bit 2
+__device__ __forceinline__ void reg_swap32(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void reg_swap16(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void reg_swap32(double& x, double& y) { swap32(x, y); }
+__device__ __forceinline__ void reg_swap16(double& x, double& y) { swap16(x, y); }
+template <typename T>
+__device__ __forceinline__ void transpose_m2_into_registers(cx<T> (&v)[16]) {
+#pragma unroll
+  for (int g = 0; g < 8; ++g) {
+    reg_swap32(v[g].re, v[g + 8].re);
+    reg_swap32(v[g].im, v[g + 8].im);
+  }
+#pragma unroll
+  for (int g = 0; g < 16; ++g)
+    if ((g & 4) == 0) {
+      reg_swap16(v[g].re, v[g + 4].re);
+      reg_swap16(v[g].im, v[g + 4].im);
+    }
+}
 
 // log + 14-point DCT-II + store for up to four frames whose mel sums sit in lanes 4 f + slot
 __device__ __forceinline__ void finish_mfcc(double acc, int nslots, int64_t row0, const FrameArgs& a,
@@ -224,18 +262,20 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   const int wave = threadIdx.x >> 6;
 
   // ---- shared tables ----
-  copy_to_lds(lds_raw + Map::win, a.win, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
+  if (!Map::win_global) copy_to_lds(lds_raw + Map::win, a.win, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::t2, a.t2, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::post, a.post, MR * 64 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
-  copy_to_lds(lds_raw + Map::t1, a.t1, 64 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::melw, a.melw, kMelPairs * 64 * 8, threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::dct, a.dct, 14 * 16 * 8, threadIdx.x, WAVES * 64);
   __syncthreads();
 
-  const cx<T>* const win = reinterpret_cast<const cx<T>*>(lds_raw + Map::win) + lane;
+  const cx<T>* const win = (Map::win_global ? reinterpret_cast<const cx<T>*>(a.win)
+                                            : reinterpret_cast<const cx<T>*>(lds_raw + Map::win)) + lane;
   const cx<T>* const t2 = reinterpret_cast<const cx<T>*>(lds_raw + Map::t2) + lane;
   const cx<T>* const post = reinterpret_cast<const cx<T>*>(lds_raw + Map::post) + lane;
-  const cx<T>* const t1 = reinterpret_cast<const cx<T>*>(lds_raw + Map::t1) + (lane >> 4);
+  // T1 table [jh][m2][jl] = w64^(m2 (4 jh + jl)): 12 values per lane, the same for the 16 lanes of
+  // a row -> one cache line per row from L1
+  const cx<T>* const t1 = reinterpret_cast<const cx<T>*>(a.t1) + 16 * (lane >> 4);
   const double* const melw = reinterpret_cast<const double*>(lds_raw + Map::melw) + lane;
   const double* const dct = reinterpret_cast<const double*>(lds_raw + Map::dct);
   unsigned char* const plane = lds_raw + Map::xchg + wave * Map::plane_bytes;
@@ -244,13 +284,9 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   const unsigned plane_addr =
       (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw + Map::xchg + wave * Map::plane_bytes;
 
-  // lane coordinates of the three layouts
-  const int m2 = lane >> 4, h = (lane >> 2) & 3, q = lane & 3;  // P1 layout: lane = 16 m2 + 4 h + q
-  const int lj1 = lane >> 2, lh = lane & 3;                      // P2 layout: lane = 4 j1 + h
-  const int e1w = h + 68 * q + 272 * m2;   // + 4 j1
-  const int e1r = 4 * lj1 + lh;            // + 68 q + 272 m2
-  const int e2w = lj1 + 68 * lh;           // + 16 j2 + 272 q
-  const int e2r = lane;                    // + 68 h + 272 q
+  // E2 lane parts: this lane holds (jh, n2) when writing and is k1 when reading
+  const int e2w = 4 * (lane >> 4) + 65 * (lane & 15);   // + 16 j2 + jl
+  const unsigned e2r_addr = plane_addr + 8u * lane;     // + 8 * 65 n2
   const int partner = (64 - lane) & 63;
 
   const TIn* const pcm = reinterpret_cast<const TIn*>(a.pcm);
@@ -294,7 +330,8 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
       cx<T> v[16];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const cx<T> w0 = win[64 * r], w1 = win[64 * (r + 8)];
+        const cx<T> w0 = (AFX_ABL & 2) ? cx<T>{(T)0.5, (T)0.25} : win[64 * r];
+        const cx<T> w1 = (AFX_ABL & 2) ? cx<T>{(T)0.125, (T)0.75} : win[64 * (r + 8)];
         v[r] = {(T)lo[r].x * w0.re, (T)lo[r].y * w0.im};
         v[r + 8] = {(T)nxt[r].x * w1.re, (T)nxt[r].y * w1.im};
         lo[r] = nxt[r];
@@ -306,21 +343,21 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         for (int r = 0; r < 8; ++r) nxt[r] = nsrc[64 * (r + 8)];
       }
 
-      // ---- P1 + T1 + E1 ----
-      dft16(v);
+      // ---- P1, E1 (register transpose), T1 ----
+      if (!(AFX_ABL & 8)) dft16(v);
+      transpose_m2_into_registers(v);   // lane = 16 jh + n2, v[4 m2 + jl]
 #pragma unroll
-      for (int j1 = 1; j1 < 16; ++j1) v[j1] = cmul(v[j1], t1[4 * j1]);
-      Xchg<T>::template run<1>(plane, plane_addr + 8u * e1r, v, [&](int j1) { return e1w + 4 * j1; });
+      for (int g = 4; g < 16; ++g) v[g] = cmul(v[g], (AFX_ABL & 2) ? cx<T>{(T)0.6, (T)0.8} : t1[g]);
 
       // ---- P2 + T2 + E2 ----
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) radix4(v[qq], v[4 + qq], v[8 + qq], v[12 + qq]);
+      for (int jl = 0; jl < 4; ++jl) radix4(v[jl], v[4 + jl], v[8 + jl], v[12 + jl]);
 #pragma unroll
-      for (int g = 0; g < 16; ++g) v[g] = cmul(v[g], t2[64 * g]);
-      Xchg<T>::template run<2>(plane, plane_addr + 8u * e2r, v, [&](int g) { return e2w + 16 * (g >> 2) + 272 * (g & 3); });
+      for (int g = 0; g < 16; ++g) v[g] = cmul(v[g], (AFX_ABL & 2) ? cx<T>{(T)0.6, (T)0.8} : t2[64 * g]);
+      Xchg<T>::run(plane, e2r_addr, e2w, v);
 
       // ---- P3: v[k2] = Z[lane + 64 k2] ----
-      dft16(v);
+      if (!(AFX_ABL & 8)) dft16(v);
 
       // ---- E3 + untangle + magnitude: mag[r] = |X[lane + 64 r]| ----
       T mag[MR];
@@ -329,7 +366,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         cx<T> p{__shfl(v[15 - r].re, partner), __shfl(v[15 - r].im, partner)};
         if (lane == 0) p = v[(16 - r) & 15];
         const cx<T> z = v[r];
-        const cx<T> w = post[64 * r];
+        const cx<T> w = (AFX_ABL & 2) ? cx<T>{(T)0.8, (T)-0.6} : post[64 * r];
         const T er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
         const T orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
         const T xr = er + (w.re * orr - w.im * oi);
@@ -348,7 +385,12 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         }
 
         // ---- MFCC: sparse mel rows now; log + DCT once per four frames (vector.c:350-391) ----
-        if (FEAT == kFeatC2 || (a.mask & 1u)) {
+        if (AFX_ABL & 4) {
+          double sacc = 0.0;
+#pragma unroll
+          for (int r = 0; r < MR; ++r) sacc += (double)mag[r];
+          if (sacc == 1.2345e-300) rec[a.lay.mfcc + (lane & 7)] = sacc;
+        } else if (FEAT == kFeatC2 || (a.mask & 1u)) {
           double e[16];
 #pragma unroll
           for (int f = 0; f < 16; ++f) e[f] = 0.0;

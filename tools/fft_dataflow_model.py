@@ -2,8 +2,9 @@
 """numpy model of the per-wave STFT dataflow used by afec_amd/csrc/afx_kernels.hip.
 
 One wave (64 lanes x 16 registers) computes the 2048-point real FFT of one frame as a
-1024-point complex FFT (z[n] = x[2n] + i x[2n+1]) in three in-register passes (16 x 4 x 16)
-with two LDS exchanges, then un-tangles even/odd spectra with the (k, 1024-k) partner fetched
+1024-point complex FFT (z[n] = x[2n] + i x[2n+1]) in three in-register passes (16 x 4 x 16):
+the first exchange is a register transpose with v_permlane32_swap / v_permlane16_swap, the second
+goes through LDS; then even/odd spectra are un-tangled with the (k, 1024-k) partner fetched
 cross-lane.  This script checks the index algebra and the LDS swizzles (bank-conflict rules
 from MI355X_MICROARCH.md) against numpy.fft; it is a design aid, not part of the product.
 """
@@ -17,60 +18,16 @@ def w(n, e):  # e^{-2 pi i e / n}
     return np.exp(-2j * np.pi * (np.asarray(e) % n) / n)
 
 
-def e1_index(j1, m2, h, q):
-    """8-byte slot index for exchange 1 (write: fixed j1, lane=(m2,h,q); read: fixed (m2,q), lane=(j1,h))."""
-    return 4 * j1 + h + 68 * q + 272 * m2   # separable: lane part + static register part
+def swap32(x, y):
+    """v_permlane32_swap: x' = (x.lanes[0:32), y.lanes[0:32)), y' = (x.lanes[32:64), y.lanes[32:64))."""
+    return np.concatenate([x[:32], y[:32]]), np.concatenate([x[32:], y[32:]])
 
 
-def e2_index(j1, j2, h, q):
-    """exchange 2 (write: fixed (j2,q), lane=(j1,h)=4*j1+h; read: fixed (h,q), lane=j1+16*j2)."""
-    return j1 + 16 * j2 + 68 * h + 272 * q
-
-
-# ds_read_b128 lane groups on gfx950 (MI355X_MICROARCH.md, LDS table)
-B128_READ_GROUPS = [
-    list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)),
-    list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
-    list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)),
-    list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64)),
-]
-
-
-def check_b128(name, slots, write):
-    """16-byte slots: ds_write_b128 = 8 contiguous lanes over 8 slots, ds_read_b128 = the irregular 16-lane groups over 16 slots."""
-    if write:
-        for g in range(0, 64, 8):
-            s = slots[g:g + 8] % 8
-            assert len(set(s.tolist())) == 8, (name, g, sorted(s.tolist()))
-    else:
-        for grp in B128_READ_GROUPS:
-            s = slots[grp] % 16
-            assert len(set(s.tolist())) == 16, (name, grp, sorted(s.tolist()))
-
-
-def check_maps_b128():
-    """complex<double> exchange in one pass through 16-byte slots: stride 66 / 264 instead of 68 / 272."""
-    lane = np.arange(NL)
-    m2, n2 = lane >> 4, lane & 15
-    h, q = n2 >> 2, n2 & 3
-    lj1, lh = lane >> 2, lane & 3
-    e1 = lambda j1, m2, h, q: 4 * j1 + h + 66 * q + 264 * m2
-    e2 = lambda j1, j2, h, q: j1 + 16 * j2 + 66 * h + 264 * q
-    seen = set()
-    for j1 in range(16):
-        idx = e1(j1, m2, h, q); check_b128("e1 write", idx, True); seen.update(idx.tolist())
-    assert len(seen) == 1024 and max(seen) < 1056
-    for mm in range(4):
-        for qq in range(4):
-            check_b128("e1 read", e1(lj1, mm, lh, qq), False)
-    seen = set()
-    for j2 in range(4):
-        for qq in range(4):
-            idx = e2(lj1, j2, lh, qq); check_b128("e2 write", idx, True); seen.update(idx.tolist())
-    assert len(seen) == 1024 and max(seen) < 1056
-    for hh in range(4):
-        for qq in range(4):
-            check_b128("e2 read", e2(lane & 15, lane >> 4, hh, qq), False)
+def swap16(x, y):
+    """v_permlane16_swap on rows of 16 lanes: x' = (x0, y0, x2, y2), y' = (x1, y1, x3, y3)."""
+    xr, yr = x.reshape(4, 16), y.reshape(4, 16)
+    return (np.stack([xr[0], yr[0], xr[2], yr[2]]).reshape(64),
+            np.stack([xr[1], yr[1], xr[3], yr[3]]).reshape(64))
 
 
 def check_conflicts(name, slots, group):
@@ -82,64 +39,49 @@ def check_conflicts(name, slots, group):
 
 def fft_wave(z):
     lane = np.arange(NL)
-    A = np.zeros((NR, NL), complex)
-    for r in range(NR):
-        A[r] = z[64 * r + lane]
-    # P1: 16-point DFT over r
+    A = np.array([z[64 * r + lane] for r in range(NR)])
+    # P1: 16-point DFT over r -> j1
     B = np.zeros_like(A)
     for j1 in range(16):
         for r in range(16):
             B[j1] += A[r] * w(16, r * j1)
-    m2, n2 = lane >> 4, lane & 15
-    h, q = n2 >> 2, n2 & 3
-    for j1 in range(16):
-        B[j1] *= w(64, m2 * j1)
-    # E1
-    lds = np.zeros(1088, complex)
-    seen = np.zeros(1088, bool)
-    for j1 in range(16):
-        idx = e1_index(j1, m2, h, q)
-        check_conflicts("e1 write", idx, 16)
-        assert not seen[idx].any(); seen[idx] = True
-        lds[idx] = B[j1]
-    assert seen.sum() == 1024
-    lj1, lh = lane >> 2, lane & 3
-    C = np.zeros_like(A)
-    for mm in range(4):
-        for qq in range(4):
-            idx = e1_index(lj1, mm, lh, qq)
-            check_conflicts("e1 read", idx, 32)
-            C[4 * mm + qq] = lds[idx]
-    # P2: 4-point DFT over m2, then twiddle w1024^(n2*k1)
-    D = np.zeros_like(A)
+    # E1 in registers: lane bit 5 <-> register bit 3, lane bit 4 <-> register bit 2
+    v = [B[g].copy() for g in range(16)]
+    for g in range(8):
+        v[g], v[g + 8] = swap32(v[g], v[g + 8])
+    for g in (0, 1, 2, 3, 8, 9, 10, 11):
+        v[g], v[g + 4] = swap16(v[g], v[g + 4])
+    jh, n2 = lane >> 4, lane & 15           # lane = 16 jh + n2, register = 4 m2 + jl, j1 = 4 jh + jl
+    # T1 = w64^(m2 j1)
+    for m2 in range(4):
+        for jl in range(4):
+            v[4 * m2 + jl] = v[4 * m2 + jl] * w(64, m2 * (4 * jh + jl))
+    # P2 over m2, then T2 = w1024^(n2 k1), k1 = j1 + 16 j2
+    D = [None] * 16
+    for jl in range(4):
+        for j2 in range(4):
+            D[4 * j2 + jl] = sum(v[4 * m2 + jl] * w(4, m2 * j2) for m2 in range(4))
+            D[4 * j2 + jl] = D[4 * j2 + jl] * w(1024, n2 * (4 * jh + jl + 16 * j2))
+    # E2 through LDS: slot = k1 + 65 n2 (write: lane part 4 jh + 65 n2, immediate 16 j2 + jl)
+    lds = np.zeros(1040, complex)
+    seen = set()
     for j2 in range(4):
-        for qq in range(4):
-            for mm in range(4):
-                D[4 * j2 + qq] += C[4 * mm + qq] * w(4, mm * j2)
-            k1 = lj1 + 16 * j2
-            nn2 = 4 * lh + qq
-            D[4 * j2 + qq] *= w(1024, nn2 * k1)
-    # E2
-    lds[:] = 0; seen[:] = False
-    for j2 in range(4):
-        for qq in range(4):
-            idx = e2_index(lj1, j2, lh, qq)
+        for jl in range(4):
+            idx = (16 * j2 + jl) + 4 * jh + 65 * n2
             check_conflicts("e2 write", idx, 16)
-            assert not seen[idx].any(); seen[idx] = True
-            lds[idx] = D[4 * j2 + qq]
-    assert seen.sum() == 1024
-    kj1, kj2 = lane & 15, lane >> 4
-    F = np.zeros_like(A)
-    for hh in range(4):
-        for qq in range(4):
-            idx = e2_index(kj1, kj2, hh, qq)
-            check_conflicts("e2 read", idx, 32)
-            F[4 * hh + qq] = lds[idx]
-    # P3: 16-point DFT over n2 -> Z[lane + 64*k2]
-    G = np.zeros_like(A)
+            seen.update(idx.tolist())
+            lds[idx] = D[4 * j2 + jl]
+    assert len(seen) == 1024 and max(seen) < 1040
+    F = []
+    for nn in range(16):
+        idx = lane + 65 * nn
+        check_conflicts("e2 read", idx, 32)
+        F.append(lds[idx])
+    # P3: 16-point DFT over n2 -> Z[lane + 64 k2]
+    G = np.zeros((16, 64), complex)
     for k2 in range(16):
-        for nn2 in range(16):
-            G[k2] += F[nn2] * w(16, nn2 * k2)
+        for nn in range(16):
+            G[k2] += F[nn] * w(16, nn * k2)
     return G
 
 
@@ -173,7 +115,6 @@ def main():
     refx = np.fft.fft(x)
     for r in range(NR):
         assert np.allclose(X[r], refx[lane + 64 * r], atol=1e-9), r
-    check_maps_b128()
     print("dataflow model OK: complex FFT, real post-processing and LDS swizzles verified")
 
 

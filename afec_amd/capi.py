@@ -105,9 +105,14 @@ def load_library():
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(_LIB_PATH) and "AFX_LIBRARY" not in os.environ:
+        try:
+            build_library()      # hipcc is part of the image, on the GPU box as well
+        except Exception as e:   # noqa: BLE001
+            raise ImportError(f"{_LIB_PATH} is missing and could not be built ({e}); the HIP extension is "
+                              "the only compute path, there is no fallback") from e
     if not os.path.exists(_LIB_PATH):
-        raise ImportError(f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                          "(the HIP extension is the only compute path; there is no fallback)")
+        raise ImportError(f"{_LIB_PATH} is missing (the HIP extension is the only compute path; there is no fallback)")
     L = ctypes.CDLL(_LIB_PATH)
     vp, i32, i64, u32 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32
     L.afx_status_str.restype = ctypes.c_char_p

@@ -84,7 +84,7 @@ def cpu_baseline(frames_per_worker):
     objects, kind "reference") when present, else the oracle restatement (kind "port").  One
     worker process per host core, the analogue of the crawler's one-file-per-task thread pool
     (Crawler.cpp:706-728)."""
-    cores = max(1, min(os.cpu_count() or 1, 64))
+    cores = max(1, min(os.cpu_count() or 1, 64))   # bounded sample: <= 64 worker processes
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     t0 = time.perf_counter()
     if os.path.exists(ref) and os.access(ref, os.X_OK):
@@ -117,14 +117,15 @@ def _oracle_worker(arg):
     return float(Oracle().run_mfcc(x)[0, 0])
 
 
-def measured_traffic(precision, mask_name):
-    """HBM bytes per launch from the committed PMC profile, when one matches this config."""
+def measured_traffic(precision, mask_name, frames):
+    """HBM bytes per launch from the committed rocprofv3 PMC profile of this kernel configuration
+    (bytes per frame x frames of this launch); None when no profile matches."""
     p = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(p):
         return None
     try:
-        t = json.load(open(p))
-        return t.get(f"{mask_name}_{precision}")
+        t = json.load(open(p)).get(f"{mask_name}_{precision}")
+        return None if t is None else t["bytes_per_frame"] * frames
     except Exception:
         return None
 
@@ -138,7 +139,9 @@ def main():
     mask = {"c2": afx.D_C2, "stats": afx.D_MFCC | afx.D_SPECTRAL_STATS,
             "all": afx.D_ALL_LOW_LEVEL}[args.mask]
     precision = afx.PRECISION_F64 if args.precision == "f64" else afx.PRECISION_F32
-    plan = afx.Plan(device=local, precision=precision, max_analysis_ms=0)
+    # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)
+    device = int(os.environ.get("AFX_BENCH_DEVICE", local))
+    plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0)
     bufs = make_buffers(args.buffers, 1234 + rank)
     batch = plan.batch(bufs, mask)
     del bufs
@@ -187,7 +190,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.precision, args.mask),
+                "traffic": measured_traffic(args.precision, args.mask, frames),
                 "kernel": "frames_kernel",
                 "algorithmic_bytes_per_frame": bytes_per_frame,
                 "launch_ms": launch_ms,

@@ -9,11 +9,11 @@
 //
 //   rms, flatness(dB), flux      masked per-band sums, reduced 16 bands at a time (wave_sum16)
 //   complexity                   band maximum (wave_max16) -> threshold -> strict local maxima
-//   contrast                     one 1024-slot bitonic sort in registers on the key
-//                                (band << 60 | double bits >> 4); after the sort every band
+//   contrast                     one 1024-slot bitonic sort in registers on the 32-bit key
+//                                (band << 27 | float bits >> 4); after the sort every band
 //                                occupies a fixed range of positions, so "mean of the n lowest /
-//                                highest" (std::sort + two loops, SA:2200-2228) is again a
-//                                masked sum over static positions
+//                                highest" (std::sort + two loops, SA:2200-2228) is a sum over
+//                                fixed position ranges of the LDS-staged sorted values
 
 #include <hip/hip_runtime.h>
 
@@ -69,77 +69,79 @@ __device__ __forceinline__ double band_max(F value_of_row, int lane) {
   return wave_max16(acc, lane);
 }
 
-using u64 = unsigned long long;
+// ---- 1024-slot bitonic sort of 32-bit keys, p = 16 lane + reg, every comparator ascending ----
+// ("flip" form: the first stage of a merge of size K pairs p with p ^ (K-1), the rest with p ^ J).
+// In-lane comparators are v_min_u32 / v_max_u32; cross-lane partners come through DPP where the
+// lane permutation is one (xor 1, 2, 8; mirrors 3, 7, 15) and through ds_bpermute otherwise.
+using u32 = unsigned;
 
-template <int CTRL>
-__device__ __forceinline__ u64 dpp_mov_u64(u64 v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)v, CTRL, 0xF, 0xF, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)(v >> 32), CTRL, 0xF, 0xF, true);
-  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
-}
-__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int m) {
-  const int lo = __shfl_xor((int)(unsigned)v, m);
-  const int hi = __shfl_xor((int)(unsigned)(v >> 32), m);
-  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
-}
-template <int LM>
-__device__ __forceinline__ u64 lane_xor(u64 v) {
-  if constexpr (LM == 1) return dpp_mov_u64<kDppXor1>(v);
-  else if constexpr (LM == 2) return dpp_mov_u64<kDppXor2>(v);
-  else if constexpr (LM == 8) return dpp_mov_u64<kDppRor8>(v);
-  else return shfl_xor_u64(v, LM);
+template <int M>   // partner = lane ^ M for M in {1, 2, 3, 4, 7, 8, 15, 16, 31, 32, 63}
+__device__ __forceinline__ u32 lane_xor_u32(u32 v) {
+  if constexpr (M == 1) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);        // quad_perm [1,0,3,2]
+  else if constexpr (M == 2) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]
+  else if constexpr (M == 3) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, true);   // quad_perm [3,2,1,0]
+  else if constexpr (M == 7) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror
+  else if constexpr (M == 8) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true);  // row_ror:8
+  else if constexpr (M == 15) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true); // row_mirror
+  else return (u32)__shfl_xor((int)v, M);
 }
 
-// one stage (distance J inside merges of size K) of the bitonic network over p = 16 lane + reg
-template <int K, int J>
-__device__ __forceinline__ void bitonic_stage(u64 (&key)[16], int lane) {
-  if constexpr (J < 16) {
+template <int J>   // in-lane stage: pairs (i, i ^ J) for J < 16, or the flip (i, i ^ (K-1)) for K <= 16 via MASK
+__device__ __forceinline__ void inlane_stage(u32 (&key)[16]) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      if ((i & J) == 0) {
-        const int l = i | J;
-        bool asc;
-        if constexpr (K <= 16) asc = (K == 16) ? ((lane & 1) == 0) : ((i & K) == 0);
-        else asc = (lane & (K >> 4)) == 0;
-        const u64 a = key[i], b = key[l];
-        const bool swap = (a > b) == asc;
-        key[i] = swap ? b : a;
-        key[l] = swap ? a : b;
-      }
-    }
-  } else {
-    constexpr int LM = J >> 4;
-    const bool asc = (K >= 1024) ? true : ((lane & (K >> 4)) == 0);
-    const bool lower = (lane & LM) == 0;
-    const bool take_min = (lower == asc);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const u64 a = key[i];
-      const u64 p = lane_xor<LM>(a);
-      const bool a_lt = a < p;
-      key[i] = (a_lt == take_min) ? a : p;
+  for (int i = 0; i < 16; ++i) {
+    const int l = i ^ J;
+    if (l > i) {
+      const u32 a = key[i], b = key[l];
+      key[i] = a < b ? a : b;
+      key[l] = a < b ? b : a;
     }
   }
 }
+// cross-lane stage: partner lane = lane ^ M, partner register = reg ^ RX (RX = 15 for a flip, 0 otherwise)
+template <int M, int RX>
+__device__ __forceinline__ void crosslane_stage(u32 (&key)[16], int lane) {
+  constexpr int TOP = (M + 1) >> 1 > 0 ? ((M & (M + 1)) == 0 ? (M + 1) >> 1 : M) : M;  // highest set bit of M
+  const bool lower = (lane & TOP) == 0;
+  u32 out[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const u32 a = key[i];
+    const u32 p = lane_xor_u32<M>(key[i ^ RX]);
+    const u32 lo = a < p ? a : p, hi = a < p ? p : a;
+    out[i] = lower ? lo : hi;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) key[i] = out[i];
+}
 template <int K, int J>
-__device__ __forceinline__ void bitonic_merge(u64 (&key)[16], int lane) {
-  bitonic_stage<K, J>(key, lane);
-  if constexpr (J > 1) bitonic_merge<K, J / 2>(key, lane);
+__device__ __forceinline__ void merge_tail(u32 (&key)[16], int lane) {
+  if constexpr (J >= 16) crosslane_stage<(J >> 4), 0>(key, lane);
+  else inlane_stage<J>(key);
+  if constexpr (J > 1) merge_tail<K, J / 2>(key, lane);
 }
 template <int K>
-__device__ __forceinline__ void bitonic_sort(u64 (&key)[16], int lane) {
-  if constexpr (K > 2) bitonic_sort<K / 2>(key, lane);
-  bitonic_merge<K, K / 2>(key, lane);
+__device__ __forceinline__ void sort_level(u32 (&key)[16], int lane) {
+  if constexpr (K > 2) sort_level<K / 2>(key, lane);
+  if constexpr (K <= 16) inlane_stage<K - 1>(key);          // flip inside the lane
+  else crosslane_stage<(K >> 4) - 1, 15>(key, lane);        // flip across lanes: lane ^ (K/16 - 1), reg ^ 15
+  if constexpr (K >= 4) merge_tail<K, K / 4>(key, lane);
 }
 
-__global__ __launch_bounds__(256) void bands_kernel(const BandArgs a) {
-  const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
+  const int lane0 = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t stride = (int64_t)gridDim.x * 4;
   __shared__ double s_thr[4][16];
+  __shared__ float s_sorted[4][1024];
   double* const thr = s_thr[threadIdx.x >> 6];
+  float* const sorted = s_sorted[threadIdx.x >> 6];
 
   for (int64_t f = wave0; f < a.n_frames; f += stride) {
+    // re-materialise the lane id every frame: keeps the hundreds of lane-range predicates below from
+    // being hoisted out of the loop into (spilled) SGPR pairs
+    int lane = lane0;
+    asm volatile("" : "+v"(lane));
     const double* const cur = a.mag + f * kHalf;
     const double* const prv = a.mag + (int64_t)a.prev[f] * kHalf;
     double x[kRows], y[kRows];
@@ -184,8 +186,10 @@ __global__ __launch_bounds__(256) void bands_kernel(const BandArgs a) {
     }
     const double cplx = band_sum([&](int r) { return pk[r]; }, lane);
 
-    // ---- contrast: sort (band, value) keys, then static position ranges ----
-    u64 key[16];
+    // ---- contrast: sort (band, value) keys, then fixed position ranges ----
+    // key = band << 27 | float bits >> 4 (rounded): 19 mantissa bits order the values, and the sums
+    // below are rebuilt from the keys (relative error <= 2^-20 per element, far inside the 1e-4 bar)
+    u32 key[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (r < kRows) {
@@ -193,30 +197,32 @@ __global__ __launch_bounds__(256) void bands_kernel(const BandArgs a) {
 #pragma unroll
         for (int b = 0; b < kNumSub; ++b)
           if (sub_touches(b, r)) bid = in_band(b, r, lane) ? b : bid;
-        const u64 bits = (u64)__double_as_longlong(fabs(x[r]));
-        key[r] = ((u64)bid << 60) | (bits >> 4);
+        const u32 bits = __float_as_uint((float)fabs(x[r]));
+        key[r] = ((u32)bid << 27) | ((bits + 8u) >> 4);
       } else {
-        key[r] = ~0ull;
+        key[r] = 0x7FFFFFFFu;
       }
     }
-    bitonic_sort<1024>(key, lane);
-    // sorted position p = 16 lane + i holds key[i]; band b sits at [sub_pos0(b), sub_pos0(b) + n_b)
+    sort_level<1024>(key, lane);
+    // sorted position p = 16 lane + i; stage the values in LDS in position order
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sorted[16 * lane + i] = __uint_as_float((key[i] & 0x07FFFFFFu) << 4);
+    wave_lds_fence();
+    // band b sits at [pos0, pos0 + n): valley = first nn, peak = last nn (nn <= 86 -> two passes of 64 lanes)
     double valley_acc[16], peak_acc[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
       valley_acc[b] = 0.0;
       peak_acc[b] = 0.0;
-    }
-    const int p0 = 16 * lane;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int p = p0 + i;
-      const double v = __longlong_as_double((long long)((key[i] & 0x0FFFFFFFFFFFFFFFull) << 4));
-#pragma unroll
-      for (int b = 0; b < kNumSub; ++b) {
+      if (b < kNumSub) {
         const int lo = sub_pos0(b), n = kSubN[b], nn = kSubNeigh[b];
-        valley_acc[b] += (p >= lo && p < lo + nn) ? v : 0.0;
-        peak_acc[b] += (p >= lo + n - nn && p < lo + n) ? v : 0.0;
+#pragma unroll
+        for (int t0 = 0; t0 < nn; t0 += 64) {
+          const int t = t0 + lane;
+          valley_acc[b] += (t < nn) ? (double)sorted[lo + (t < nn ? t : 0)] : 0.0;
+          peak_acc[b] += (t < nn) ? (double)sorted[lo + n - nn + (t < nn ? t : 0)] : 0.0;
+        }
       }
     }
     const double vsum = wave_sum16(valley_acc, lane);

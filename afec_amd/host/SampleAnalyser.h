@@ -1,0 +1,95 @@
+// afec_amd/host/SampleAnalyser.h -- C++ host side above the C-ABI (include/afx.h), mirroring the
+// reference's interface for this path: TSampleAnalyser (Export/SampleAnalyser.h:33-63) and the
+// low-level part of TSampleDescriptors (Export/SampleDescriptors.h:152-356, 395-465).  Same names,
+// same argument meaning, errors as exceptions (TReadableException there, std::runtime_error here).
+//
+// Only what the GPU path produces is present: the stateful neighbours of the loop (whitening,
+// pitch, rhythm) are not part of this library.
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+struct afx_plan;
+
+namespace afec {
+
+class TReadableException : public std::runtime_error {
+public:
+  explicit TReadableException(const std::string& What) : std::runtime_error(What) {}
+};
+
+// TSampleDescriptors::TFramedScalarData (SampleDescriptors.h:152-230): values per frame plus the
+// 13 statistics TStatistics::Calc fills
+struct TFramedScalarData {
+  std::vector<double> mValues;  // [frame]
+  double mMin = 0, mMax = 0, mMedian = 0, mMean = 0, mGeometricMean = 0, mVariance = 0, mCentroid = 0,
+         mSpread = 0, mSkewness = 0, mKurtosis = 0, mFlatness = 0, mDMean = 0, mDVariance = 0;
+  void CalcStatistics();
+};
+
+// TSampleDescriptors::TFramedVectorData<W> (SampleDescriptors.h:262-356): [frame][band] values plus
+// per-band statistics
+template <int W>
+struct TFramedVectorData {
+  std::vector<std::array<double, W>> mValues;  // [frame][band]
+  std::array<double, W> mMin{}, mMax{}, mMedian{}, mMean{}, mGeometricMean{}, mVariance{}, mCentroid{},
+      mSpread{}, mSkewness{}, mKurtosis{}, mFlatness{}, mDMean{}, mDVariance{};
+  void CalcStatistics();
+};
+
+// the low-level descriptors of TSampleDescriptors that lie on the GPU path
+struct TSampleDescriptors {
+  enum { kNumberOfSpectrumSubBands = 14, kNumberOfSpectrumBands = 28, kNumberOfCepstrumCoefficients = 14 };
+
+  TFramedScalarData mAmplitudePeak, mAmplitudeRms;
+  TFramedScalarData mSpectralRms, mSpectralCentroid, mSpectralRolloff, mSpectralSpread, mSpectralSkewness,
+      mSpectralKurtosis, mSpectralFlatness, mSpectralContrast, mSpectralFlux;
+  TFramedVectorData<kNumberOfSpectrumSubBands> mSpectralRmsBands, mSpectralFlatnessBands, mSpectralFluxBands,
+      mSpectralComplexityBands, mSpectralContrastBands;
+  TFramedVectorData<kNumberOfSpectrumBands> mSpectrumBands;
+  TFramedVectorData<kNumberOfCepstrumCoefficients> mCepstrumBands;
+
+  // magnitude spectra [frame][1024] for the CPU-resident neighbours (optional)
+  std::vector<double> mMagnitudeSpectrum;
+
+  // TSampleAnalyser::CalcStatistics (SampleAnalyser.cpp:2402-2412)
+  void CalcStatistics();
+};
+
+// TStatistics::Calc (Statistics.cpp:12-90) on the host, used by CalcStatistics above
+namespace TStatistics {
+void Calc(double& Min, double& Max, double& Median, double& Mean, double& GeometricMean, double& Variance,
+          double& Centroid, double& Spread, double& Skewness, double& Kurtosis, double& Flatness,
+          double& AbsDMean, double& AbsDVariance, const double* pX, int Length);
+}
+
+class TSampleAnalyser {
+public:
+  // Device: HIP device ordinal.  Throws TReadableException when the GPU path cannot be set up.
+  TSampleAnalyser(int SampleRate, int FftFrameSize, int HopFrameSize, int Device = 0);
+  ~TSampleAnalyser();
+  TSampleAnalyser(const TSampleAnalyser&) = delete;
+  TSampleAnalyser& operator=(const TSampleAnalyser&) = delete;
+
+  // frames the loop yields for a normalised buffer (SampleAnalyser.cpp:760-764, 814)
+  int64_t NumberOfFrames(int64_t NumberOfSamples) const;
+
+  // AnalyzeLowLevelDescriptors for one decoded, mono, peak-normalised sample
+  // (TSampleData::mData); const and thread-safe like the reference
+  TSampleDescriptors AnalyzeLowLevelDescriptors(const std::vector<double>& SampleData, bool WithMagnitudes = false) const;
+
+  // the same for many samples in one GPU batch; Failed[i] receives the message for buffers
+  // that could not be analysed (one bad sample does not fail the batch, SampleAnalyser.cpp:368-408)
+  std::vector<TSampleDescriptors> AnalyzeLowLevelDescriptors(
+      const std::vector<const std::vector<double>*>& Samples, std::vector<std::string>* pFailed = nullptr) const;
+
+private:
+  afx_plan* mpPlan;
+  int mSampleRate, mFftFrameSize, mHopFrameSize;
+};
+
+}  // namespace afec

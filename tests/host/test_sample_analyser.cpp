@@ -1,0 +1,119 @@
+// tests/host/test_sample_analyser.cpp -- C++ tests of the host layer, written like the reference's
+// own Boost tests (Source/Crawler/FeatureExtraction/Test/TestStatistics.cpp).
+//
+//   host_test stats     TStatistics::Calc known answers (no GPU)
+//   host_test analyse   TSampleAnalyser::AnalyzeLowLevelDescriptors vs the oracle (GPU)
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <random>
+#include <vector>
+
+#include "../../afec_amd/host/SampleAnalyser.h"
+#include "../../oracle/afx_oracle.h"
+
+static int gFailures = 0;
+#define CHECK(cond)                                                            \
+  do {                                                                         \
+    if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); ++gFailures; } \
+  } while (0)
+#define CHECK_EQUAL_EPSILON(a, b, eps) CHECK(std::fabs((a) - (b)) <= (eps))
+
+static void Calc13(const std::vector<double>& x, double (&s)[13]) {
+  afec::TStatistics::Calc(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], x.data(),
+                          (int)x.size());
+}
+
+static int TestStatistics() {
+  // TestStatistics.cpp:36-58
+  const std::vector<std::vector<double>> Seqs = {{1, 2, 3, 4, 5, 6}, {6, 5, 4, 3, 2, 1}, {3, 2, 4, 6, 5, 1}, {4, 3, 6, 5, 2, 1}};
+  for (const auto& q : Seqs) {
+    double s[13] = {0};
+    Calc13(q, s);
+    CHECK(s[0] == 1 && s[1] == 6);
+    CHECK(s[2] == 3);                            // Median
+    CHECK_EQUAL_EPSILON(s[3], 21.0 / 6, 1e-16);  // Mean
+    CHECK_EQUAL_EPSILON(s[5], 2.9, 0.1);         // Variance
+    CHECK_EQUAL_EPSILON(s[4], 3.0, 1.0);         // GeometricMean, roughly
+  }
+  // TestStatistics.cpp:62-90 (centroid)
+  double s[13] = {0};
+  Calc13({1, 1, 1, 1, 1, 1}, s);
+  CHECK_EQUAL_EPSILON(s[6], 2.5, 0.001);
+  // against the oracle restatement on random series, incl. the Length <= 2 branches
+  std::mt19937 gen(5);
+  std::uniform_real_distribution<double> U(-3.0, 5.0);
+  for (int n : {0, 1, 2, 3, 7, 64, 85, 860}) {
+    std::vector<double> x((size_t)n);
+    for (auto& v : x) v = U(gen);
+    double a[13], b[13];
+    for (int i = 0; i < 13; ++i) a[i] = b[i] = 7.0;
+    Calc13(x, a);
+    afx_oracle_calc_statistics(x.data(), n, b);
+    for (int i = 0; i < 13; ++i) CHECK_EQUAL_EPSILON(a[i], b[i], 1e-12 * (1.0 + std::fabs(b[i])));
+  }
+  return gFailures;
+}
+
+static int TestAnalyse() {
+  std::mt19937 gen(9);
+  std::uniform_real_distribution<double> U(-1.0, 1.0);
+  std::vector<double> a(2048 + 1024 * 20), b(5000), c(100);
+  for (size_t i = 0; i < a.size(); ++i) a[i] = 0.5 * std::sin(2 * M_PI * 440.0 * i / 44100.0) + 0.1 * U(gen);
+  for (auto& v : b) v = U(gen);
+  for (auto& v : c) v = U(gen);
+
+  afec::TSampleAnalyser Analyser(44100, 2048, 1024);
+  CHECK(Analyser.NumberOfFrames(882000) == 860 && Analyser.NumberOfFrames(900000) == 860);  // 20 s cap
+  std::vector<std::string> Failed;
+  const auto Results = Analyser.AnalyzeLowLevelDescriptors({&a, &b, &c}, &Failed);
+  CHECK(Results.size() == 3 && Failed[0].empty() && Failed[1].empty() && Failed[2].empty());
+  CHECK(Results[2].mSpectralRms.mValues.empty());   // shorter than one frame: no frames, no error
+
+  afx_oracle* o = afx_oracle_create(44100, 2048, 1024);
+  const std::vector<double>* Inputs[2] = {&a, &b};
+  for (int i = 0; i < 2; ++i) {
+    const int64_t nf = afx_oracle_num_frames(o, (int64_t)Inputs[i]->size(), 1);
+    std::vector<double> rec((size_t)nf * AFXO_RECORD);
+    afx_oracle_run(o, Inputs[i]->data(), (int64_t)Inputs[i]->size(), 1, rec.data());
+    const auto& R = Results[i];
+    CHECK((int64_t)R.mCepstrumBands.mValues.size() == nf);
+    for (int64_t f = 0; f < nf; ++f) {
+      const double* r = &rec[(size_t)f * AFXO_RECORD];
+      for (int k = 0; k < 14; ++k) CHECK_EQUAL_EPSILON(R.mCepstrumBands.mValues[f][k], r[AFXO_MFCC + k], 1e-4 * std::fabs(r[AFXO_MFCC + k]) + 1e-6);
+      for (int k = 0; k < 28; ++k) CHECK_EQUAL_EPSILON(R.mSpectrumBands.mValues[f][k], r[AFXO_BANDS + k], 1e-4 * r[AFXO_BANDS + k] + 1e-18);
+      for (int k = 0; k < 14; ++k) CHECK_EQUAL_EPSILON(R.mSpectralContrastBands.mValues[f][k], r[AFXO_SUB_CONTRAST + k], 1e-4 * std::fabs(r[AFXO_SUB_CONTRAST + k]) + 1e-9);
+      CHECK_EQUAL_EPSILON(R.mSpectralCentroid.mValues[f], r[AFXO_CENTROID], 1e-4 * r[AFXO_CENTROID] + 1e-7);
+      CHECK(R.mSpectralRolloff.mValues[f] == r[AFXO_ROLLOFF]);
+      CHECK_EQUAL_EPSILON(R.mSpectralFlux.mValues[f], r[AFXO_FLUX], 1e-4 * std::fabs(r[AFXO_FLUX]) + 1e-7);
+      CHECK(R.mAmplitudePeak.mValues[f] == r[AFXO_AMP_PEAK]);
+    }
+    // per-file statistics of one series against the oracle's TStatistics::Calc
+    std::vector<double> series((size_t)nf);
+    for (int64_t f = 0; f < nf; ++f) series[(size_t)f] = rec[(size_t)f * AFXO_RECORD + AFXO_CENTROID];
+    double s[13] = {0};
+    afx_oracle_calc_statistics(series.data(), (int)nf, s);
+    CHECK_EQUAL_EPSILON(R.mSpectralCentroid.mMedian, s[2], 1e-4 * s[2]);
+    CHECK_EQUAL_EPSILON(R.mSpectralCentroid.mVariance, s[5], 1e-3 * s[5] + 1e-9);
+  }
+  afx_oracle_destroy(o);
+
+  // error behaviour: an unsupported geometry throws like the reference's constructor would assert
+  bool Thrown = false;
+  try { afec::TSampleAnalyser Bad(48000, 2048, 1024); } catch (const afec::TReadableException&) { Thrown = true; }
+  CHECK(Thrown);
+  return gFailures;
+}
+
+int main(int argc, char** argv) {
+  int rc = 2;
+  try {
+    if (argc >= 2 && !std::strcmp(argv[1], "stats")) rc = TestStatistics();
+    else if (argc >= 2 && !std::strcmp(argv[1], "analyse")) rc = TestAnalyse();
+  } catch (const std::exception& e) {
+    std::printf("EXCEPTION: %s\n", e.what());
+    return 3;
+  }
+  if (rc == 0) std::printf("OK\n");
+  return rc;
+}

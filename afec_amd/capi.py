@@ -27,6 +27,10 @@ D_BAND_FEATURES = 1 << 10
 D_AMPLITUDE_PEAK = 1 << 11
 D_AMPLITUDE_RMS = 1 << 12
 D_MAGNITUDE = 1 << 13
+D_STATISTICS = 1 << 14
+NUM_STATISTICS = 13
+STAT_NAMES = ["min", "max", "median", "mean", "gmean", "variance", "centroid", "spread", "skewness",
+              "kurtosis", "flatness", "dmean", "dvariance"]
 D_C2 = D_MFCC
 D_SPECTRAL_STATS = 0x1FE
 D_ALL_LOW_LEVEL = 0x1FFF
@@ -38,7 +42,7 @@ EXPORTS = [
     "afx_status_str", "afx_last_error", "afx_plan_create", "afx_plan_destroy",
     "afx_plan_get_window", "afx_plan_get_mel_table", "afx_plan_get_bin_range", "afx_num_frames",
     "afx_extract_batch", "afx_batch_create", "afx_batch_total_frames", "afx_batch_run",
-    "afx_batch_sync", "afx_batch_run_timed", "afx_batch_fetch", "afx_batch_destroy",
+    "afx_batch_sync", "afx_batch_run_timed", "afx_batch_fetch", "afx_batch_fetch_statistics", "afx_batch_destroy",
     "afx_algorithmic_bytes_per_frame",
 ]
 
@@ -82,6 +86,10 @@ class _Buf(ctypes.Structure):
 class _Out(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n, _ in OUT_FIELDS] + [
         ("frame_offset", ctypes.c_void_p), ("buf_status", ctypes.c_void_p)]
+
+
+class _StatsOut(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_void_p) for n, _ in OUT_FIELDS if n != "magnitude"] + [("stats_status", ctypes.c_void_p)]
 
 
 def library_path():
@@ -134,6 +142,7 @@ def load_library():
     L.afx_batch_sync.argtypes = [vp]
     L.afx_batch_run_timed.argtypes = [vp, i32, ctypes.POINTER(ctypes.c_float)]
     L.afx_batch_fetch.argtypes = [vp, ctypes.POINTER(_Out)]
+    L.afx_batch_fetch_statistics.argtypes = [vp, ctypes.POINTER(_StatsOut)]
     L.afx_batch_destroy.argtypes = [vp]
     L.afx_batch_destroy.restype = None
     L.afx_algorithmic_bytes_per_frame.restype = i64
@@ -268,6 +277,22 @@ class Batch:
     def fetch(self):
         out, res = _alloc_out(self.mask, self.total_frames, self.n_bufs)
         _check(self.L, self.L.afx_batch_fetch(self.h, ctypes.byref(out)))
+        return res
+
+    def fetch_statistics(self):
+        """dict name -> [n_bufs, W, 13] (W squeezed for scalar series) + "stats_status"."""
+        out = _StatsOut()
+        res = {}
+        for name, width in OUT_FIELDS:
+            if name == "magnitude" or not (self.mask & FIELD_MASK[name]):
+                continue
+            a = np.zeros((self.n_bufs, width, NUM_STATISTICS) if width > 1 else (self.n_bufs, NUM_STATISTICS))
+            res[name] = a
+            setattr(out, name, a.ctypes.data if a.size else None)
+        st = np.zeros(max(1, self.n_bufs), dtype=np.int32)
+        out.stats_status = st.ctypes.data
+        _check(self.L, self.L.afx_batch_fetch_statistics(self.h, ctypes.byref(out)))
+        res["stats_status"] = st[:self.n_bufs]
         return res
 
     def close(self):

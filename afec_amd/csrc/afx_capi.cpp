@@ -151,6 +151,8 @@ struct afx_batch {
   double* d_rec = nullptr;
   double* d_mag = nullptr;
   int32_t* d_prev = nullptr;
+  int64_t* d_frame_offset = nullptr;
+  double* d_stats = nullptr;
   bool mag_wanted = false;
 };
 
@@ -381,8 +383,11 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
   if (!plan || !out_batch || n_bufs < 0 || (n_bufs > 0 && !bufs))
     return fail(AFX_ERR_INVALID_ARG, "null argument");
   *out_batch = nullptr;
-  if (mask == 0 || (mask & ~(uint32_t)(AFX_D_ALL_LOW_LEVEL | AFX_D_MAGNITUDE)))
+  if ((mask & ~(uint32_t)AFX_D_STATISTICS) == 0 ||
+      (mask & ~(uint32_t)(AFX_D_ALL_LOW_LEVEL | AFX_D_MAGNITUDE | AFX_D_STATISTICS)))
     return fail(AFX_ERR_INVALID_ARG, "bad descriptor mask");
+  const bool want_stats = (mask & AFX_D_STATISTICS) != 0;
+  mask &= ~(uint32_t)AFX_D_STATISTICS;   // the kernels see the descriptor bits only
   HIP_TRY(hipSetDevice(plan->desc.device));
 
   afx_batch* b = new (std::nothrow) afx_batch();
@@ -489,6 +494,11 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
     if ((e = hipMalloc((void**)&b->d_prev, prev.size() * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(prev)"));
     if ((e = hipMemcpyAsync(b->d_prev, prev.data(), prev.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(prev)"));
   }
+  if (want_stats && n_bufs > 0 && b->lay.stride > 0) {
+    if ((e = hipMalloc((void**)&b->d_frame_offset, b->frame_offset.size() * sizeof(int64_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(frame_offset)"));
+    if ((e = hipMemcpyAsync(b->d_frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(frame_offset)"));
+    if ((e = hipMalloc((void**)&b->d_stats, (size_t)n_bufs * b->lay.stride * 13 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stats)"));
+  }
   if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
   *out_batch = b;
   return AFX_OK;
@@ -515,6 +525,12 @@ int afx_batch_run(afx_batch* b) {
     afx::BandArgs ba{};
     ba.mag = b->d_mag; ba.prev = b->d_prev; ba.n_frames = b->total_frames; ba.rec = b->d_rec; ba.lay = b->lay;
     HIP_TRY(afx::launch_bands(ba, b->stream));
+  }
+  if (b->d_stats) {
+    afx::StatsArgs sa{};
+    sa.rec = b->d_rec; sa.frame_offset = b->d_frame_offset; sa.n_bufs = b->n_bufs; sa.stride = b->lay.stride;
+    sa.stats = b->d_stats;
+    HIP_TRY(afx::launch_stats(sa, b->stream));
   }
   return AFX_OK;
 }
@@ -575,11 +591,46 @@ int afx_batch_fetch(afx_batch* b, afx_out* out) {
   return AFX_OK;
 }
 
+int afx_batch_fetch_statistics(afx_batch* b, afx_stats_out* out) {
+  if (!b || !out) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  if (b->n_bufs == 0) return AFX_OK;
+  if (!b->d_stats) return fail(AFX_ERR_INVALID_ARG, "AFX_D_STATISTICS was not in the batch mask");
+  HIP_TRY(hipSetDevice(b->plan->desc.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  const afx::RecordLayout& l = b->lay;
+  std::vector<double> st((size_t)b->n_bufs * l.stride * 13);
+  HIP_TRY(hipMemcpy(st.data(), b->d_stats, st.size() * sizeof(double), hipMemcpyDeviceToHost));
+  struct Field { double* dst; int32_t off; int width; };
+  const Field fields[] = {
+      {out->mfcc, l.mfcc, 14}, {out->spectral_rms, l.srms, 1}, {out->spectral_centroid, l.centroid, 1},
+      {out->spectral_spread, l.spread, 1}, {out->spectral_skewness, l.skew, 1},
+      {out->spectral_kurtosis, l.kurt, 1}, {out->spectral_rolloff, l.rolloff, 1},
+      {out->spectral_flatness, l.flatness, 1}, {out->spectral_flux, l.flux, 1},
+      {out->spectrum_bands, l.bands, 28}, {out->amplitude_peak, l.amp_peak, 1},
+      {out->amplitude_rms, l.amp_rms, 1}, {out->sub_rms, l.sub_rms, 14}, {out->sub_flatness, l.sub_flat, 14},
+      {out->sub_flux, l.sub_flux, 14}, {out->sub_complexity, l.sub_cplx, 14},
+      {out->sub_contrast, l.sub_contrast, 14}, {out->spectral_contrast, l.contrast, 1}};
+  for (const Field& f : fields) {
+    if (!f.dst) continue;
+    if (f.off < 0) return fail(AFX_ERR_INVALID_ARG, "statistics requested for a series that is not in the batch mask");
+    for (int32_t i = 0; i < b->n_bufs; ++i)
+      std::memcpy(f.dst + (size_t)i * f.width * 13, st.data() + ((size_t)i * l.stride + f.off) * 13,
+                  (size_t)f.width * 13 * sizeof(double));
+  }
+  if (out->stats_status)
+    for (int32_t i = 0; i < b->n_bufs; ++i) {
+      const int64_t n = b->frame_offset[i + 1] - b->frame_offset[i];
+      out->stats_status[i] = (b->buf_status[i] != AFX_OK) ? b->buf_status[i] : (n > 1024 ? AFX_ERR_UNSUPPORTED : AFX_OK);
+    }
+  return AFX_OK;
+}
+
 void afx_batch_destroy(afx_batch* b) {
   if (!b) return;
   hipSetDevice(b->plan->desc.device);
   if (b->stream) hipStreamSynchronize(b->stream);
   hipFree(b->d_pcm); hipFree(b->d_chunks); hipFree(b->d_rec); hipFree(b->d_mag); hipFree(b->d_prev);
+  hipFree(b->d_frame_offset); hipFree(b->d_stats);
   if (b->ev0) hipEventDestroy(b->ev0);
   if (b->ev1) hipEventDestroy(b->ev1);
   if (b->stream) hipStreamDestroy(b->stream);

@@ -107,4 +107,14 @@ struct BandArgs {
 };
 hipError_t launch_bands(const BandArgs& a, hipStream_t stream);
 
+// per-buffer statistics of every record column (TStatistics::Calc, Statistics.cpp:12-90)
+struct StatsArgs {
+  const double* rec;            // [F][stride]
+  const int64_t* frame_offset;  // [n_bufs + 1], device
+  int32_t n_bufs;
+  int32_t stride;
+  double* stats;                // [n_bufs][stride][13]
+};
+hipError_t launch_stats(const StatsArgs& a, hipStream_t stream);
+
 }  // namespace afx

@@ -1,0 +1,214 @@
+// afec_amd/csrc/afx_stats.hip -- per-file statistics of every framed series:
+// TStatistics::Calc (Statistics.cpp:12-90) as TFramedScalarData / TFramedVectorData::OnCalcStatistics
+// apply it to each series after the frame loop (SampleAnalyser.cpp:1065, 2402-2412).
+//
+// One wave per (buffer, record column).  A series of n <= 1024 frames sits in registers as
+// x[16 lane' + i] ... (position p = R lane + reg, R = 1, 2, 4, 8 or 16 registers per lane picked
+// from n), the moments are wave reductions, the median comes from a bitonic sort of
+// order-preserving 64-bit keys (Statistics.cpp:316-413 selects element (n-1)/2 of the sorted
+// series, i.e. the lower median).  Results: double[n_bufs][stride][13].
+
+#include <hip/hip_runtime.h>
+
+#include "afx_internal.h"
+#include "afx_device.h"
+
+namespace afx {
+namespace {
+
+using u64 = unsigned long long;
+
+__device__ __forceinline__ u64 shfl_xor64(u64 v, int m) {
+  const int lo = __shfl_xor((int)(unsigned)v, m);
+  const int hi = __shfl_xor((int)(unsigned)(v >> 32), m);
+  return ((u64)(unsigned)hi << 32) | (unsigned)lo;
+}
+
+// bitonic sort of R x 64 keys, p = R lane + reg, all comparators ascending ("flip" form)
+template <int R, int J>
+__device__ __forceinline__ void stat_inlane(u64 (&key)[R]) {
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int l = i ^ J;
+    if (l > i && l < R) {
+      const u64 a = key[i], b = key[l];
+      key[i] = a < b ? a : b;
+      key[l] = a < b ? b : a;
+    }
+  }
+}
+template <int R, int M, bool FLIP>
+__device__ __forceinline__ void stat_crosslane(u64 (&key)[R], int lane) {
+  constexpr int TOP = ((M & (M + 1)) == 0) ? (M + 1) >> 1 : M;
+  const bool lower = (lane & TOP) == 0;
+  u64 out[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const u64 a = key[i];
+    const u64 p = shfl_xor64(key[FLIP ? (R - 1 - i) : i], M);
+    const u64 lo = a < p ? a : p, hi = a < p ? p : a;
+    out[i] = lower ? lo : hi;
+  }
+#pragma unroll
+  for (int i = 0; i < R; ++i) key[i] = out[i];
+}
+template <int R, int J>
+__device__ __forceinline__ void stat_tail(u64 (&key)[R], int lane) {
+  if constexpr (J >= R) stat_crosslane<R, J / R, false>(key, lane);
+  else stat_inlane<R, J>(key);
+  if constexpr (J > 1) stat_tail<R, J / 2>(key, lane);
+}
+template <int R, int K>
+__device__ __forceinline__ void stat_sort(u64 (&key)[R], int lane) {
+  if constexpr (K > 2) stat_sort<R, K / 2>(key, lane);
+  if constexpr (K <= R) stat_inlane<R, K - 1>(key);
+  else stat_crosslane<R, K / R - 1, true>(key, lane);
+  if constexpr (K >= 4) stat_tail<R, K / 4>(key, lane);
+}
+
+__device__ __forceinline__ u64 order_key(double v) {
+  const u64 b = (u64)__double_as_longlong(v);
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(u64 k) {
+  const u64 b = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)b);
+}
+
+__device__ __forceinline__ double wave_min(double v) {
+  v = fmin(v, dpp_mov<kDppXor1>(v));
+  v = fmin(v, dpp_mov<kDppXor2>(v));
+  v = fmin(v, dpp_mov<kDppHalfMirror>(v));
+  v = fmin(v, dpp_mov<kDppMirror>(v));
+  v = fmin(v, __shfl_xor(v, 16));
+  v = fmin(v, __shfl_xor(v, 32));
+  return v;
+}
+
+// statistics of one series held as x[reg] = series[R lane + reg]; n >= 2
+template <int R>
+__device__ void series_stats(const double* col, int64_t cstride, int n, int lane, double* out) {
+  double x[R], nxt[R];
+  bool ok[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int p = R * lane + i;
+    ok[i] = p < n;
+    x[i] = ok[i] ? col[(int64_t)p * cstride] : 0.0;
+    nxt[i] = (p + 1 < n) ? col[(int64_t)(p + 1) * cstride] : 0.0;
+  }
+  const double dn = (double)n;
+  double mn = 1.0e308, mx = -1.0e308, s = 0.0, sj = 0.0, slog = 0.0, sd = 0.0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int p = R * lane + i;
+    mn = ok[i] ? fmin(mn, x[i]) : mn;
+    mx = ok[i] ? fmax(mx, x[i]) : mx;
+    s += x[i];
+    sj += (double)p * x[i];
+    slog += ok[i] ? fast_log(fabs(x[i]) + 1e-20) : 0.0;    // GeometricMean, Statistics.cpp:417-455
+    sd += (p + 1 < n) ? fabs(nxt[i] - x[i]) : 0.0;
+  }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  s = wave_sum(s);
+  sj = wave_sum(sj);
+  slog = wave_sum(slog);
+  sd = wave_sum(sd);
+  const double mean = s / dn;                                // Mean, n >= 2
+  const double gmean = exp(slog / dn);
+  const double cen = (s == 0.0) ? 0.0 : sj / s;              // Centroid, Statistics.cpp:459-477
+  const int nd = n - 1;
+  const double dmean = (nd >= 2) ? sd / (double)nd : sd;     // Mean of the n-1 absolute differences
+  double var = 0.0, sv = 0.0, dvar = 0.0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int p = R * lane + i;
+    const double t = x[i] - mean;
+    var += ok[i] ? t * t : 0.0;
+    const double u = (double)p - cen;
+    sv += ok[i] ? u * u * x[i] : 0.0;
+    const double w = fabs(nxt[i] - x[i]) - dmean;
+    dvar += (p + 1 < n) ? w * w : 0.0;
+  }
+  var = wave_sum(var) / dn;
+  sv = wave_sum(sv);
+  dvar = wave_sum(dvar);
+  const double spr = (s == 0.0) ? 0.0 : sv / s;              // Spread, Statistics.cpp:486-506
+  double sk = 0.0, ku = 0.0;
+  if (fabs(spr) > (double)1e-12f) {                          // Statistics.cpp:510-554
+#pragma unroll
+    for (int i = 0; i < R; ++i) {
+      const double t = (x[i] - cen) / spr;
+      const double tt = t * t;
+      sk += ok[i] ? tt * t : 0.0;
+      ku += ok[i] ? tt * tt : 0.0;
+    }
+    sk = wave_sum(sk) / dn;
+    ku = wave_sum(ku) / dn - 3.0;
+  }
+  // median: element (n-1)/2 of the sorted series
+  u64 key[R];
+#pragma unroll
+  for (int i = 0; i < R; ++i) key[i] = ok[i] ? order_key(x[i]) : ~0ull;
+  stat_sort<R, 64 * R>(key, lane);
+  const int pm = (n - 1) / 2;
+  u64 km = 0;
+#pragma unroll
+  for (int i = 0; i < R; ++i) {
+    const int lo = __shfl((int)(unsigned)key[i], pm / R), hi = __shfl((int)(unsigned)(key[i] >> 32), pm / R);
+    if ((pm % R) == i) km = ((u64)(unsigned)hi << 32) | (unsigned)lo;
+  }
+  if (lane == 0) {
+    out[0] = mn; out[1] = mx; out[2] = key_value(km); out[3] = mean; out[4] = gmean; out[5] = var;
+    out[6] = cen; out[7] = spr; out[8] = sk; out[9] = ku;
+    out[10] = (mean == 0.0) ? 0.0 : gmean / mean;            // Flatness, Statistics.cpp:565-574
+    out[11] = (n > 2) ? dmean : 0.0;
+    out[12] = (n > 2) ? ((nd >= 2) ? dvar / (double)nd : 0.0) : 0.0;
+  }
+}
+
+__global__ __launch_bounds__(256) void stats_kernel(const StatsArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t total = (int64_t)a.n_bufs * a.stride;
+  for (int64_t w = wave0; w < total; w += (int64_t)gridDim.x * 4) {
+    const int64_t buf = w / a.stride;
+    const int colidx = (int)(w - buf * a.stride);
+    const int64_t f0 = a.frame_offset[buf];
+    const int64_t nn = a.frame_offset[buf + 1] - f0;
+    double* const out = a.stats + w * 13;
+    const double* const col = a.rec + f0 * a.stride + colidx;
+    if (nn > 1024) {   // not representable in one wave's registers: flagged, host reports AFX_ERR_UNSUPPORTED
+      if (lane < 13) out[lane] = __longlong_as_double(0x7FF8000000000000ll);
+      continue;
+    }
+    const int n = (int)nn;
+    if (n <= 1) {      // Statistics.cpp:72-89: only min/max/mean (and zeros) are assigned
+      if (lane < 13) out[lane] = 0.0;
+      if (n == 1 && lane == 0) {
+        const double v = col[0];
+        out[0] = v; out[1] = v; out[3] = v;
+      }
+      continue;
+    }
+    if (n <= 64) series_stats<1>(col, a.stride, n, lane, out);
+    else if (n <= 128) series_stats<2>(col, a.stride, n, lane, out);
+    else if (n <= 256) series_stats<4>(col, a.stride, n, lane, out);
+    else if (n <= 512) series_stats<8>(col, a.stride, n, lane, out);
+    else series_stats<16>(col, a.stride, n, lane, out);
+  }
+}
+
+}  // namespace
+
+hipError_t launch_stats(const StatsArgs& a, hipStream_t stream) {
+  const int64_t total = (int64_t)a.n_bufs * a.stride;
+  if (total <= 0) return hipSuccess;
+  const int64_t want = (total + 3) / 4;
+  const int grid = (int)(want < 256 * 32 ? want : 256 * 32);
+  hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -66,6 +66,9 @@ enum {
   AFX_D_AMPLITUDE_RMS = 1u << 12,    /* amplitude_rms       [F]      :1774-1783 */
   AFX_D_MAGNITUDE = 1u << 13,        /* magnitude spectrum  [F][1024] for CPU-resident consumers
                                         (whitening, pitch; SampleAnalyser.cpp:850-927)        */
+  AFX_D_STATISTICS = 1u << 14,       /* additionally reduce every selected series of every buffer to
+                                        the 13 values of TStatistics::Calc (Statistics.cpp:12-90),
+                                        as TSampleAnalyser::CalcStatistics does (SampleAnalyser.cpp:2402) */
   AFX_D_C2 = AFX_D_MFCC,
   AFX_D_SPECTRAL_STATS = 0x1FEu,     /* bits 1..8 */
   AFX_D_ALL_LOW_LEVEL = 0x1FFFu      /* everything except the raw magnitudes */
@@ -137,6 +140,38 @@ typedef struct {
                                 does not fail the batch, cf. SampleAnalyser.cpp:368-408)      */
 } afx_out;
 
+/* Per-buffer statistics (AFX_D_STATISTICS): the same fields as afx_out, each an array
+ * [n_bufs][W][AFX_NUM_STATISTICS] of doubles (W = 1 for scalar series), in the order of
+ * TFramedScalarData's members (SampleDescriptors.h:172-186).  Series of more than 1024 frames (only
+ * possible with the 20 s cap disabled) are not reduced: their buffer gets AFX_ERR_UNSUPPORTED in
+ * stats_status and NaNs in the arrays. */
+#define AFX_NUM_STATISTICS 13
+enum {
+  AFX_S_MIN = 0, AFX_S_MAX, AFX_S_MEDIAN, AFX_S_MEAN, AFX_S_GMEAN, AFX_S_VARIANCE, AFX_S_CENTROID,
+  AFX_S_SPREAD, AFX_S_SKEWNESS, AFX_S_KURTOSIS, AFX_S_FLATNESS, AFX_S_DMEAN, AFX_S_DVARIANCE
+};
+typedef struct {
+  double* mfcc;              /* [n_bufs][14][13] */
+  double* spectral_rms;      /* [n_bufs][13]     */
+  double* spectral_centroid;
+  double* spectral_spread;
+  double* spectral_skewness;
+  double* spectral_kurtosis;
+  double* spectral_rolloff;
+  double* spectral_flatness;
+  double* spectral_flux;
+  double* spectrum_bands;    /* [n_bufs][28][13] */
+  double* sub_rms;           /* [n_bufs][14][13] */
+  double* sub_flatness;
+  double* sub_flux;
+  double* sub_complexity;
+  double* sub_contrast;
+  double* spectral_contrast; /* [n_bufs][13]     */
+  double* amplitude_peak;
+  double* amplitude_rms;
+  int32_t* stats_status;     /* [n_bufs], optional */
+} afx_stats_out;
+
 /* One-shot: upload n_bufs host buffers, run the HIP path, download the selected descriptors.
  * This is the call TSampleAnalyser::AnalyzeLowLevelDescriptors would make (n_bufs = 1 per file,
  * or many files per call from a batching crawler).  Thread-safe on a shared plan.            */
@@ -155,6 +190,7 @@ int afx_batch_sync(afx_batch* batch);                   /* wait for the batch st
  * device time of the bracket in milliseconds (the stream is idle on return)                   */
 int afx_batch_run_timed(afx_batch* batch, int32_t steps, float* elapsed_ms);
 int afx_batch_fetch(afx_batch* batch, afx_out* out);    /* D2H + unpack, synchronous            */
+int afx_batch_fetch_statistics(afx_batch* batch, afx_stats_out* out); /* needs AFX_D_STATISTICS in the mask */
 void afx_batch_destroy(afx_batch* batch);
 
 /* static facts for roofline accounting (bytes the algorithm must move per frame for `mask`) */

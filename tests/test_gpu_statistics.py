@@ -1,0 +1,83 @@
+"""per-file statistics (TStatistics::Calc, Statistics.cpp:12-90) of every
+framed series, reduced on the GPU.  Checked against the oracle's restatement of Calc applied to the
+GPU's own series (isolates the reduction kernel) and end to end against the oracle."""
+import numpy as np
+import pytest
+
+import afec_amd as afx
+from tests import _oracle
+from tests._oracle import FIELDS, Oracle
+
+pytestmark = pytest.mark.gpu
+
+# order-insensitive sums in double: agreement to rounding; median is an exact element of the series
+RTOL = 1e-9
+ATOL = 1e-12
+
+
+def ref_stats(series):
+    return _oracle.calc_statistics(series, np.zeros(13))
+
+
+def test_statistics_kernel_matches_calc_on_its_own_series():
+    rng = np.random.default_rng(21)
+    lens = [0, 100, 2048, 3072, 2048 + 1024 * 2, 2048 + 1024 * 63, 2048 + 1024 * 64, 2048 + 1024 * 84, 2048 + 1024 * 127,
+            2048 + 1024 * 128, 2048 + 1024 * 300, 2048 + 1024 * 859]
+    bufs = [(0.5 * rng.standard_normal(n) * np.linspace(1.0, 0.1, max(n, 1))[:n]).astype(np.float32) for n in lens]
+    plan = afx.Plan(max_analysis_ms=20000)
+    mask = afx.D_ALL_LOW_LEVEL | afx.D_STATISTICS
+    b = plan.batch(bufs, mask)
+    b.run()
+    series = b.fetch()
+    stats = b.fetch_statistics()
+    assert stats["stats_status"].tolist() == [0] * len(bufs)
+    off = series["frame_offset"]
+    for name, width in afx.capi.OUT_FIELDS:
+        if name == "magnitude":
+            continue
+        vals = series[name].reshape(series[name].shape[0], -1)
+        got = stats[name].reshape(len(bufs), width, 13)
+        for i in range(len(bufs)):
+            for w in range(width):
+                want = ref_stats(vals[off[i]:off[i + 1], w])
+                err = np.abs(got[i, w] - want)
+                lim = RTOL * np.abs(want) + ATOL
+                assert np.all(err <= lim), (name, i, w, got[i, w], want)
+    b.close()
+    plan.close()
+
+
+def test_statistics_end_to_end_against_oracle():
+    rng = np.random.default_rng(22)
+    t = np.arange(2048 + 1024 * 84)
+    x = (0.4 * np.sin(2 * np.pi * 330 * t / 44100) * np.exp(-t / 40000.0) + 0.05 * rng.uniform(-1, 1, t.size)).astype(np.float32)
+    plan = afx.Plan()
+    b = plan.batch([x], afx.D_MFCC | afx.D_SPECTRAL_CENTROID | afx.D_SPECTRAL_RMS | afx.D_SPECTRUM_BANDS | afx.D_STATISTICS)
+    b.run()
+    stats = b.fetch_statistics()
+    ref = Oracle().run(x.astype(np.float64), cap=True)
+    for name in ("mfcc", "spectral_centroid", "spectral_rms", "spectrum_bands"):
+        a, e = FIELDS[name]
+        got = stats[name].reshape(1, e - a, 13)[0]
+        for w in range(e - a):
+            want = ref_stats(ref[:, a + w])
+            # the series themselves agree to 1e-4 relative; moments inherit that, higher central moments
+            # (skewness, kurtosis: divide by the spread of the *positions*) get a looser bound
+            tol = np.array([1e-4] * 8 + [1e-2, 1e-2] + [1e-4] * 3)
+            err = np.abs(got[w] - want)
+            assert np.all(err <= tol * np.abs(want) + 1e-6 * (1 + np.abs(want).max())), (name, w, got[w], want)
+    b.close()
+    plan.close()
+
+
+def test_statistics_over_1024_frames_is_flagged():
+    rng = np.random.default_rng(23)
+    x = rng.uniform(-1, 1, 2048 + 1024 * 1100).astype(np.float32)
+    plan = afx.Plan(max_analysis_ms=0)
+    b = plan.batch([x, x[:5000]], afx.D_SPECTRAL_RMS | afx.D_STATISTICS)
+    b.run()
+    st = b.fetch_statistics()
+    assert st["stats_status"].tolist() == [-2, 0]
+    assert np.all(np.isnan(st["spectral_rms"][0])) and np.all(np.isfinite(st["spectral_rms"][1]))
+    b.close()
+    plan.close()

@@ -151,6 +151,26 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       y[r] = prv[64 * r + lane];
     }
 
+    // ---- spectral_flux: Pearson r with the previous frame over bins 1..738 (SA:1919-1933,
+    //      Statistics.cpp:604-638); frame 0 of a buffer is compared with itself (SA:937-940) ----
+    if (a.flags & kBandsFlux) {
+      double fa = 0.0, fb = 0.0, faa = 0.0, fbb = 0.0, fab = 0.0;
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        const int k = 64 * r + lane;
+        const bool ok = k >= kFirstBin && k <= kLastBin;
+        const double p = ok ? x[r] : 0.0, q = ok ? y[r] : 0.0;
+        fa += p; fb += q; faa += p * p; fbb += q * q; fab += p * q;
+      }
+      fa = wave_sum(fa); fb = wave_sum(fb); faa = wave_sum(faa); fbb = wave_sum(fbb); fab = wave_sum(fab);
+      const double n = (double)kBinCount;
+      const double ma = fa / n, mb = fb / n;
+      const double denom2 = (faa - ma * ma * n) * (fbb - mb * mb * n);
+      const double num = fab - (ma * mb * n);
+      if (lane == 0) a.rec[f * a.lay.stride + a.lay.flux] = (fabs(denom2) > (double)1e-12f) ? num / sqrt(denom2) : 0.0;
+    }
+    if (!(a.flags & kBandsFeatures)) continue;
+
     // ---- masked per-band sums: lane L ends up with band (L >> 2) & 15 ----
     const double sx = band_sum([&](int r) { return x[r]; }, lane);
     const double sxx = band_sum([&](int r) { return x[r] * x[r]; }, lane);

@@ -396,7 +396,8 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
   b->mask = mask;
   b->n_bufs = n_bufs;
   b->lay = make_layout(mask);
-  b->mag_wanted = (mask & (AFX_D_MAGNITUDE | AFX_D_BAND_FEATURES)) != 0;
+  // flux and the sub-band descriptors are computed from the stored magnitudes by the second kernel
+  b->mag_wanted = (mask & (AFX_D_MAGNITUDE | AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) != 0;
   b->frame_offset.assign((size_t)n_bufs + 1, 0);
   b->buf_status.assign((size_t)n_bufs, AFX_OK);
 
@@ -435,20 +436,18 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
 
   // chunking: K consecutive frames per wave; enough chunks to fill the chip, long enough to
   // amortise the 2048-sample lead-in of each chunk
-  const int64_t target_waves = (int64_t)plan->cu_count * 64;
+  const int64_t target_waves = (int64_t)plan->cu_count * 16;
   int K = (int)std::min<int64_t>(32, std::max<int64_t>(4, frames / std::max<int64_t>(1, target_waves)));
-  const bool need_prev = (mask & AFX_D_SPECTRAL_FLUX) != 0;
   std::vector<afx::Chunk> chunks;
   for (int i = 0; i < n_bufs; ++i) {
     const int64_t f = b->frame_offset[i + 1] - b->frame_offset[i];
     for (int64_t f0 = 0; f0 < f; f0 += K) {
       afx::Chunk c;
       const bool first = (f0 == 0);
-      const bool preroll = need_prev && !first;
-      c.sample_off = arena_off[i] + (f0 - (preroll ? 1 : 0)) * plan->desc.hop_size;
+      c.sample_off = arena_off[i] + f0 * plan->desc.hop_size;
       c.frame0 = (int32_t)(b->frame_offset[i] + f0);
       c.nframes = (int16_t)std::min<int64_t>(K, f - f0);
-      c.flags = (int16_t)((first ? afx::kChunkFirstOfBuffer : 0) | (preroll ? afx::kChunkPreroll : 0));
+      c.flags = (int16_t)(first ? afx::kChunkFirstOfBuffer : 0);
       chunks.push_back(c);
     }
   }
@@ -486,7 +485,7 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
   if (frames > 0 && b->mag_wanted) {
     if ((e = hipMalloc((void**)&b->d_mag, (size_t)frames * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(mag)"));
   }
-  if (frames > 0 && (mask & AFX_D_BAND_FEATURES)) {
+  if (frames > 0 && (mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX))) {
     std::vector<int32_t> prev((size_t)frames);
     for (int i = 0; i < n_bufs; ++i)
       for (int64_t f = b->frame_offset[i]; f < b->frame_offset[i + 1]; ++f)
@@ -521,9 +520,10 @@ int afx_batch_run(afx_batch* b) {
   const DeviceTables& t = b->plan->dev;
   a.win = t.win; a.t1 = t.t1; a.t2 = t.t2; a.post = t.post; a.melw = t.melw; a.dct = t.dct;
   HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
-  if (b->mask & AFX_D_BAND_FEATURES) {
+  if (b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) {
     afx::BandArgs ba{};
     ba.mag = b->d_mag; ba.prev = b->d_prev; ba.n_frames = b->total_frames; ba.rec = b->d_rec; ba.lay = b->lay;
+    ba.flags = ((b->mask & AFX_D_BAND_FEATURES) ? afx::kBandsFeatures : 0) | ((b->mask & AFX_D_SPECTRAL_FLUX) ? afx::kBandsFlux : 0);
     HIP_TRY(afx::launch_bands(ba, b->stream));
   }
   if (b->d_stats) {

@@ -66,7 +66,7 @@ struct Chunk {
   int16_t nframes;     // emitted frames
   int16_t flags;
 };
-enum { kChunkFirstOfBuffer = 1, kChunkPreroll = 2 };
+enum { kChunkFirstOfBuffer = 1 };
 
 // per-frame output record: offsets in doubles, -1 = not selected
 struct RecordLayout {
@@ -104,7 +104,9 @@ struct BandArgs {
   int64_t n_frames;
   double* rec;          // same per-frame records the frame kernel writes
   RecordLayout lay;
+  uint32_t flags;       // kBandsFeatures | kBandsFlux
 };
+enum { kBandsFeatures = 1, kBandsFlux = 2 };
 hipError_t launch_bands(const BandArgs& a, hipStream_t stream);
 
 // per-buffer statistics of every record column (TStatistics::Calc, Statistics.cpp:12-90)

@@ -29,7 +29,8 @@
 // What each stage replaces in the reference (SampleAnalyser.cpp = SA):
 //   window+FFT+magnitude  SA:826-845 (xtract_windowed, TFftTransformComplex, TAudioMath::Magnitude)
 //   mel+log+DCT           SA:2052-2063 -> LibXtract vector.c:350-391
-//   rms/centroid/spread/skew/kurt/rolloff/flatness/flux   SA:1808-1933 -> Statistics.cpp, scalar.c
+//   rms/centroid/spread/skew/kurt/rolloff/flatness        SA:1808-1915 -> Statistics.cpp, scalar.c
+//   (flux, SA:1919-1933, needs the previous frame: afx_bands.hip, from the stored magnitudes)
 //   28 bands              SA:2007-2048
 //   amplitude peak/rms    SA:1760-1783
 
@@ -56,7 +57,8 @@ constexpr int kPlaneSlots = 1040;
 // feature classes the kernel is specialised for (the host picks the smallest that covers the mask)
 constexpr int kFeatC2 = 0;     // MFCC only: magnitudes of bins 0..383
 constexpr int kFeatStats = 1;  // + rms/centroid/spread/skew/kurt/rolloff/flatness, amplitude: bins 0..767
-constexpr int kFeatFull = 2;   // + flux, 28 bands, magnitude output: all 1024 bins, previous frame kept
+constexpr int kFeatFull = 2;   // + 28 bands, magnitude output: all 1024 bins (flux and the sub-band
+                               // descriptors are computed from the stored magnitudes by afx_bands.hip)
 
 template <typename T>
 struct cx {
@@ -296,8 +298,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];
     const Pair* src = reinterpret_cast<const Pair*>(pcm + ch.sample_off) + lane;
-    const bool preroll = (ch.flags & kChunkPreroll) != 0;
-    const int total = ch.nframes + (preroll ? 1 : 0);
+    const int total = ch.nframes;
 
     Pair lo[8], nxt[8];
 #pragma unroll
@@ -305,9 +306,6 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) nxt[r] = src[64 * (r + 8)];
 
-    double prev_mag[FEAT == kFeatFull ? 16 : 1];
-#pragma unroll
-    for (int r = 0; r < (FEAT == kFeatFull ? 16 : 1); ++r) prev_mag[r] = 0.0;
     double mel_acc = 0.0;  // mel sums of up to four finished frames: lane 4 f + slot
     int pending = 0;
     int64_t pending_row0 = 0;
@@ -374,8 +372,8 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         mag[r] = mag_sqrt(xr * xr + xi * xi);
       }
 
-      const bool emit = !(preroll && fi == 0);
-      const int64_t row = (int64_t)ch.frame0 + fi - (preroll ? 1 : 0);
+      const bool emit = true;
+      const int64_t row = (int64_t)ch.frame0 + fi;
       double* const rec = a.rec + row * a.lay.stride;
 
       if (emit) {
@@ -409,10 +407,8 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         }
 
         // ---- spectral statistics over bins 1..738, j = bin - 1 (SA:1808-1933) ----
-        if (FEAT != kFeatC2 && (a.mask & 0x1FEu)) {
+        if (FEAT != kFeatC2 && (a.mask & 0xFEu)) {
           double s1 = 0.0, s2 = 0.0, sj = 0.0, prod = 1.0;
-          double fa = 0.0, fb = 0.0, faa = 0.0, fbb = 0.0, fab = 0.0;
-          const bool first = (fi == 0) && !preroll;  // SA:937-940: frame 0 is compared with itself
 #pragma unroll
           for (int r = 0; r < 12; ++r) {
             const int k = 64 * r + lane;
@@ -422,10 +418,6 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
             s2 += m * m;
             sj += (double)(k - kFirstBin) * m;
             prod *= ok ? (m + 1e-20) : 1.0;
-            if (FEAT == kFeatFull) {
-              const double b = first ? m : (ok ? prev_mag[r] : 0.0);
-              fa += m; fb += b; faa += m * m; fbb += b * b; fab += m * b;
-            }
           }
           s1 = wave_sum(s1);
           const double n = (double)kBinCount;
@@ -481,15 +473,6 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
             const double fl = (am == 0.0) ? 0.0 : gm / am;
             const double d = lin_to_db(fl) / -60.0;
             if (lane == 0) rec[a.lay.flatness] = nan_to_zero(d < 1.0 ? d : 1.0);
-          }
-          if (FEAT == kFeatFull && (a.mask & (1u << 8))) {  // flux = Pearson r with the previous frame
-            fa = wave_sum(fa); fb = wave_sum(fb); faa = wave_sum(faa); fbb = wave_sum(fbb);
-            fab = wave_sum(fab);
-            const double ma = fa / n, mb = fb / n;
-            const double denom2 = (faa - ma * ma * n) * (fbb - mb * mb * n);
-            const double num = fab - (ma * mb * n);
-            const double fx = (fabs(denom2) > (double)1e-12f) ? num / sqrt(denom2) : 0.0;
-            if (lane == 0) rec[a.lay.flux] = fx;
           }
           if (a.mask & (1u << 6)) {  // rolloff (scalar.c:472-492): 43 * #elements until 85 %
             // natural-order copy in LDS, then each lane walks 12 consecutive bins
@@ -554,10 +537,6 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
           if (a.mask & (1u << 11)) rec[a.lay.amp_peak] = amp_peak;
           if (a.mask & (1u << 12)) rec[a.lay.amp_rms] = nan_to_zero(sqrt(amp_sq / (double)kHop));
         }
-      }
-      if (FEAT == kFeatFull) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) prev_mag[r] = (double)mag[r];
       }
     }
     if (pending > 0) finish_mfcc(mel_acc, pending, pending_row0, a, dct, lane);

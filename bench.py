@@ -37,6 +37,9 @@ def parse_args():
     ap.add_argument("--buffers", type=int, default=64, help="10k-frame buffers per GPU per step")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--mask", default="c2", choices=["c2", "stats", "all"])
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+                    help="c2: --buffers x 10k-frame buffers (headline); c3: 1000 synthetic 2.0 s files, full "
+                         "low-level set + per-file statistics (BASELINE.json configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=30000, help="frames per CPU worker for the baseline")
     return ap.parse_args()
@@ -52,6 +55,24 @@ def make_buffers(n_buffers, seed):
         x -= 1.0
         bufs.append(x)
     return bufs
+
+
+def make_c3_files(n_files, seed):
+    """2.0 s mono files (88 200 samples -> 85 frames each): 1-3 sines, a decaying noise
+    burst, 50 ms of leading silence; peak-normalised like LoadSample's output."""
+    rng = np.random.Generator(np.random.MT19937(seed))
+    n = 88200
+    t = np.arange(n, dtype=np.float64) / 44100.0
+    files = []
+    for _ in range(n_files):
+        x = np.zeros(n)
+        for _ in range(int(rng.integers(1, 4))):
+            x += rng.uniform(0.2, 0.6) * np.sin(2 * np.pi * rng.uniform(110.0, 4000.0) * t + rng.uniform(0, 6.28))
+        x += rng.uniform(0.2, 0.8) * rng.uniform(-1, 1, n) * np.exp(-t / rng.uniform(0.05, 0.5))
+        x[:2205] = 0.0
+        x /= np.max(np.abs(x))
+        files.append(x.astype(np.float32))
+    return files
 
 
 def dist_setup(n_gpus):
@@ -142,11 +163,16 @@ def main():
     # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)
     device = int(os.environ.get("AFX_BENCH_DEVICE", local))
     plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0)
-    bufs = make_buffers(args.buffers, 1234 + rank)
+    if args.workload == "c3":
+        mask = afx.D_ALL_LOW_LEVEL | afx.D_STATISTICS
+        bufs = make_c3_files(1000, 1234 + rank)
+    else:
+        bufs = make_buffers(args.buffers, 1234 + rank)
+    n_bufs = len(bufs)
     batch = plan.batch(bufs, mask)
     del bufs
     frames = batch.total_frames
-    bytes_per_frame = plan.bytes_per_frame(mask, afx.PCM_F32)
+    bytes_per_frame = plan.bytes_per_frame(mask & ~afx.D_STATISTICS, afx.PCM_F32)
 
     for _ in range(args.warmup):
         batch.run()
@@ -177,10 +203,13 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {
-                "workload": f"C2 x{args.buffers}: 2048/1024 STFT + 14-coef MFCC, {args.buffers} mono float32 "
-                            f"buffers of {FRAMES_PER_BUFFER} frames per GPU, U(-1,1) MT19937"
-                            if args.mask == "c2" else f"{args.mask} descriptor set, {args.buffers} x {FRAMES_PER_BUFFER} frames",
+                "workload": (f"C3: full low-level descriptor set + per-file statistics, {n_bufs} synthetic 2.0 s "
+                             f"mono float32 files per GPU") if args.workload == "c3" else
+                            (f"C2 x{args.buffers}: 2048/1024 STFT + 14-coef MFCC, {args.buffers} mono float32 "
+                             f"buffers of {FRAMES_PER_BUFFER} frames per GPU, U(-1,1) MT19937"
+                             if args.mask == "c2" else f"{args.mask} descriptor set, {args.buffers} x {FRAMES_PER_BUFFER} frames"),
                 "frames_per_gpu_per_step": frames,
+                "files_per_gpu_per_step": n_bufs,
                 "pcm": "f32 resident in HBM",
                 "parallelism": f"replicas x{world} (buffers sharded, no collective)",
             },
@@ -190,7 +219,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.precision, args.mask, frames),
+                "traffic": measured_traffic(args.precision, args.mask if args.workload == "c2" else "c3", frames),
                 "kernel": "frames_kernel",
                 "algorithmic_bytes_per_frame": bytes_per_frame,
                 "launch_ms": launch_ms,

@@ -43,8 +43,9 @@ EXPORTS = [
     "afx_plan_get_window", "afx_plan_get_mel_table", "afx_plan_get_bin_range", "afx_num_frames",
     "afx_extract_batch", "afx_batch_create", "afx_batch_total_frames", "afx_batch_run",
     "afx_batch_sync", "afx_batch_run_timed", "afx_batch_fetch", "afx_batch_fetch_statistics", "afx_batch_destroy",
-    "afx_algorithmic_bytes_per_frame",
+    "afx_algorithmic_bytes_per_frame", "afx_batch_create_from_raw", "afx_batch_fetch_samples",
 ]
+RAW_I16, RAW_I24, RAW_F32 = 0, 1, 2
 
 # afx_out fields: name -> width per frame, in declaration order
 OUT_FIELDS = [
@@ -86,6 +87,17 @@ class _Buf(ctypes.Structure):
 class _Out(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n, _ in OUT_FIELDS] + [
         ("frame_offset", ctypes.c_void_p), ("buf_status", ctypes.c_void_p)]
+
+
+class _Raw(ctypes.Structure):
+    _fields_ = [("data", ctypes.c_void_p), ("format", ctypes.c_int32), ("channels", ctypes.c_int32),
+                ("sample_rate", ctypes.c_int32), ("reserved", ctypes.c_int32), ("n_frames", ctypes.c_int64)]
+
+
+class _LoadInfo(ctypes.Structure):
+    _fields_ = [("peak_value", ctypes.c_float), ("rms_value", ctypes.c_float), ("data_offset", ctypes.c_int32),
+                ("silent_leading", ctypes.c_int32), ("silent_trailing", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("n_samples", ctypes.c_int64)]
 
 
 class _StatsOut(ctypes.Structure):
@@ -145,6 +157,8 @@ def load_library():
     L.afx_batch_fetch_statistics.argtypes = [vp, ctypes.POINTER(_StatsOut)]
     L.afx_batch_destroy.argtypes = [vp]
     L.afx_batch_destroy.restype = None
+    L.afx_batch_create_from_raw.argtypes = [vp, ctypes.POINTER(_Raw), i32, u32, ctypes.POINTER(vp), ctypes.POINTER(_LoadInfo)]
+    L.afx_batch_fetch_samples.argtypes = [vp, i32, vp, i64]
     L.afx_algorithmic_bytes_per_frame.restype = i64
     L.afx_algorithmic_bytes_per_frame.argtypes = [vp, u32, i32]
     _lib = L
@@ -249,6 +263,37 @@ class Plan:
     def batch(self, bufs, mask=D_ALL_LOW_LEVEL):
         return Batch(self, bufs, mask)
 
+    def batch_from_raw(self, raws, mask=D_ALL_LOW_LEVEL):
+        """raws: list of (array, channels[, sample_rate]); array dtype int16 / float32 (interleaved,
+        shape [frames*channels] or [frames, channels]) or uint8 of packed 24-bit little-endian samples.
+        Returns (Batch, list of load-info dicts): the LoadSample front end on the GPU."""
+        n = len(raws)
+        arr = (_Raw * max(1, n))()
+        keep = []
+        for i, item in enumerate(raws):
+            data, channels = item[0], int(item[1])
+            rate = int(item[2]) if len(item) > 2 else 0
+            data = np.ascontiguousarray(np.asarray(data).reshape(-1))
+            if data.dtype == np.int16:
+                fmt, frames = RAW_I16, data.size // max(channels, 1)
+            elif data.dtype == np.float32:
+                fmt, frames = RAW_F32, data.size // max(channels, 1)
+            elif data.dtype == np.uint8:
+                fmt, frames = RAW_I24, data.size // (3 * max(channels, 1))
+            else:
+                raise TypeError("raw PCM must be int16, float32 or uint8 (packed int24)")
+            keep.append(data)
+            arr[i].data = data.ctypes.data if data.size else None
+            arr[i].format, arr[i].channels, arr[i].sample_rate, arr[i].n_frames = fmt, channels, rate, frames
+        info = (_LoadInfo * max(1, n))()
+        h = ctypes.c_void_p()
+        _check(self.L, self.L.afx_batch_create_from_raw(self.h, arr, n, mask, ctypes.byref(h), info))
+        b = Batch.__new__(Batch)
+        b.plan, b.L, b.mask, b.n_bufs, b.h = self, self.L, mask, n, h
+        b.total_frames = int(self.L.afx_batch_total_frames(h))
+        infos = [{k: getattr(info[i], k) for k, _ in _LoadInfo._fields_ if k != "reserved"} for i in range(n)]
+        return b, infos
+
 
 class Batch:
     """afx_batch: PCM resident in HBM, re-runnable."""
@@ -278,6 +323,11 @@ class Batch:
         out, res = _alloc_out(self.mask, self.total_frames, self.n_bufs)
         _check(self.L, self.L.afx_batch_fetch(self.h, ctypes.byref(out)))
         return res
+
+    def fetch_samples(self, buf, n):
+        a = np.zeros(n, dtype=np.float64)
+        _check(self.L, self.L.afx_batch_fetch_samples(self.h, buf, a.ctypes.data, n))
+        return a
 
     def fetch_statistics(self):
         """dict name -> [n_bufs, W, 13] (W squeezed for scalar series) + "stats_status"."""

@@ -153,6 +153,7 @@ struct afx_batch {
   int32_t* d_prev = nullptr;
   int64_t* d_frame_offset = nullptr;
   double* d_stats = nullptr;
+  std::vector<int64_t> arena_off, used;  // per buffer: start and length (samples) of its analysed prefix in d_pcm
   bool mag_wanted = false;
 };
 
@@ -378,17 +379,18 @@ int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int
   return in + out;
 }
 
-int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask,
-                     afx_batch** out_batch) {
-  if (!plan || !out_batch || n_bufs < 0 || (n_bufs > 0 && !bufs))
-    return fail(AFX_ERR_INVALID_ARG, "null argument");
-  *out_batch = nullptr;
-  if ((mask & ~(uint32_t)AFX_D_STATISTICS) == 0 ||
-      (mask & ~(uint32_t)(AFX_D_ALL_LOW_LEVEL | AFX_D_MAGNITUDE | AFX_D_STATISTICS)))
-    return fail(AFX_ERR_INVALID_ARG, "bad descriptor mask");
+}  // extern "C"
+
+namespace {
+
+// Common tail of batch creation: lengths[i] = samples of buffer i as AnalyzeLowLevelDescriptors would
+// see them; fill() puts the analysed prefix of every buffer at arena_off[i] of b->d_pcm (element
+// size esz) using b->stream.
+template <typename Fill>
+int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const std::vector<int64_t>& lengths,
+                const std::vector<int32_t>& status, Fill fill, afx_batch** out_batch) {
   const bool want_stats = (mask & AFX_D_STATISTICS) != 0;
   mask &= ~(uint32_t)AFX_D_STATISTICS;   // the kernels see the descriptor bits only
-  HIP_TRY(hipSetDevice(plan->desc.device));
 
   afx_batch* b = new (std::nothrow) afx_batch();
   if (!b) return fail(AFX_ERR_OUT_OF_MEMORY, "host allocation failed");
@@ -399,34 +401,23 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
   // flux and the sub-band descriptors are computed from the stored magnitudes by the second kernel
   b->mag_wanted = (mask & (AFX_D_MAGNITUDE | AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) != 0;
   b->frame_offset.assign((size_t)n_bufs + 1, 0);
-  b->buf_status.assign((size_t)n_bufs, AFX_OK);
-
-  // one PCM dtype per batch (the arena is homogeneous); first valid buffer decides
-  int dtype = -1;
-  for (int i = 0; i < n_bufs; ++i) {
-    const afx_buf& s = bufs[i];
-    const bool good = s.n_samples >= 0 && (s.n_samples == 0 || s.pcm) &&
-                      (s.dtype == AFX_PCM_F32 || s.dtype == AFX_PCM_F64);
-    if (!good) { b->buf_status[i] = AFX_ERR_BAD_BUFFER; continue; }
-    if (dtype < 0) dtype = s.dtype;
-    if (s.dtype != dtype) b->buf_status[i] = AFX_ERR_BAD_BUFFER;
-  }
-  if (dtype < 0) dtype = AFX_PCM_F32;
+  b->buf_status = status;
   b->pcm_dtype = dtype;
   const size_t esz = (dtype == AFX_PCM_F64) ? 8 : 4;
 
   // arena offsets: every buffer starts on a 16-byte boundary and only the analysed prefix
-  // (SampleAnalyser.cpp:760-764) of buffers that yield at least one frame is uploaded
-  std::vector<int64_t> arena_off((size_t)n_bufs, 0), used((size_t)n_bufs, 0);
+  // (SampleAnalyser.cpp:760-764) of buffers that yield at least one frame is kept
+  b->arena_off.assign((size_t)n_bufs, 0);
+  b->used.assign((size_t)n_bufs, 0);
   int64_t arena = 0, frames = 0;
   for (int i = 0; i < n_bufs; ++i) {
     b->frame_offset[i] = frames;
     if (b->buf_status[i] != AFX_OK) continue;
-    const int64_t f = num_frames(plan, bufs[i].n_samples);
+    const int64_t f = num_frames(plan, lengths[i]);
     if (f > 0) {
-      used[i] = (f - 1) * plan->desc.hop_size + plan->desc.fft_size;
-      arena_off[i] = arena;
-      arena += (used[i] + 3) & ~(int64_t)3;
+      b->used[i] = (f - 1) * plan->desc.hop_size + plan->desc.fft_size;
+      b->arena_off[i] = arena;
+      arena += (b->used[i] + 3) & ~(int64_t)3;
       frames += f;
     }
   }
@@ -444,7 +435,7 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
     for (int64_t f0 = 0; f0 < f; f0 += K) {
       afx::Chunk c;
       const bool first = (f0 == 0);
-      c.sample_off = arena_off[i] + f0 * plan->desc.hop_size;
+      c.sample_off = b->arena_off[i] + f0 * plan->desc.hop_size;
       c.frame0 = (int32_t)(b->frame_offset[i] + f0);
       c.nframes = (int16_t)std::min<int64_t>(K, f - f0);
       c.flags = (int16_t)(first ? afx::kChunkFirstOfBuffer : 0);
@@ -465,15 +456,10 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
   if ((e = hipEventCreate(&b->ev0)) != hipSuccess) return cleanup(hip_fail(e, "hipEventCreate"));
   if ((e = hipEventCreate(&b->ev1)) != hipSuccess) return cleanup(hip_fail(e, "hipEventCreate"));
   if (arena > 0) {
-    // +16 KiB tail so the unconditional next-hop prefetch of the last frame stays inside the arena
     if ((e = hipMalloc(&b->d_pcm, (size_t)arena * esz + 16384)) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(pcm)"));
     if ((e = hipMemsetAsync(b->d_pcm, 0, (size_t)arena * esz + 16384, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemset"));
-    for (int i = 0; i < n_bufs; ++i)
-      if (used[i] > 0) {
-        e = hipMemcpyAsync((char*)b->d_pcm + (size_t)arena_off[i] * esz, bufs[i].pcm, (size_t)used[i] * esz,
-                           hipMemcpyHostToDevice, b->stream);
-        if (e != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(pcm)"));
-      }
+    const int st = fill(b);
+    if (st != AFX_OK) return cleanup(st);
   }
   if (b->n_chunks > 0) {
     if ((e = hipMalloc((void**)&b->d_chunks, chunks.size() * sizeof(afx::Chunk))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(chunks)"));
@@ -500,6 +486,150 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
   }
   if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
   *out_batch = b;
+  return AFX_OK;
+}
+
+bool mask_ok(uint32_t mask) {
+  return (mask & ~(uint32_t)AFX_D_STATISTICS) != 0 &&
+         !(mask & ~(uint32_t)(AFX_D_ALL_LOW_LEVEL | AFX_D_MAGNITUDE | AFX_D_STATISTICS));
+}
+
+}  // namespace
+
+extern "C" {
+
+int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask,
+                     afx_batch** out_batch) {
+  if (!plan || !out_batch || n_bufs < 0 || (n_bufs > 0 && !bufs))
+    return fail(AFX_ERR_INVALID_ARG, "null argument");
+  *out_batch = nullptr;
+  if (!mask_ok(mask)) return fail(AFX_ERR_INVALID_ARG, "bad descriptor mask");
+  HIP_TRY(hipSetDevice(plan->desc.device));
+
+  // one PCM dtype per batch (the arena is homogeneous); first valid buffer decides
+  std::vector<int32_t> status((size_t)n_bufs, AFX_OK);
+  std::vector<int64_t> lengths((size_t)n_bufs, 0);
+  int dtype = -1;
+  for (int i = 0; i < n_bufs; ++i) {
+    const afx_buf& s = bufs[i];
+    const bool good = s.n_samples >= 0 && (s.n_samples == 0 || s.pcm) &&
+                      (s.dtype == AFX_PCM_F32 || s.dtype == AFX_PCM_F64);
+    if (!good) { status[i] = AFX_ERR_BAD_BUFFER; continue; }
+    if (dtype < 0) dtype = s.dtype;
+    if (s.dtype != dtype) status[i] = AFX_ERR_BAD_BUFFER;
+    lengths[i] = s.n_samples;
+  }
+  if (dtype < 0) dtype = AFX_PCM_F32;
+  const size_t esz = (dtype == AFX_PCM_F64) ? 8 : 4;
+  auto fill = [&](afx_batch* b) -> int {
+    for (int i = 0; i < n_bufs; ++i)
+      if (b->used[i] > 0) {
+        hipError_t e = hipMemcpyAsync((char*)b->d_pcm + (size_t)b->arena_off[i] * esz, bufs[i].pcm,
+                                      (size_t)b->used[i] * esz, hipMemcpyHostToDevice, b->stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpy(pcm)");
+      }
+    return AFX_OK;
+  };
+  return build_batch(plan, n_bufs, mask, dtype, lengths, status, fill, out_batch);
+}
+
+// LoadSample front end (SampleAnalyser.cpp:484-718) on the GPU: decoded interleaved PCM in,
+// peak-normalised, silence-trimmed, padded mono doubles in the analysis arena out.
+int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_bufs, uint32_t mask,
+                              afx_batch** out_batch, afx_load_info* info) {
+  if (!plan || !out_batch || n_bufs < 0 || (n_bufs > 0 && !raws))
+    return fail(AFX_ERR_INVALID_ARG, "null argument");
+  *out_batch = nullptr;
+  if (!mask_ok(mask)) return fail(AFX_ERR_INVALID_ARG, "bad descriptor mask");
+  HIP_TRY(hipSetDevice(plan->desc.device));
+
+  std::vector<int32_t> status((size_t)n_bufs, AFX_OK);
+  std::vector<afx::LoadFile> files((size_t)n_bufs);
+  int64_t raw_bytes = 0;
+  for (int i = 0; i < n_bufs; ++i) {
+    const afx_raw& r = raws[i];
+    const int bps = r.format == AFX_RAW_I16 ? 2 : (r.format == AFX_RAW_I24 ? 3 : (r.format == AFX_RAW_F32 ? 4 : 0));
+    // SampleAnalyser.cpp:472-482: 1..8 channels, non-empty; resampling (sample_rate != plan rate,
+    // SampleAnalyser.cpp:563-607) is not part of this front end
+    const bool good = bps && r.data && r.n_frames > 0 && r.n_frames < 0x7FFFFFFF && r.channels >= 1 && r.channels <= 8 &&
+                      (r.sample_rate == 0 || r.sample_rate == plan->desc.sample_rate);
+    files[i] = afx::LoadFile{0, 0, 0, 0};
+    if (!good) { status[i] = (bps && r.data && r.n_frames > 0 && r.channels >= 1 && r.channels <= 8) ? AFX_ERR_UNSUPPORTED : AFX_ERR_BAD_BUFFER; continue; }
+    files[i] = afx::LoadFile{raw_bytes, r.n_frames, r.channels, r.format};
+    raw_bytes += ((int64_t)r.n_frames * r.channels * bps + 15) & ~(int64_t)15;
+  }
+  hipStream_t s = nullptr;
+  unsigned char* d_raw = nullptr;
+  afx::LoadFile* d_files = nullptr;
+  afx::LoadScan* d_scan = nullptr;
+  auto free_tmp = [&]() { hipFree(d_raw); hipFree(d_files); hipFree(d_scan); if (s) hipStreamDestroy(s); };
+  auto bail = [&](int st) { free_tmp(); return st; };
+  hipError_t e;
+  std::vector<afx::LoadScan> scan((size_t)n_bufs);
+  if (n_bufs > 0) {
+    if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return bail(hip_fail(e, "hipStreamCreate"));
+    if ((e = hipMalloc((void**)&d_raw, (size_t)raw_bytes + 16)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(raw)"));
+    if ((e = hipMalloc((void**)&d_files, files.size() * sizeof(afx::LoadFile))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(files)"));
+    if ((e = hipMalloc((void**)&d_scan, scan.size() * sizeof(afx::LoadScan))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(scan)"));
+    for (int i = 0; i < n_bufs; ++i)
+      if (status[i] == AFX_OK) {
+        const int bps = raws[i].format == AFX_RAW_I16 ? 2 : (raws[i].format == AFX_RAW_I24 ? 3 : 4);
+        if ((e = hipMemcpyAsync(d_raw + files[i].raw_off, raws[i].data, (size_t)raws[i].n_frames * raws[i].channels * bps,
+                                hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
+      }
+    if ((e = hipMemcpyAsync(d_files, files.data(), files.size() * sizeof(afx::LoadFile), hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(files)"));
+    // -48 dB of full scale (MSilenceThresholdDb, SampleAnalyser.cpp:51, 648-649)
+    const double silence_floor = 32768.0 * std::exp(-48.0 * (std::log(10.0) / 20.0));
+    if ((e = afx::launch_load_scan(d_raw, d_files, n_bufs, silence_floor, d_scan, s)) != hipSuccess) return bail(hip_fail(e, "load_scan"));
+    if ((e = hipMemcpyAsync(scan.data(), d_scan, scan.size() * sizeof(afx::LoadScan), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(scan)"));
+    if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(hip_fail(e, "hipStreamSynchronize"));
+  }
+  // padding rules of SampleAnalyser.cpp:681-701
+  const int fft = plan->desc.fft_size;
+  std::vector<int64_t> lengths((size_t)n_bufs, 0);
+  std::vector<afx::LoadPlace> place((size_t)n_bufs);
+  for (int i = 0; i < n_bufs; ++i) {
+    place[i] = afx::LoadPlace{};
+    if (status[i] != AFX_OK) { if (info) info[i] = afx_load_info{}; continue; }
+    const int64_t n = files[i].n_frames, lead = scan[i].lead, trail = scan[i].trail;
+    const int64_t audible = n - lead - trail;
+    const int64_t end_pad = ((audible % fft) < fft / 2) ? fft / 2 : 0;
+    const int64_t start_pad = (audible + end_pad < fft) ? fft - audible - end_pad : 0;
+    lengths[i] = audible + start_pad + end_pad;
+    place[i].lead = lead; place[i].audible = audible; place[i].start_pad = start_pad;
+    place[i].scaling = scan[i].amplification / 32768.0;      // FinalScaling, SampleAnalyser.cpp:712
+    if (info) {
+      info[i].peak_value = (float)std::min(1.0, (double)scan[i].max_amp / 32768.0);
+      info[i].rms_value = (float)std::min(1.0, std::sqrt(scan[i].sum_sq / (double)n));
+      info[i].data_offset = (int32_t)(-lead + start_pad);
+      info[i].silent_leading = (int32_t)lead;
+      info[i].silent_trailing = (int32_t)trail;
+      info[i].reserved = 0;
+      info[i].n_samples = lengths[i];
+    }
+  }
+  auto fill = [&](afx_batch* b) -> int {
+    afx::LoadPlace* d_place = nullptr;
+    hipError_t e2;
+    for (int i = 0; i < n_bufs; ++i) place[i].out_off = b->arena_off[i], place[i].out_n = b->used[i];
+    if ((e2 = hipMalloc((void**)&d_place, place.size() * sizeof(afx::LoadPlace))) != hipSuccess) return hip_fail(e2, "hipMalloc(place)");
+    e2 = hipMemcpyAsync(d_place, place.data(), place.size() * sizeof(afx::LoadPlace), hipMemcpyHostToDevice, b->stream);
+    if (e2 == hipSuccess) e2 = afx::launch_load_write(d_raw, d_files, d_place, n_bufs, (double*)b->d_pcm, b->stream);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(b->stream);
+    hipFree(d_place);
+    return e2 == hipSuccess ? AFX_OK : hip_fail(e2, "load_write");
+  };
+  const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, fill, out_batch);
+  free_tmp();
+  return st;
+}
+
+int afx_batch_fetch_samples(afx_batch* b, int32_t buf, double* dst, int64_t n) {
+  if (!b || !dst || buf < 0 || buf >= b->n_bufs || n < 0) return fail(AFX_ERR_INVALID_ARG, "bad argument");
+  if (b->pcm_dtype != AFX_PCM_F64) return fail(AFX_ERR_INVALID_ARG, "batch does not hold double PCM");
+  const int64_t m = std::min<int64_t>(n, b->used[buf]);
+  HIP_TRY(hipSetDevice(b->plan->desc.device));
+  if (m > 0) HIP_TRY(hipMemcpy(dst, (const double*)b->d_pcm + b->arena_off[buf], (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
   return AFX_OK;
 }
 

@@ -119,4 +119,31 @@ struct StatsArgs {
 };
 hipError_t launch_stats(const StatsArgs& a, hipStream_t stream);
 
+// ---- LoadSample front end (SampleAnalyser.cpp:484-718) ----
+struct LoadFile {
+  int64_t raw_off;   // byte offset of the interleaved PCM in the raw arena
+  int64_t n_frames;  // sample frames
+  int32_t channels;
+  int32_t format;    // AFX_RAW_*
+};
+struct LoadScan {    // per file, produced by the scan kernel
+  double sum_sq;         // sum (x / 32768)^2 of the mono mix
+  double amplification;  // 32768 / max|x|  (1 when silent)
+  float max_amp;         // max |x| of the mono mix in "16-bit float" units
+  int32_t lead, trail;   // silent leading / trailing samples at -48 dB after normalisation
+  int32_t pad;
+};
+struct LoadPlace {   // per file, where the normalised samples go
+  int64_t out_off;   // first sample of the buffer in the analysis arena
+  int64_t out_n;     // samples of the analysed prefix kept in the arena
+  int64_t lead;      // first audible source sample
+  int64_t audible;   // audible samples
+  int64_t start_pad; // zeros in front (StartFrameOffset)
+  double scaling;    // FinalScaling
+};
+hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int n_files, double silence_floor,
+                            LoadScan* scan, hipStream_t stream);
+hipError_t launch_load_write(const unsigned char* raw, const LoadFile* files, const LoadPlace* place, int n_files,
+                             double* arena, hipStream_t stream);
+
 }  // namespace afx

@@ -1,0 +1,131 @@
+// afec_amd/csrc/afx_load.hip -- LoadSample front end on the GPU.
+//
+// TSampleAnalyser::LoadSample (SampleAnalyser.cpp:484-718) after the container decode: conversion to
+// the "16-bit float" range, mono mix-down, rms / peak, peak normalisation factor, -48 dB silence trim
+// and zero padding.  Byte / integer work and two reductions per file: HBM-bound by construction
+// (2..4 bytes in, 8 bytes out per sample), one workgroup per file.
+//
+//   load_scan   pass 1: max |x| and sum (x/32768)^2 of the mono mix; pass 2 (same workgroup): first and
+//               last sample whose normalised magnitude exceeds the silence floor
+//   load_write  writes scaling * x[lead + n] as doubles behind start_pad zeros (the arena is pre-zeroed)
+
+#include <hip/hip_runtime.h>
+
+#include "afx_internal.h"
+
+namespace afx {
+namespace {
+
+// the reference's decoders hand LoadSample "16-bit floats" (CoreFileFormats/Export/SampleConverter.h)
+__device__ __forceinline__ float to_16bit_float(const unsigned char* raw, int format, int64_t idx) {
+  if (format == 0) return (float)reinterpret_cast<const short*>(raw)[idx];            // :446-449
+  if (format == 1) {                                                                  // :474-486
+    const unsigned char* b = raw + 3 * idx;
+    const int v = (int)(((unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)b[2] << 16)) << 8);
+    return (float)((double)v * 32768.0 / 2147483648.0);
+  }
+  const double d = (double)reinterpret_cast<const float*>(raw)[idx] * 32768.0;        // :529-533
+  return (float)(d < -32768.0 ? -32768.0 : (d > 32767.0 ? 32767.0 : d));
+}
+
+// mono mix in float with the first channel as destination (SampleAnalyser.cpp:535-548)
+__device__ __forceinline__ float mono_sample(const unsigned char* raw, int format, int channels, int64_t n) {
+  float d = to_16bit_float(raw, format, n * channels);
+  if (channels > 1) {
+    for (int c = 1; c < channels; ++c) d = __fadd_rn(d, to_16bit_float(raw, format, n * channels + c));
+    d = __fmul_rn(d, 1.0f / (float)channels);
+  }
+  return d;
+}
+
+constexpr int kLoadThreads = 256;
+
+template <typename T, typename Op>
+__device__ __forceinline__ T block_reduce(T v, T* scratch, Op op) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = op(v, __shfl_xor(v, o));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+  __syncthreads();
+  T r = scratch[0];
+  for (int w = 1; w < kLoadThreads / 64; ++w) r = op(r, scratch[w]);
+  return r;
+}
+
+__global__ __launch_bounds__(kLoadThreads) void load_scan_kernel(const unsigned char* raw, const LoadFile* files,
+                                                                 double silence_floor, LoadScan* scan) {
+  __shared__ double sd[kLoadThreads / 64];
+  __shared__ float sf[kLoadThreads / 64];
+  __shared__ long long sl[kLoadThreads / 64];
+  const LoadFile f = files[blockIdx.x];
+  if (f.n_frames <= 0) {
+    if (threadIdx.x == 0) scan[blockIdx.x] = LoadScan{0.0, 1.0, 0.0f, 0, 0, 0};
+    return;
+  }
+  const unsigned char* src = raw + f.raw_off;
+  // pass 1: rms and peak (SampleAnalyser.cpp:612-637)
+  double sum_sq = 0.0;
+  float mx = 0.0f;
+  for (int64_t n = threadIdx.x; n < f.n_frames; n += kLoadThreads) {
+    const float x = mono_sample(src, f.format, f.channels, n);
+    const double t = (double)(x / 32768.0f);
+    sum_sq += t * t;
+    mx = fmaxf(mx, fabsf(x));
+  }
+  sum_sq = block_reduce(sum_sq, sd, [](double a, double b) { return a + b; });
+  mx = block_reduce(mx, sf, [](float a, float b) { return fmaxf(a, b); });
+  const double max_amp = (double)mx;
+  const double amplification = (max_amp > (double)1e-12f) ? 32768.0 / max_amp : 1.0;
+  // pass 2: silent leading / trailing samples (SampleAnalyser.cpp:651-669)
+  long long first = f.n_frames, last = -1;
+  for (int64_t n = threadIdx.x; n < f.n_frames; n += kLoadThreads) {
+    const float x = mono_sample(src, f.format, f.channels, n);
+    if (fabs(amplification * (double)x) > silence_floor) {
+      first = n < first ? n : first;
+      last = n > last ? n : last;
+    }
+  }
+  first = block_reduce(first, sl, [](long long a, long long b) { return a < b ? a : b; });
+  last = block_reduce(last, sl, [](long long a, long long b) { return a > b ? a : b; });
+  if (threadIdx.x == 0) {
+    LoadScan r;
+    r.sum_sq = sum_sq;
+    r.amplification = amplification;
+    r.max_amp = mx;
+    r.lead = (int32_t)first;                                      // == n_frames when everything is silent
+    r.trail = (last < 0) ? 0 : (int32_t)(f.n_frames - 1 - last);  // the trailing scan stops above `lead`
+    r.pad = 0;
+    scan[blockIdx.x] = r;
+  }
+}
+
+__global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned char* raw, const LoadFile* files,
+                                                                  const LoadPlace* place, double* arena) {
+  const LoadFile f = files[blockIdx.x];
+  const LoadPlace p = place[blockIdx.x];
+  if (f.n_frames <= 0 || p.out_n <= 0) return;
+  const unsigned char* src = raw + f.raw_off;
+  double* dst = arena + p.out_off;
+  // only the analysed prefix is kept; zeros of the start / end pads are already there
+  const int64_t n_copy = (p.audible < p.out_n - p.start_pad) ? p.audible : (p.out_n - p.start_pad);
+  for (int64_t n = (int64_t)blockIdx.y * kLoadThreads + threadIdx.x; n < n_copy; n += (int64_t)gridDim.y * kLoadThreads)
+    dst[p.start_pad + n] = (double)mono_sample(src, f.format, f.channels, p.lead + n) * p.scaling;  // SA:712-718
+}
+
+}  // namespace
+
+hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int n_files, double silence_floor,
+                            LoadScan* scan, hipStream_t stream) {
+  if (n_files <= 0) return hipSuccess;
+  hipLaunchKernelGGL(load_scan_kernel, dim3(n_files), dim3(kLoadThreads), 0, stream, raw, files, silence_floor, scan);
+  return hipGetLastError();
+}
+
+hipError_t launch_load_write(const unsigned char* raw, const LoadFile* files, const LoadPlace* place, int n_files,
+                             double* arena, hipStream_t stream) {
+  if (n_files <= 0) return hipSuccess;
+  hipLaunchKernelGGL(load_write_kernel, dim3(n_files, 8), dim3(kLoadThreads), 0, stream, raw, files, place, arena);
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -193,6 +193,39 @@ int afx_batch_fetch(afx_batch* batch, afx_out* out);    /* D2H + unpack, synchro
 int afx_batch_fetch_statistics(afx_batch* batch, afx_stats_out* out); /* needs AFX_D_STATISTICS in the mask */
 void afx_batch_destroy(afx_batch* batch);
 
+/* ---- LoadSample front end: TSampleAnalyser::LoadSample, SampleAnalyser.cpp:484-718 ---- *
+ * Decoded, interleaved PCM of a file in; on the GPU: conversion to the reference's "16-bit float"
+ * range, mono mix-down, peak / rms, peak normalisation, -48 dB leading / trailing silence trim, and the
+ * half-frame / one-frame zero padding.  The result is the double buffer TSampleData::mData holds and
+ * stays in HBM as the batch's PCM arena.  Decoding the container and resampling files that are not at
+ * the plan's rate stay with the caller (buffers with another sample_rate get AFX_ERR_UNSUPPORTED). */
+enum {
+  AFX_RAW_I16 = 0, /* int16                      (S16BitSignedTo16BitFloat, SampleConverter.h:446-449) */
+  AFX_RAW_I24 = 1, /* packed little-endian int24 (S24BitTo16BitFloat, SampleConverter.h:474-486)       */
+  AFX_RAW_F32 = 2  /* float in [-1, 1]           (S0To1FloatTo16BitFloat, SampleConverter.h:529-533)   */
+};
+typedef struct {
+  const void* data;    /* host pointer, interleaved by channel */
+  int32_t format;      /* AFX_RAW_* */
+  int32_t channels;    /* 1..8 (SampleAnalyser.cpp:472-477) */
+  int32_t sample_rate; /* 0 = the plan's rate */
+  int32_t reserved;
+  int64_t n_frames;    /* sample frames per channel */
+} afx_raw;
+typedef struct {
+  float peak_value;        /* TSampleData::mPeakValue  */
+  float rms_value;         /* TSampleData::mRmsValue   */
+  int32_t data_offset;     /* TSampleData::mDataOffset */
+  int32_t silent_leading;
+  int32_t silent_trailing;
+  int32_t reserved;
+  int64_t n_samples;       /* TSampleData::mData.Size() */
+} afx_load_info;
+int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_bufs, uint32_t mask,
+                              afx_batch** out_batch, afx_load_info* info /* [n_bufs], optional */);
+/* the normalised samples of buffer `buf` (its analysed prefix) for the CPU-resident neighbours */
+int afx_batch_fetch_samples(afx_batch* batch, int32_t buf, double* dst, int64_t n);
+
 /* static facts for roofline accounting (bytes the algorithm must move per frame for `mask`) */
 int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int32_t pcm_dtype);
 

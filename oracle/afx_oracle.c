@@ -494,3 +494,70 @@ int64_t afx_oracle_run_mfcc(const afx_oracle* o, const double* x, int64_t n_samp
   free(re);
   return frames;
 }
+
+/* ---- LoadSample (SA:484-718), decoded interleaved PCM in, normalised mono double out ---- */
+
+static float to_16bit_float(const void* pcm, int format, int64_t idx) {
+  if (format == 0) return (float)((const int16_t*)pcm)[idx];           /* SampleConverter.h:446-449 */
+  if (format == 1) {                                                    /* SampleConverter.h:474-486 */
+    const unsigned char* b = (const unsigned char*)pcm + 3 * idx;
+    const int32_t v = (int32_t)(((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16)) << 8);
+    return (float)(v * 32768.0 / 2147483648.0);
+  }
+  {                                                                     /* SampleConverter.h:529-533 */
+    const double d = (double)((const float*)pcm)[idx] * 32768.0;
+    return (float)(d < -32768.0 ? -32768.0 : (d > 32767.0 ? 32767.0 : d));
+  }
+}
+
+double* afx_oracle_load_sample(const void* pcm, int format, int channels, int64_t n_frames, int fft_size,
+                               afx_oracle_load_info* info) {
+  const float scale = 65536 / 2.0f;   /* sScaleFactor = M16BitSampleRange / 2.0f, SA:533 */
+  float* mono = (float*)malloc(sizeof(float) * (size_t)(n_frames > 0 ? n_frames : 1));
+  int64_t n, lead, trail, audible, start_pad, end_pad, size;
+  double rms = 0.0, max_amp, amplification, floor_lin, final_scaling;
+  float mn, mx;
+  double* out;
+  /* mix down to mono in float, first channel as destination (SA:535-556) */
+  for (n = 0; n < n_frames; ++n) {
+    float d = to_16bit_float(pcm, format, n * channels);
+    if (channels > 1) {
+      const float mix = 1.0f / (float)channels;
+      int c;
+      for (c = 1; c < channels; ++c) d += to_16bit_float(pcm, format, n * channels + c);
+      d *= mix;
+    }
+    mono[n] = d;
+  }
+  /* rms (SA:612-619) */
+  for (n = 0; n < n_frames; ++n) { const double t = (double)(mono[n] / scale); rms += t * t; }
+  info->rms_value = (float)fmin(1.0, sqrt(rms / (double)(1 * n_frames)));
+  /* peak and normalisation factor (SA:624-637) */
+  mn = mx = mono[0];
+  for (n = 1; n < n_frames; ++n) { if (mono[n] < mn) mn = mono[n]; if (mono[n] > mx) mx = mono[n]; }
+  max_amp = (double)(fabsf(mn) > fabsf(mx) ? fabsf(mn) : fabsf(mx));
+  info->peak_value = (float)fmin(1.0, max_amp / scale);
+  amplification = (max_amp > (double)1e-12f) ? scale / max_amp : 1.0;
+  /* leading / trailing silence below -48 dB of full scale (SA:648-669) */
+  floor_lin = scale * exp(-48.0 * (log(10.0) / 20.0));
+  lead = 0;
+  for (n = 0; n < n_frames; ++n, ++lead) if (fabs(amplification * mono[n]) > floor_lin) break;
+  trail = 0;
+  for (n = n_frames - 1; n > lead; --n, ++trail) if (fabs(amplification * mono[n]) > floor_lin) break;
+  /* pad so that at least half of the last frame and one full frame get analysed (SA:681-696) */
+  audible = n_frames - lead - trail;
+  end_pad = ((audible % fft_size) < fft_size / 2) ? fft_size / 2 : 0;
+  start_pad = (audible + end_pad < fft_size) ? fft_size - audible - end_pad : 0;
+  size = audible + start_pad + end_pad;
+  out = (double*)calloc((size_t)size, sizeof(double));
+  final_scaling = amplification / scale;
+  for (n = 0; n < audible; ++n) out[n + start_pad] = mono[n + lead] * final_scaling;   /* SA:712-718 */
+  info->data_offset = (int32_t)(-lead + start_pad);
+  info->silent_leading = (int32_t)lead;
+  info->silent_trailing = (int32_t)trail;
+  info->n_samples = size;
+  free(mono);
+  return out;
+}
+
+void afx_oracle_free(void* p) { free(p); }

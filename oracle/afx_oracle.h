@@ -62,6 +62,24 @@ double afx_oracle_lin_to_db(double v);
  * kurtosis,flatness,dmean,dvariance (fields the reference leaves untouched stay as passed in) */
 void afx_oracle_calc_statistics(const double* x, int n, double* out13);
 
+/* ---- LoadSample front end (SampleAnalyser.cpp:484-718) on already-decoded interleaved PCM ----
+ * PARITY UNPINNED for this function: SampleAnalyser.cpp does not build here (aubio, Shark, CoreTypes)
+ * and the reference's tests hold no value-level fixture for it; it is a line-by-line restatement.
+ * format: 0 = int16, 1 = packed little-endian int24, 2 = float32 (the reference's decoders turn all
+ * of them into "16-bit floats", CoreFileFormats/Export/SampleConverter.h:446-449, 474-486, 529-533). */
+typedef struct {
+  float peak_value;        /* TSampleData::mPeakValue */
+  float rms_value;         /* TSampleData::mRmsValue  */
+  int32_t data_offset;     /* TSampleData::mDataOffset = -leading + start pad */
+  int32_t silent_leading;
+  int32_t silent_trailing;
+  int64_t n_samples;       /* size of TSampleData::mData */
+} afx_oracle_load_info;
+/* returns a malloc'ed normalised mono buffer (caller frees with afx_oracle_free) */
+double* afx_oracle_load_sample(const void* pcm, int format, int channels, int64_t n_frames, int fft_size,
+                               afx_oracle_load_info* info);
+void afx_oracle_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

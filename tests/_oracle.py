@@ -70,6 +70,33 @@ def lib():
     return _lib
 
 
+class _LoadInfo(ctypes.Structure):
+    _fields_ = [("peak_value", ctypes.c_float), ("rms_value", ctypes.c_float), ("data_offset", ctypes.c_int32),
+                ("silent_leading", ctypes.c_int32), ("silent_trailing", ctypes.c_int32), ("n_samples", ctypes.c_int64)]
+
+
+def load_sample(data, channels, fft=2048):
+    """oracle LoadSample: data int16 / float32 interleaved, or uint8 packed int24 -> (mono doubles, info dict)."""
+    L = lib()
+    L.afx_oracle_load_sample.restype = ctypes.c_void_p
+    L.afx_oracle_load_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                         ctypes.POINTER(_LoadInfo)]
+    L.afx_oracle_free.argtypes = [ctypes.c_void_p]
+    data = np.ascontiguousarray(np.asarray(data).reshape(-1))
+    if data.dtype == np.int16:
+        fmt, frames = 0, data.size // channels
+    elif data.dtype == np.uint8:
+        fmt, frames = 1, data.size // (3 * channels)
+    else:
+        data = data.astype(np.float32)
+        fmt, frames = 2, data.size // channels
+    info = _LoadInfo()
+    p = L.afx_oracle_load_sample(data.ctypes.data, fmt, channels, frames, fft, ctypes.byref(info))
+    out = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), (info.n_samples,)).copy()
+    L.afx_oracle_free(p)
+    return out, {k: getattr(info, k) for k, _ in _LoadInfo._fields_}
+
+
 class Oracle:
     def __init__(self, sample_rate=44100, fft=2048, hop=1024):
         self.L = lib()

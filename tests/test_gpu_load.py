@@ -1,0 +1,83 @@
+"""the LoadSample front end on the GPU (afx_batch_create_from_raw) against the
+oracle's restatement of SampleAnalyser.cpp:484-718.  Integer / float conversion, mix-down, trim
+offsets and the normalised samples must be bit-exact; rms is a sum in a different order."""
+import numpy as np
+import pytest
+
+import afec_amd as afx
+from tests import _oracle, _tol
+from tests._oracle import FIELDS, Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def pack24(x):
+    v = np.clip(np.round(x * 8388607.0), -8388608, 8388607).astype(np.int32)
+    b = np.zeros((v.size, 3), dtype=np.uint8)
+    b[:, 0], b[:, 1], b[:, 2] = v & 0xFF, (v >> 8) & 0xFF, (v >> 16) & 0xFF
+    return b.reshape(-1)
+
+
+def make_files():
+    rng = np.random.default_rng(31)
+    t = np.arange(30000)
+    tone = 0.3 * np.sin(2 * np.pi * 440 * t / 44100) * np.exp(-t / 9000.0)
+    lead = np.concatenate([np.zeros(2205), tone, np.zeros(4000)])
+    stereo = np.stack([lead, 0.8 * np.roll(lead, 7)], axis=1)
+    files = [
+        ((lead * 20000).astype(np.int16), 1),                               # mono 16-bit, leading + trailing silence
+        ((stereo * 30000).astype(np.int16), 2),                             # stereo 16-bit
+        (pack24(0.5 * rng.uniform(-1, 1, 5000)), 1),                        # mono 24-bit, no silence
+        (rng.uniform(-1.2, 1.2, (7000, 2)).astype(np.float32), 2),          # float stereo with clipping
+        (np.zeros(3000, dtype=np.int16), 1),                                # digital silence
+        ((0.6 * np.sin(2 * np.pi * 100 * np.arange(700) / 44100) * 32767).astype(np.int16), 1),  # shorter than a frame
+        (np.concatenate([np.zeros(100), [0.5], np.zeros(100)]).astype(np.float32), 1),           # one loud sample
+        ((rng.uniform(-1, 1, (4097, 6)) * 9000).astype(np.int16), 6),       # 5.1
+    ]
+    return files
+
+
+def test_load_front_end_matches_oracle():
+    files = make_files()
+    plan = afx.Plan()
+    mask = afx.D_MFCC | afx.D_SPECTRAL_CENTROID | afx.D_AMPLITUDE_PEAK
+    batch, infos = plan.batch_from_raw(files, mask)
+    batch.run()
+    res = batch.fetch()
+    ora = Oracle()
+    row = 0
+    for i, (data, ch) in enumerate(files):
+        want, winfo = _oracle.load_sample(data, ch)
+        got_info = infos[i]
+        for k in ("data_offset", "silent_leading", "silent_trailing", "n_samples"):
+            assert got_info[k] == winfo[k], (i, k, got_info[k], winfo[k])
+        assert got_info["peak_value"] == winfo["peak_value"], i
+        assert abs(got_info["rms_value"] - winfo["rms_value"]) <= 2e-7 * max(1e-30, winfo["rms_value"]) + 1e-12, i
+        nf = plan.num_frames(len(want))
+        kept = (nf - 1) * 1024 + 2048 if nf > 0 else 0
+        got = batch.fetch_samples(i, kept)
+        np.testing.assert_array_equal(got, want[:kept], err_msg=f"file {i}")
+        ref = ora.run(want, cap=True)
+        assert ref.shape[0] == nf
+        a, b = FIELDS["mfcc"]
+        _tol.check("mfcc", res["mfcc"][row:row + nf], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"file {i} ")
+        a, b = FIELDS["amplitude_peak"]
+        np.testing.assert_array_equal(res["amplitude_peak"][row:row + nf], ref[:, a])
+        row += nf
+    assert row == batch.total_frames
+    batch.close()
+    plan.close()
+
+
+def test_load_front_end_rejects_bad_files_individually():
+    rng = np.random.default_rng(32)
+    good = (rng.uniform(-1, 1, 5000) * 20000).astype(np.int16)
+    plan = afx.Plan()
+    batch, infos = plan.batch_from_raw([(good, 1), (good, 9), (good, 1, 48000), (good, 1)], afx.D_MFCC)
+    batch.run()
+    res = batch.fetch()
+    assert res["buf_status"].tolist() == [0, -6, -2, 0]     # 9 channels: bad buffer; 48 kHz: needs resampling
+    assert res["frame_offset"].tolist() == [0, 4, 4, 4, 8]   # 5000 audible + 1024 end pad -> 4 frames
+    np.testing.assert_array_equal(res["mfcc"][:4], res["mfcc"][4:])
+    batch.close()
+    plan.close()

@@ -1,0 +1,94 @@
+"""Edge cases and concurrency of the C-ABI on the GPU."""
+import threading
+import time
+
+import numpy as np
+import pytest
+
+import afec_amd as afx
+from tests import _tol
+from tests._oracle import Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_empty_batch_and_all_short_buffers():
+    plan = afx.Plan()
+    res = plan.extract([], afx.D_MFCC)
+    assert res["mfcc"].shape == (0, 14) and res["frame_offset"].tolist() == [0]
+    res = plan.extract([np.zeros(10, np.float32), np.zeros(2047, np.float32)], afx.D_ALL_LOW_LEVEL)
+    assert res["mfcc"].shape == (0, 14) and res["frame_offset"].tolist() == [0, 0, 0]
+    b = plan.batch([np.zeros(5, np.float32)], afx.D_MFCC | afx.D_STATISTICS)
+    b.run()
+    st = b.fetch_statistics()
+    assert np.all(st["mfcc"] == 0.0)          # Length == 0: TStatistics::Calc assigns zeros
+    b.close()
+    plan.close()
+
+
+def test_concurrent_calls_on_one_plan_match_serial():
+    """The plan is shared by worker threads like the const TSampleAnalyser (Crawler.cpp:599, 706-728)."""
+    rng = np.random.default_rng(41)
+    inputs = [[rng.uniform(-1, 1, 2048 + 1024 * int(rng.integers(1, 60))).astype(np.float32) for _ in range(5)]
+              for _ in range(8)]
+    plan = afx.Plan()
+    mask = afx.D_ALL_LOW_LEVEL
+    serial = [plan.extract(bufs, mask) for bufs in inputs]
+    out = [None] * len(inputs)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                out[i] = plan.extract(inputs[i], mask)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(inputs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for a, b in zip(serial, out):
+        for k in a:
+            np.testing.assert_array_equal(a[k], b[k])
+    plan.close()
+
+
+def test_long_uncapped_buffer_head_and_tail():
+    rng = np.random.default_rng(42)
+    nf = 70000                                   # > 2 x 32-frame chunks per wave, ~287 MB of f32 PCM
+    x = rng.uniform(-1, 1, 2048 + 1024 * (nf - 1)).astype(np.float32)
+    plan = afx.Plan(max_analysis_ms=0)
+    res = plan.extract([x], afx.D_MFCC | afx.D_SPECTRAL_ROLLOFF | afx.D_SPECTRAL_FLUX)
+    assert res["mfcc"].shape == (nf, 14)
+    ora = Oracle()
+    for f0 in (0, 31, 32, 33, nf - 40):
+        seg = x[f0 * 1024: f0 * 1024 + 2048 + 1024 * 7].astype(np.float64)
+        want = ora.run(seg)
+        _tol.check("mfcc", res["mfcc"][f0:f0 + 8], want[:, 1024:1038], *_tol.GPU_TOL["mfcc"], what=f"f0={f0} ")
+        np.testing.assert_array_equal(res["spectral_rolloff"][f0:f0 + 8], want[:, 1043])
+        # flux of a frame depends on the previous frame of the same buffer, not of the slice
+        if f0 == 0:
+            _tol.check("flux", res["spectral_flux"][:8], want[:, 1045], *_tol.GPU_TOL["spectral_flux"])
+        else:
+            _tol.check("flux", res["spectral_flux"][f0 + 1:f0 + 8], want[1:, 1045], *_tol.GPU_TOL["spectral_flux"])
+    plan.close()
+
+
+def test_pcie_inclusive_one_shot_rate_is_reported():
+    """DESIGN.md section 7 quotes the PCIe-inclusive afx_extract_batch rate; keep it measurable."""
+    rng = np.random.default_rng(43)
+    x = rng.uniform(-1, 1, 2048 + 1024 * 9999).astype(np.float32)
+    plan = afx.Plan(max_analysis_ms=0)
+    plan.extract([x], afx.D_C2)
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        plan.extract([x], afx.D_C2)
+    dt = (time.perf_counter() - t0) / n
+    rate = 10000 / dt
+    print(f"one-shot afx_extract_batch, 10k frames incl. H2D/D2H and allocation: {rate / 1e6:.2f} M frames/s")
+    assert rate > 1e5
+    plan.close()

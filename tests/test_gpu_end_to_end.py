@@ -1,0 +1,77 @@
+"""End to end at BASELINE.json's C3 / C4 shapes: decoded PCM -> LoadSample front end (f3) -> the
+spectral path -> per-file statistics (f1), all on the GPU through the C-ABI, against the oracle
+pipeline (load_sample -> run -> calc_statistics) on a sample of the files."""
+import numpy as np
+import pytest
+
+import afec_amd as afx
+from tests import _oracle, _tol
+from tests._oracle import FIELDS, Oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def synth_file(rng, seconds, stereo):
+    n = int(44100 * seconds)
+    t = np.arange(n) / 44100.0
+    x = np.zeros(n)
+    for _ in range(int(rng.integers(1, 4))):
+        x += rng.uniform(0.2, 0.6) * np.sin(2 * np.pi * rng.uniform(110.0, 4000.0) * t + rng.uniform(0, 6.28))
+    x += rng.uniform(0.2, 0.8) * rng.uniform(-1, 1, n) * np.exp(-t / rng.uniform(0.05, 0.5))
+    x[:2205] = 0.0                                   # 50 ms of leading silence
+    x *= rng.uniform(0.1, 0.9) / np.max(np.abs(x))
+    if stereo:                                       # R = L delayed 7 samples x 0.8
+        y = np.stack([x, 0.8 * np.roll(x, 7)], axis=1)
+        return (y * 32767).astype(np.int16), 2
+    return (x * 32767).astype(np.int16), 1
+
+
+@pytest.mark.parametrize("shape", ["c3_mono_2s", "c4_stereo_1s"])
+def test_pipeline_matches_oracle_on_sampled_files(shape):
+    rng = np.random.default_rng(51)
+    stereo = shape.startswith("c4")
+    n_files = 300
+    files = [synth_file(rng, 1.0 if stereo else 2.0, stereo) for _ in range(n_files)]
+    plan = afx.Plan()
+    mask = afx.D_ALL_LOW_LEVEL | afx.D_STATISTICS
+    batch, infos = plan.batch_from_raw(files, mask)
+    batch.run()
+    res = batch.fetch()
+    stats = batch.fetch_statistics()
+    assert stats["stats_status"].tolist() == [0] * n_files and res["buf_status"].tolist() == [0] * n_files
+    off = res["frame_offset"]
+    ora = Oracle()
+    for i in rng.choice(n_files, 8, replace=False):
+        data, ch = files[i]
+        mono, info = _oracle.load_sample(data, ch)
+        assert infos[i]["n_samples"] == info["n_samples"] and infos[i]["data_offset"] == info["data_offset"]
+        ref = ora.run(mono, cap=True)
+        assert off[i + 1] - off[i] == ref.shape[0]
+        for field, (a, b) in FIELDS.items():
+            if field == "mag":
+                continue
+            rtol, atol = _tol.GPU_TOL[field]
+            got = res[field][off[i]:off[i + 1]].reshape(ref.shape[0], -1)
+            _tol.check(field, got, ref[:, a:b], rtol, atol, what=f"{shape} file {i} ")
+            # per-file statistics of the same series
+            width = b - a
+            gs = stats[field].reshape(n_files, width, 13)[i]
+            for w in range(width):
+                want = _oracle.calc_statistics(ref[:, a + w], np.zeros(13))
+                # inherits the series' 1e-4; skewness / kurtosis of a series divide by the spread of the frame
+                # positions, and dvariance squares differences of neighbours: looser relative bound
+                tol = np.array([1e-4, 1e-4, 1e-4, 1e-4, 1e-4, 5e-4, 1e-4, 1e-4, 5e-3, 5e-3, 2e-4, 5e-4, 2e-3])
+                scale = 1e-6 * (1.0 + np.max(np.abs(want)))
+                if field in ("spectral_rolloff", "sub_complexity"):
+                    continue                          # discrete series: compared above frame by frame
+                err = np.abs(gs[w] - want)
+                ok = err <= tol * np.abs(want) + scale
+                # TStatistics::Centroid / Spread / Flatness divide by the *sum* (mean) of the series: for a
+                # series that sums to rounding residue (e.g. band flux values of +-1) they are decided by the
+                # last bit of the inputs in any implementation
+                series = ref[:, a + w]
+                if abs(series.sum()) < 1e-6 * np.abs(series).sum():
+                    ok[[6, 7, 8, 9, 10]] = True
+                assert np.all(ok), (shape, int(i), field, w, gs[w], want)
+    batch.close()
+    plan.close()

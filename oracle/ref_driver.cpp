@@ -135,75 +135,64 @@ static void Frame(TRef& R, const double* x, const double* mag, const double* las
   // CalcSpectralFlux (1919-1933)
   out[oFlux] = TStatistics::Flux(m, last + R.mFirstBin, n);
 
-  // CalcSpectralBandFeatures (2067-2308) -- body is inline in SampleAnalyser.cpp, restated
+  // CalcSpectralBandFeatures (SampleAnalyser.cpp:2067-2308): the body is inline member code, so its
+  // control flow is restated here; Mean / Flux / Flatness go through the reference's TStatistics.
   {
-    static const double sBandFrequencies[] = { 50.0, 100.0, 200.0, 400.0, 630.0, 920.0, 1270.0,
+    static const double edges_hz[kNumSub] = { 50.0, 100.0, 200.0, 400.0, 630.0, 920.0, 1270.0,
       1720.0, 2320.0, 3150.0, 4400.0, 6400.0, 9500.0, 15500.0 };
-    const double NeighbourRatio = 0.3, Epsilon = 1e-30;
-    const double FrequenciesPerBin = kSampleRate / kFft;
-    const int FirstBin = TMath::d2iRound(20.0 / FrequenciesPerBin);
-    int NumberOfBinsInBands[kNumSub];
+    const double hz_per_bin = kSampleRate / kFft;                    // integer division, as there
+    const int first_bin = TMath::d2iRound(20.0 / hz_per_bin);
+    int width[kNumSub];
     for (int b = 0; b < kNumSub; ++b) {
-      const int StartBin = (b == 0) ? FirstBin : TMath::d2iRound(sBandFrequencies[b - 1] / FrequenciesPerBin);
-      const int EndBin = TMath::d2iRound(sBandFrequencies[b] / FrequenciesPerBin);
-      NumberOfBinsInBands[b] = EndBin - StartBin + 1;
+      const int lo = (b == 0) ? first_bin : TMath::d2iRound(edges_hz[b - 1] / hz_per_bin);
+      width[b] = TMath::d2iRound(edges_hz[b] / hz_per_bin) - lo + 1;
     }
-    std::vector<double> Magnitudes(mag, mag + kFft / 2), LastMagnitudes(last, last + kFft / 2);
-    double ContrastSum = 0.0;
-    for (int BandIndex = 0, CurrentBin = FirstBin; BandIndex < kNumSub; ++BandIndex) {
-      const int NumBinsInBand = MMin(NumberOfBinsInBands[BandIndex], (int)Magnitudes.size() - CurrentBin);
-      const double BandMean = TStatistics::Mean(Magnitudes.data() + CurrentBin, NumBinsInBand);
-      double Rms = 0.0;
-      for (int i = 0; i < NumBinsInBand; ++i) Rms += TMathT<double>::Square(Magnitudes[CurrentBin + i]);
-      Rms = ::sqrt(Rms / (double)NumBinsInBand);
-      const double Flatness = SFlatnessDb(Magnitudes.data() + CurrentBin, NumBinsInBand);
-      const double Flux = TStatistics::Flux(Magnitudes.data() + CurrentBin, LastMagnitudes.data() + CurrentBin, NumBinsInBand);
-      double ComplexityThreshold = 0.0;
-      for (int i = 0; i < NumBinsInBand; ++i) ComplexityThreshold = MMax(ComplexityThreshold, Magnitudes[CurrentBin + i]);
-      ComplexityThreshold *= 0.25;
-      double Complexity = 0;
-      if (ComplexityThreshold > 0.0) {
-        for (int i = 0; i < NumBinsInBand; ++i) {
-          const int b = CurrentBin + i;
-          if (mag[b] > ComplexityThreshold) {
-            if (b > 0 && b < (int)Magnitudes.size() - 1 && mag[b] > mag[b - 1] && mag[b] > mag[b + 1]) ++Complexity;
-          }
-        }
-      }
-      std::sort(Magnitudes.begin() + CurrentBin, Magnitudes.begin() + CurrentBin + NumBinsInBand);
-      const int NeighbourBins = MMax(1, (int)(NeighbourRatio * NumBinsInBand));
-      double Sum = 0;
-      for (int i = 0; i < NeighbourBins && i < NumBinsInBand; ++i) Sum += Magnitudes[CurrentBin + i];
-      const double Valley = Sum / NeighbourBins + Epsilon;
-      Sum = 0;
-      for (int i = NumBinsInBand; i > NumBinsInBand - NeighbourBins; --i) Sum += Magnitudes[CurrentBin + i - 1];
-      const double Peak = Sum / NeighbourBins + Epsilon;
-      const double Contrast = -1.0 * ::pow(Peak / Valley, 1.0 / ::log(BandMean + Epsilon));
-      out[oSubRms + BandIndex] = Rms;
-      out[oSubFlat + BandIndex] = Flatness;
-      out[oSubFlux + BandIndex] = Flux;
-      out[oSubCplx + BandIndex] = Complexity;
-      out[oSubContrast + BandIndex] = Contrast;
-      ContrastSum += Contrast;
-      CurrentBin += NumBinsInBand;
+    std::vector<double> cur(mag, mag + kFft / 2), prv(last, last + kFft / 2);  // cur gets sorted band by band
+    double contrast_total = 0.0;
+    int at = first_bin;
+    for (int b = 0; b < kNumSub; ++b) {
+      const int nb = std::min(width[b], (int)cur.size() - at);
+      double* seg = cur.data() + at;
+      const double seg_mean = TStatistics::Mean(seg, nb);
+      double sq = 0.0, top = 0.0;
+      for (int i = 0; i < nb; ++i) { sq += seg[i] * seg[i]; top = std::max(top, seg[i]); }
+      out[oSubRms + b] = ::sqrt(sq / (double)nb);
+      out[oSubFlat + b] = SFlatnessDb(seg, nb);
+      out[oSubFlux + b] = TStatistics::Flux(seg, prv.data() + at, nb);
+      // strict local maxima of the *unsorted* spectrum above a quarter of the band maximum
+      const double thr = 0.25 * top;
+      double peaks = 0;
+      if (thr > 0.0)
+        for (int k = at; k < at + nb; ++k)
+          if (mag[k] > thr && k > 0 && k < (int)cur.size() - 1 && mag[k] > mag[k - 1] && mag[k] > mag[k + 1]) ++peaks;
+      out[oSubCplx + b] = peaks;
+      // contrast from the mean of the lowest / highest 30 % of the sorted band
+      std::sort(seg, seg + nb);
+      const int take = std::max(1, (int)(0.3 * nb));
+      double lo_sum = 0, hi_sum = 0;
+      for (int i = 0; i < take && i < nb; ++i) lo_sum += seg[i];
+      for (int i = nb; i > nb - take; --i) hi_sum += seg[i - 1];
+      const double valley = lo_sum / take + 1e-30, peak = hi_sum / take + 1e-30;
+      out[oSubContrast + b] = -1.0 * ::pow(peak / valley, 1.0 / ::log(seg_mean + 1e-30));
+      contrast_total += out[oSubContrast + b];
+      at += nb;
     }
-    out[oContrast] = ContrastSum / kNumSub;
+    out[oContrast] = contrast_total / kNumSub;
   }
 
-  // CalcSpectrumBands (2007-2048) -- inline body, restated
+  // CalcSpectrumBands (SampleAnalyser.cpp:2007-2048): inline body, restated
   {
-    static const double sBandFrequencies[] = { 50.0, 100.0, 150.0, 200.0, 300.0, 400.0, 510.0, 630.0,
+    static const double edges_hz[kNumBands] = { 50.0, 100.0, 150.0, 200.0, 300.0, 400.0, 510.0, 630.0,
       770.0, 920.0, 1080.0, 1270.0, 1480.0, 1720.0, 2000.0, 2320.0, 2700.0, 3150.0, 3700.0, 4400.0,
       5300.0, 6400.0, 7700.0, 9500.0, 12000.0, 15500.0, 19000.0, 22050.0 };
-    const double FrequenciesPerBin = kSampleRate / kFft;
-    const int FirstBin = TMath::d2iRound(20.0 / FrequenciesPerBin);
+    const double hz_per_bin = kSampleRate / kFft;
+    const int first_bin = TMath::d2iRound(20.0 / hz_per_bin);
     for (int b = 0; b < kNumBands; ++b) out[oBands + b] = 0.0;
     for (int b = 0; b < kNumBands; ++b) {
-      int StartBin = TMath::d2iRound((b == 0) ? FirstBin : sBandFrequencies[b - 1] / FrequenciesPerBin);
-      if (StartBin >= kFft / 2) break;
-      int EndBin = TMath::d2iRound(sBandFrequencies[b] / FrequenciesPerBin);
-      EndBin = MMin(kFft / 2, EndBin);
-      for (int s = StartBin; s < EndBin; s++) out[oBands + b] += TMathT<double>::Square(mag[s]);
+      const int lo = TMath::d2iRound((b == 0) ? (double)first_bin : edges_hz[b - 1] / hz_per_bin);
+      if (lo >= kFft / 2) break;
+      const int hi = std::min(kFft / 2, TMath::d2iRound(edges_hz[b] / hz_per_bin));
+      for (int k = lo; k < hi; ++k) out[oBands + b] += mag[k] * mag[k];
     }
   }
 

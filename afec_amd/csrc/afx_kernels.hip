@@ -48,6 +48,12 @@ namespace {
 #ifndef AFX_WAVES_C2
 #define AFX_WAVES_C2 8
 #endif
+#ifndef AFX_WIN_GLOBAL
+#define AFX_WIN_GLOBAL 1   // double kernels: window table from global memory (1) or LDS (0)
+#endif
+#ifndef AFX_TABLE_BATCH
+#define AFX_TABLE_BATCH 0  // >0: fence the scheduler every N table reads (caps live table registers)
+#endif
 
 // E2 plane: 8-byte slots, slot = k1 + 65 n2 (k1 < 64, n2 < 16): write = lane part (4 jh + 65 n2)
 // + immediate (16 j2 + jl), read = lane + immediate 65 n2.  complex<float> is one slot;
@@ -127,7 +133,7 @@ struct InPair<double> {
 // LDS instruction issue, the vector-memory path is otherwise idle.
 template <typename T, int POST_ROWS>
 struct LdsMap {
-  static constexpr bool win_global = sizeof(T) == 8;
+  static constexpr bool win_global = sizeof(T) == 8 && AFX_WIN_GLOBAL;
   static constexpr int win = 0;                                                     // [16][64] cx<T>
   static constexpr int t2 = win + (win_global ? 0 : 1024 * (int)sizeof(cx<T>));     // [16][64] cx<T>
   static constexpr int post = t2 + 1024 * (int)sizeof(cx<T>);                       // [POST_ROWS][64] cx<T>
@@ -333,6 +339,9 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         v[r] = {(T)lo[r].x * w0.re, (T)lo[r].y * w0.im};
         v[r + 8] = {(T)nxt[r].x * w1.re, (T)nxt[r].y * w1.im};
         lo[r] = nxt[r];
+#if AFX_TABLE_BATCH
+        if ((2 * r + 2) % AFX_TABLE_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
       }
       // prefetch the next frame's new hop (rows 8..15 of frame fi + 1)
       if (fi + 1 < total) {
@@ -351,7 +360,12 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) radix4(v[jl], v[4 + jl], v[8 + jl], v[12 + jl]);
 #pragma unroll
-      for (int g = 0; g < 16; ++g) v[g] = cmul(v[g], (AFX_ABL & 2) ? cx<T>{(T)0.6, (T)0.8} : t2[64 * g]);
+      for (int g = 0; g < 16; ++g) {
+        v[g] = cmul(v[g], (AFX_ABL & 2) ? cx<T>{(T)0.6, (T)0.8} : t2[64 * g]);
+#if AFX_TABLE_BATCH
+        if ((g + 1) % AFX_TABLE_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
+#endif
+      }
       Xchg<T>::run(plane, e2r_addr, e2w, v);
 
       // ---- P3: v[k2] = Z[lane + 64 k2] ----

@@ -124,7 +124,23 @@ struct DeviceTables {
 
 }  // namespace
 
+// Device buffers, stream and events of one batch.  Kept in a small per-plan pool so that the
+// one-file-per-call pattern of the reference (one Extract() per worker thread and file,
+// Crawler.cpp:706-728) does not pay hipMalloc / hipStreamCreate on every call.
+struct Workspace {
+  struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+  };
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  Buf pcm, chunks, rec, mag, prev, foff, stats;
+  size_t bytes() const { return pcm.cap + chunks.cap + rec.cap + mag.cap + prev.cap + foff.cap + stats.cap; }
+};
+
 struct afx_plan {
+  std::mutex pool_mutex;
+  std::vector<Workspace*> pool;
   afx_plan_desc desc;
   int first_bin, last_bin, bin_count;
   std::vector<double> window;  // [fft]
@@ -144,6 +160,7 @@ struct afx_batch {
   int n_chunks = 0;
   int grid_blocks = 0;
   afx::RecordLayout lay{};
+  Workspace* ws = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   void* d_pcm = nullptr;
@@ -223,6 +240,61 @@ void free_tables(afx_plan* p) {
   hipFree(p->dev.win); hipFree(p->dev.t1); hipFree(p->dev.t2); hipFree(p->dev.post);
   hipFree(p->dev.melw); hipFree(p->dev.dct);
   p->dev = DeviceTables{};
+}
+
+void ws_free(Workspace* w) {
+  if (!w) return;
+  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rec, &w->mag, &w->prev, &w->foff, &w->stats}) hipFree(b->p);
+  if (w->ev0) hipEventDestroy(w->ev0);
+  if (w->ev1) hipEventDestroy(w->ev1);
+  if (w->stream) hipStreamDestroy(w->stream);
+  delete w;
+}
+
+// pooled workspaces: at most 16 idle ones per plan, none larger than 1 GiB
+constexpr size_t kPoolMaxIdle = 16;
+constexpr size_t kPoolMaxBytes = (size_t)1 << 30;
+
+Workspace* ws_acquire(afx_plan* plan, hipError_t* err) {
+  {
+    std::lock_guard<std::mutex> lock(plan->pool_mutex);
+    if (!plan->pool.empty()) {
+      Workspace* w = plan->pool.back();
+      plan->pool.pop_back();
+      return w;
+    }
+  }
+  Workspace* w = new (std::nothrow) Workspace();
+  if (!w) { *err = hipErrorOutOfMemory; return nullptr; }
+  hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreate(&w->ev0);
+  if (e == hipSuccess) e = hipEventCreate(&w->ev1);
+  if (e != hipSuccess) { *err = e; ws_free(w); return nullptr; }
+  return w;
+}
+
+void ws_release(afx_plan* plan, Workspace* w) {
+  if (!w) return;
+  if (w->bytes() <= kPoolMaxBytes) {
+    std::lock_guard<std::mutex> lock(plan->pool_mutex);
+    if (plan->pool.size() < kPoolMaxIdle) {
+      plan->pool.push_back(w);
+      return;
+    }
+  }
+  ws_free(w);
+}
+
+hipError_t ws_reserve(Workspace::Buf& b, size_t bytes) {
+  if (bytes <= b.cap) return hipSuccess;
+  hipFree(b.p);
+  b.p = nullptr;
+  b.cap = 0;
+  const size_t want = bytes + bytes / 4 + 4096;
+  hipError_t e = hipMalloc(&b.p, want);
+  if (e != hipSuccess) return e;
+  b.cap = want;
+  return hipSuccess;
 }
 
 afx::RecordLayout make_layout(uint32_t mask) {
@@ -345,6 +417,8 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
 void afx_plan_destroy(afx_plan* plan) {
   if (!plan) return;
   hipSetDevice(plan->desc.device);
+  for (Workspace* w : plan->pool) ws_free(w);
+  plan->pool.clear();
   free_tables(plan);
   delete plan;
 }
@@ -388,7 +462,7 @@ namespace {
 // size esz) using b->stream.
 template <typename Fill>
 int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const std::vector<int64_t>& lengths,
-                const std::vector<int32_t>& status, Fill fill, afx_batch** out_batch) {
+                const std::vector<int32_t>& status, bool zero_arena, Fill fill, afx_batch** out_batch) {
   const bool want_stats = (mask & AFX_D_STATISTICS) != 0;
   mask &= ~(uint32_t)AFX_D_STATISTICS;   // the kernels see the descriptor bits only
 
@@ -451,38 +525,48 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   if (b->grid_blocks < 1) b->grid_blocks = 1;
 
   auto cleanup = [&](int st) { afx_batch_destroy(b); return st; };
-  hipError_t e;
-  if ((e = hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamCreate"));
-  if ((e = hipEventCreate(&b->ev0)) != hipSuccess) return cleanup(hip_fail(e, "hipEventCreate"));
-  if ((e = hipEventCreate(&b->ev1)) != hipSuccess) return cleanup(hip_fail(e, "hipEventCreate"));
+  hipError_t e = hipSuccess;
+  b->ws = ws_acquire(plan, &e);
+  if (!b->ws) return cleanup(hip_fail(e, "workspace"));
+  Workspace& w = *b->ws;
+  b->stream = w.stream; b->ev0 = w.ev0; b->ev1 = w.ev1;
   if (arena > 0) {
-    if ((e = hipMalloc(&b->d_pcm, (size_t)arena * esz + 16384)) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(pcm)"));
-    if ((e = hipMemsetAsync(b->d_pcm, 0, (size_t)arena * esz + 16384, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemset"));
+    if ((e = ws_reserve(w.pcm, (size_t)arena * esz + 64)) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(pcm)"));
+    b->d_pcm = w.pcm.p;
+    if (zero_arena && (e = hipMemsetAsync(b->d_pcm, 0, (size_t)arena * esz, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemset"));
     const int st = fill(b);
     if (st != AFX_OK) return cleanup(st);
   }
   if (b->n_chunks > 0) {
-    if ((e = hipMalloc((void**)&b->d_chunks, chunks.size() * sizeof(afx::Chunk))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(chunks)"));
+    if ((e = ws_reserve(w.chunks, chunks.size() * sizeof(afx::Chunk))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(chunks)"));
+    b->d_chunks = (afx::Chunk*)w.chunks.p;
     if ((e = hipMemcpyAsync(b->d_chunks, chunks.data(), chunks.size() * sizeof(afx::Chunk), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(chunks)"));
   }
   if (frames > 0 && b->lay.stride > 0) {
-    if ((e = hipMalloc((void**)&b->d_rec, (size_t)frames * b->lay.stride * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rec)"));
+    if ((e = ws_reserve(w.rec, (size_t)frames * b->lay.stride * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rec)"));
+    b->d_rec = (double*)w.rec.p;
   }
   if (frames > 0 && b->mag_wanted) {
-    if ((e = hipMalloc((void**)&b->d_mag, (size_t)frames * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(mag)"));
+    if ((e = ws_reserve(w.mag, (size_t)frames * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(mag)"));
+    b->d_mag = (double*)w.mag.p;
   }
   if (frames > 0 && (mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX))) {
     std::vector<int32_t> prev((size_t)frames);
     for (int i = 0; i < n_bufs; ++i)
       for (int64_t f = b->frame_offset[i]; f < b->frame_offset[i + 1]; ++f)
         prev[(size_t)f] = (int32_t)((f == b->frame_offset[i]) ? f : f - 1);  // SampleAnalyser.cpp:937-940
-    if ((e = hipMalloc((void**)&b->d_prev, prev.size() * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(prev)"));
+    if ((e = ws_reserve(w.prev, prev.size() * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(prev)"));
+    b->d_prev = (int32_t*)w.prev.p;
+    // pageable source: the copy is complete (staged) when the call returns
     if ((e = hipMemcpyAsync(b->d_prev, prev.data(), prev.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(prev)"));
+    if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
   }
   if (want_stats && n_bufs > 0 && b->lay.stride > 0) {
-    if ((e = hipMalloc((void**)&b->d_frame_offset, b->frame_offset.size() * sizeof(int64_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(frame_offset)"));
+    if ((e = ws_reserve(w.foff, b->frame_offset.size() * sizeof(int64_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(frame_offset)"));
+    b->d_frame_offset = (int64_t*)w.foff.p;
     if ((e = hipMemcpyAsync(b->d_frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(frame_offset)"));
-    if ((e = hipMalloc((void**)&b->d_stats, (size_t)n_bufs * b->lay.stride * 13 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stats)"));
+    if ((e = ws_reserve(w.stats, (size_t)n_bufs * b->lay.stride * 13 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stats)"));
+    b->d_stats = (double*)w.stats.p;
   }
   if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
   *out_batch = b;
@@ -530,7 +614,7 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
       }
     return AFX_OK;
   };
-  return build_batch(plan, n_bufs, mask, dtype, lengths, status, fill, out_batch);
+  return build_batch(plan, n_bufs, mask, dtype, lengths, status, /*zero_arena=*/false, fill, out_batch);
 }
 
 // LoadSample front end (SampleAnalyser.cpp:484-718) on the GPU: decoded interleaved PCM in,
@@ -619,7 +703,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     hipFree(d_place);
     return e2 == hipSuccess ? AFX_OK : hip_fail(e2, "load_write");
   };
-  const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, fill, out_batch);
+  const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch);
   free_tmp();
   return st;
 }
@@ -637,8 +721,17 @@ int64_t afx_batch_total_frames(const afx_batch* batch) { return batch ? batch->t
 
 int afx_batch_run(afx_batch* b) {
   if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
-  if (b->total_frames == 0) return AFX_OK;
   HIP_TRY(hipSetDevice(b->plan->desc.device));
+  if (b->total_frames == 0) {
+    // nothing to analyse; empty series still reduce to TStatistics::Calc's Length == 0 result
+    if (b->d_stats) {
+      afx::StatsArgs sa{};
+      sa.rec = b->d_rec; sa.frame_offset = b->d_frame_offset; sa.n_bufs = b->n_bufs; sa.stride = b->lay.stride;
+      sa.stats = b->d_stats;
+      HIP_TRY(afx::launch_stats(sa, b->stream));
+    }
+    return AFX_OK;
+  }
   afx::FrameArgs a{};
   a.pcm = b->d_pcm;
   a.chunks = b->d_chunks;
@@ -759,11 +852,7 @@ void afx_batch_destroy(afx_batch* b) {
   if (!b) return;
   hipSetDevice(b->plan->desc.device);
   if (b->stream) hipStreamSynchronize(b->stream);
-  hipFree(b->d_pcm); hipFree(b->d_chunks); hipFree(b->d_rec); hipFree(b->d_mag); hipFree(b->d_prev);
-  hipFree(b->d_frame_offset); hipFree(b->d_stats);
-  if (b->ev0) hipEventDestroy(b->ev0);
-  if (b->ev1) hipEventDestroy(b->ev1);
-  if (b->stream) hipStreamDestroy(b->stream);
+  ws_release(b->plan, b->ws);
   delete b;
 }
 

@@ -567,8 +567,14 @@ hipError_t launch_one(const FrameArgs& a, int grid_blocks, hipStream_t stream) {
   constexpr int MR = (FEAT == kFeatC2) ? kMelRows : (FEAT == kFeatStats ? 12 : 16);
   const size_t lds = (size_t)LdsMap<T, MR>::total(WAVES);
   auto k = frames_kernel<T, TIn, FEAT, WAVES>;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  static bool attribute_set[16] = {};   // per device: raising the dynamic LDS limit once is enough
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attribute_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16) attribute_set[dev] = true;
+  }
   hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(WAVES * 64), lds, stream, a);
   return hipGetLastError();
 }

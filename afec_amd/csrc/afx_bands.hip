@@ -260,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     }
     const double mean = (nb >= 2.0) ? sx / nb : sx;                    // TStatistics::Mean
     const double rms = sqrt(sxx / nb);                                 // SA:2154-2159
-    const double gm = exp(slog / nb);                                  // Statistics.cpp:442
+    const double gm = fast_exp(slog / nb);                             // Statistics.cpp:442
     const double fl = (mean == 0.0) ? 0.0 : gm / mean;                 // Statistics.cpp:565-574
     double fdb = lin_to_db(fl) / -60.0;                                // SFlatnessDb, SA:129-133
     fdb = fdb < 1.0 ? fdb : 1.0;
@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     const double num = sxy - (ma * mb * nb);
     const double flux = (fabs(denom2) > (double)1e-12f) ? num / sqrt(denom2) : 0.0;
     const double valley = vsum / nn + 1e-30, peakv = psum / nn + 1e-30;  // SA:2216, 2228
-    const double contrast = -1.0 * pow(peakv / valley, 1.0 / log(mean + 1e-30));  // SA:2231-2232
+    // pow(a, b) = exp(b log a), a > 0 (SA:2231-2232)
+    const double contrast = -1.0 * fast_exp(fast_log(peakv / valley) / fast_log(mean + 1e-30));
 
     double* const rec = a.rec + f * a.lay.stride;
     if (valid && (lane & 3) == 0) {

@@ -69,24 +69,27 @@ __device__ __forceinline__ double wave_sum16(double (&a)[16], int lane) {
   return z;
 }
 
-// full-wave sum, result in every lane
+// value of lane L (compile-time) as a wave-uniform double: two v_readlane_b32, no LDS traffic
+template <int L>
+__device__ __forceinline__ double read_lane(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), L);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), L);
+  return __hiloint2double(hi, lo);
+}
+// full-wave sum, result in every lane: DPP inside the 16-lane rows, readlane across the four rows
 __device__ __forceinline__ double wave_sum(double v) {
   v += dpp_mov<kDppXor1>(v);
   v += dpp_mov<kDppXor2>(v);
   v += dpp_mov<kDppHalfMirror>(v);
   v += dpp_mov<kDppMirror>(v);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
+  return (read_lane<0>(v) + read_lane<16>(v)) + (read_lane<32>(v) + read_lane<48>(v));
 }
 __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_mov<kDppXor1>(v));
   v = fmax(v, dpp_mov<kDppXor2>(v));
   v = fmax(v, dpp_mov<kDppHalfMirror>(v));
   v = fmax(v, dpp_mov<kDppMirror>(v));
-  v = fmax(v, __shfl_xor(v, 16));
-  v = fmax(v, __shfl_xor(v, 32));
-  return v;
+  return fmax(fmax(read_lane<0>(v), read_lane<16>(v)), fmax(read_lane<32>(v), read_lane<48>(v)));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
@@ -181,6 +184,27 @@ __device__ __forceinline__ double fast_log(double x) {
   p = fma(p, z, 1.0 / 3.0);
   p = fma(p, z, 1.0);
   return fma((double)e, 0.693147180559945309417, 2.0 * s * p);
+}
+
+// e^x for |x| < 700: x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor on r (|error| < 2e-16 relative), ldexp
+__device__ __forceinline__ double fast_exp(double x) {
+  const double kf = rint(x * 1.44269504088896340736);
+  const double r = fma(-kf, 1.90821492927058770002e-10, fma(-kf, 6.93147180369123816490e-01, x));
+  double p = 1.0 / 6227020800.0;
+  p = fma(p, r, 1.0 / 479001600.0);
+  p = fma(p, r, 1.0 / 39916800.0);
+  p = fma(p, r, 1.0 / 3628800.0);
+  p = fma(p, r, 1.0 / 362880.0);
+  p = fma(p, r, 1.0 / 40320.0);
+  p = fma(p, r, 1.0 / 5040.0);
+  p = fma(p, r, 1.0 / 720.0);
+  p = fma(p, r, 1.0 / 120.0);
+  p = fma(p, r, 1.0 / 24.0);
+  p = fma(p, r, 1.0 / 6.0);
+  p = fma(p, r, 0.5);
+  p = fma(p, r, 1.0);
+  p = fma(p, r, 1.0);
+  return ldexp(p, (int)kf);
 }
 
 }  // namespace

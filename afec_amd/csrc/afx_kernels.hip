@@ -266,7 +266,8 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   constexpr int MR = (FEAT == kFeatC2) ? kMelRows : (FEAT == kFeatStats ? 12 : 16);
   using Map = LdsMap<T, MR>;
   extern __shared__ __align__(16) unsigned char lds_raw[];
-  const int lane = threadIdx.x & 63;
+  const int lane0 = threadIdx.x & 63;
+  const int lane = lane0;
   const int wave = threadIdx.x >> 6;
 
   // ---- shared tables ----
@@ -317,6 +318,10 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
     int64_t pending_row0 = 0;
 
     for (int fi = 0; fi < total; ++fi) {
+      // the statistics classes test hundreds of lane ranges: re-materialise the lane id per frame so the
+      // predicates are recomputed instead of being hoisted into (spilled) SGPR pairs
+      int lane = lane0;
+      if (FEAT != kFeatC2) asm volatile("" : "+v"(lane));
       // ---- time-domain descriptors on the hop = rows 0..7 (SA:871-872) ----
       double amp_peak = 0.0, amp_sq = 0.0;
       if (FEAT != kFeatC2 && (a.mask & ((1u << 11) | (1u << 12)))) {
@@ -481,8 +486,8 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
             }
           }
           if (a.mask & (1u << 7)) {  // flatness: GM / AM in dB / -60, clamped (SA:129-133)
-            const double sumlog = wave_sum(log(prod));
-            const double gm = exp(sumlog / n);
+            const double sumlog = wave_sum(fast_log(prod));
+            const double gm = fast_exp(sumlog / n);
             const double am = s1 / n;
             const double fl = (am == 0.0) ? 0.0 : gm / am;
             const double d = lin_to_db(fl) / -60.0;

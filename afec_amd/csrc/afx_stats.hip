@@ -116,7 +116,7 @@ __device__ void series_stats(const double* col, int64_t cstride, int n, int lane
   slog = wave_sum(slog);
   sd = wave_sum(sd);
   const double mean = s / dn;                                // Mean, n >= 2
-  const double gmean = exp(slog / dn);
+  const double gmean = fast_exp(slog / dn);
   const double cen = (s == 0.0) ? 0.0 : sj / s;              // Centroid, Statistics.cpp:459-477
   const int nd = n - 1;
   const double dmean = (nd >= 2) ? sd / (double)nd : sd;     // Mean of the n-1 absolute differences

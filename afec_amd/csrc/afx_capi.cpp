@@ -118,7 +118,7 @@ struct DeviceTables {
   void* t1 = nullptr;
   void* t2 = nullptr;
   void* post = nullptr;
-  double* melw = nullptr;
+  void* melw = nullptr;
   double* dct = nullptr;
 };
 
@@ -215,7 +215,7 @@ int upload_tables(afx_plan* p) {
   int st = (p->desc.precision == AFX_PRECISION_F64) ? upload_tables_typed<double>(p)
                                                     : upload_tables_typed<float>(p);
   if (st != AFX_OK) return st;
-  // packed mel rows: one 64-lane row per (r, f) pair the static cover lists
+  // packed mel rows: one 64-lane row per (r, f) pair the static cover lists, in the kernel's precision
   std::vector<double> melw((size_t)afx::kMelPairs * 64, 0.0);
   int idx = 0;
   for (int r = 0; r < afx::kMelRows; ++r)
@@ -225,12 +225,18 @@ int upload_tables(afx_plan* p) {
           melw[(size_t)idx * 64 + lane] = p->mel[(size_t)f * afx::kHalf + 64 * r + lane];
         ++idx;
       }
+  if (p->desc.precision == AFX_PRECISION_F64) {
+    HIP_TRY(hipMalloc(&p->dev.melw, melw.size() * sizeof(double)));
+    HIP_TRY(hipMemcpy(p->dev.melw, melw.data(), melw.size() * sizeof(double), hipMemcpyHostToDevice));
+  } else {
+    std::vector<float> melf(melw.begin(), melw.end());
+    HIP_TRY(hipMalloc(&p->dev.melw, melf.size() * sizeof(float)));
+    HIP_TRY(hipMemcpy(p->dev.melw, melf.data(), melf.size() * sizeof(float), hipMemcpyHostToDevice));
+  }
   // DCT-II basis exactly as xtract_dct evaluates it (vector.c:381-385)
   std::vector<double> dct(14 * 16, 0.0);
   for (int n = 0; n < 14; ++n)
     for (int m = 1; m <= 14; ++m) dct[16 * n + (m - 1)] = std::cos(M_PI * (n / (double)14) * (m - 0.5));
-  HIP_TRY(hipMalloc((void**)&p->dev.melw, melw.size() * sizeof(double)));
-  HIP_TRY(hipMemcpy(p->dev.melw, melw.data(), melw.size() * sizeof(double), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc((void**)&p->dev.dct, dct.size() * sizeof(double)));
   HIP_TRY(hipMemcpy(p->dev.dct, dct.data(), dct.size() * sizeof(double), hipMemcpyHostToDevice));
   return AFX_OK;

@@ -41,9 +41,25 @@ __device__ __forceinline__ void swap16(double& x, double& y) {
   y = __hiloint2double(hi[1], lo[1]);
 }
 
+__device__ __forceinline__ void swap32(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float& x, float& y) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+
 // Sum 16 per-lane values over the wave at once ("transposed" butterfly): on return lane L holds
 // the wave total of a[(L >> 2) & 15].  15 adds + 24 swaps + a few DPP moves instead of 16 x 6 steps.
-__device__ __forceinline__ double wave_sum16(double (&a)[16], int lane) {
+template <typename A>
+__device__ __forceinline__ A wave_sum16(A (&a)[16], int lane) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
     swap32(a[i], a[i + 8]);
@@ -57,13 +73,13 @@ __device__ __forceinline__ double wave_sum16(double (&a)[16], int lane) {
   const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const double keep = b3 ? a[i + 2] : a[i];
-    const double send = b3 ? a[i] : a[i + 2];
+    const A keep = b3 ? a[i + 2] : a[i];
+    const A send = b3 ? a[i] : a[i + 2];
     a[i] = keep + dpp_mov<kDppRor8>(send);
   }
-  const double keep = b2 ? a[1] : a[0];
-  const double send = b2 ? a[0] : a[1];
-  double z = keep + dpp_mov<kDppHalfMirror>(send);
+  const A keep = b2 ? a[1] : a[0];
+  const A send = b2 ? a[0] : a[1];
+  A z = keep + dpp_mov<kDppHalfMirror>(send);
   z += dpp_mov<kDppXor2>(z);
   z += dpp_mov<kDppXor1>(z);
   return z;

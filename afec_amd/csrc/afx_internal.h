@@ -87,7 +87,7 @@ struct FrameArgs {
   const void* t1;    // [4][4][4] complex w64^(m2*(4*jh+jl)), index 16*jh + 4*m2 + jl        (T)
   const void* t2;    // [16][64] complex w1024^(n2*(4*jh+jl+16*j2)), reg=4*j2+jl, lane=16*jh+n2 (T)
   const void* post;  // [16][64] complex w2048^(lane+64r)                             (T)
-  const double* melw;  // [kMelPairs][64]
+  const void* melw;    // [kMelPairs][64] packed mel rows                                  (T)
   const double* dct;   // [14][16]: cos(pi * (n/14) * (m + 0.5)), m < 14
 };
 

@@ -137,8 +137,8 @@ struct LdsMap {
   static constexpr int win = 0;                                                     // [16][64] cx<T>
   static constexpr int t2 = win + (win_global ? 0 : 1024 * (int)sizeof(cx<T>));     // [16][64] cx<T>
   static constexpr int post = t2 + 1024 * (int)sizeof(cx<T>);                       // [POST_ROWS][64] cx<T>
-  static constexpr int melw = post + POST_ROWS * 64 * (int)sizeof(cx<T>);           // [22][64] double
-  static constexpr int dct = melw + kMelPairs * 64 * 8;                             // [14][16] double
+  static constexpr int melw = post + POST_ROWS * 64 * (int)sizeof(cx<T>);           // [22][64] T
+  static constexpr int dct = melw + kMelPairs * 64 * (int)sizeof(T);                // [14][16] double
   static constexpr int xchg = dct + 14 * 16 * 8;                                    // kWaves planes
   static constexpr int plane_bytes = kPlaneSlots * 8;
   static constexpr int total(int waves) { return xchg + waves * plane_bytes; }
@@ -221,18 +221,10 @@ struct Xchg<double> {
 
 // E1 in registers: 2x2 block transposes between a lane bit and a register bit.
 //   swap32(v[g], v[g+8]):  lane bit 5 <-> register bit 3      swap16(v[g], v[g+4]):  lane bit 4 <-> register bit 2
-__device__ __forceinline__ void reg_swap32(float& x, float& y) {
-  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  x = __uint_as_float(r[0]);
-  y = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void reg_swap16(float& x, float& y) {
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  x = __uint_as_float(r[0]);
-  y = __uint_as_float(r[1]);
-}
-__device__ __forceinline__ void reg_swap32(double& x, double& y) { swap32(x, y); }
-__device__ __forceinline__ void reg_swap16(double& x, double& y) { swap16(x, y); }
+template <typename T>
+__device__ __forceinline__ void reg_swap32(T& x, T& y) { swap32(x, y); }
+template <typename T>
+__device__ __forceinline__ void reg_swap16(T& x, T& y) { swap16(x, y); }
 template <typename T>
 __device__ __forceinline__ void transpose_m2_into_registers(cx<T> (&v)[16]) {
 #pragma unroll
@@ -274,7 +266,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   if (!Map::win_global) copy_to_lds(lds_raw + Map::win, a.win, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::t2, a.t2, 1024 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::post, a.post, MR * 64 * (int)sizeof(cx<T>), threadIdx.x, WAVES * 64);
-  copy_to_lds(lds_raw + Map::melw, a.melw, kMelPairs * 64 * 8, threadIdx.x, WAVES * 64);
+  copy_to_lds(lds_raw + Map::melw, a.melw, kMelPairs * 64 * (int)sizeof(T), threadIdx.x, WAVES * 64);
   copy_to_lds(lds_raw + Map::dct, a.dct, 14 * 16 * 8, threadIdx.x, WAVES * 64);
   __syncthreads();
 
@@ -285,7 +277,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   // T1 table [jh][m2][jl] = w64^(m2 (4 jh + jl)): 12 values per lane, the same for the 16 lanes of
   // a row -> one cache line per row from L1
   const cx<T>* const t1 = reinterpret_cast<const cx<T>*>(a.t1) + 16 * (lane >> 4);
-  const double* const melw = reinterpret_cast<const double*>(lds_raw + Map::melw) + lane;
+  const T* const melw = reinterpret_cast<const T*>(lds_raw + Map::melw) + lane;
   const double* const dct = reinterpret_cast<const double*>(lds_raw + Map::dct);
   unsigned char* const plane = lds_raw + Map::xchg + wave * Map::plane_bytes;
   double* const lds_mag = reinterpret_cast<double*>(plane);
@@ -408,15 +400,17 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
           for (int r = 0; r < MR; ++r) sacc += (double)mag[r];
           if (sacc == 1.2345e-300) rec[a.lay.mfcc + (lane & 7)] = sacc;
         } else if (FEAT == kFeatC2 || (a.mask & 1u)) {
-          double e[16];
+          // mel partial sums in the kernel's own precision (the float kernels' magnitudes carry 1e-7
+          // already); the log and the DCT below are always double
+          T e[16];
 #pragma unroll
-          for (int f = 0; f < 16; ++f) e[f] = 0.0;
+          for (int f = 0; f < 16; ++f) e[f] = (T)0;
 #pragma unroll
           for (int r = 0; r < kMelRows; ++r)
 #pragma unroll
             for (int f = 0; f < kNumCep; ++f)
-              if (mel_touches(f, r)) e[f] += (double)mag[r] * melw[64 * mel_pair_index(r, f)];
-          const double tot = wave_sum16(e, lane);  // lane L: filter (L >> 2) & 15
+              if (mel_touches(f, r)) e[f] += mag[r] * melw[64 * mel_pair_index(r, f)];
+          const double tot = (double)wave_sum16(e, lane);  // lane L: filter (L >> 2) & 15
           if (pending == 0) pending_row0 = row;
           if ((lane & 3) == pending) mel_acc = tot;
           if (++pending == 4) {

@@ -507,8 +507,19 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
 
   // chunking: K consecutive frames per wave; enough chunks to fill the chip, long enough to
   // amortise the 2048-sample lead-in of each chunk
-  const int64_t target_waves = (int64_t)plan->cu_count * 16;
-  int K = (int)std::min<int64_t>(32, std::max<int64_t>(4, frames / std::max<int64_t>(1, target_waves)));
+  // K is picked to minimise (rounds of the wave slots) x (frames per chunk + lead-in): long chunks for
+  // big batches, one round of short chunks when the batch barely fills the chip
+  const int64_t slots = (int64_t)plan->cu_count * afx::frames_waves_per_block(mask);
+  int K = 32;
+  {
+    double best = 1e300;
+    for (int k = 1; k <= 32; ++k) {
+      int64_t nchunks = 0;
+      for (int i = 0; i < n_bufs; ++i) nchunks += (b->frame_offset[i + 1] - b->frame_offset[i] + k - 1) / k;
+      const double cost = (double)((nchunks + slots - 1) / slots) * (k + 0.5);
+      if (cost < best - 1e-9 || (std::fabs(cost - best) <= 1e-9 && k > K)) { best = cost; K = k; }
+    }
+  }
   std::vector<afx::Chunk> chunks;
   for (int i = 0; i < n_bufs; ++i) {
     const int64_t f = b->frame_offset[i + 1] - b->frame_offset[i];

@@ -186,6 +186,16 @@ def main():
         dist.barrier()
     seconds, frames_all = reduce_max_sum(dist, t1 - t0, frames)
 
+    # the literal BASELINE configs[1] shape as a secondary number: ONE resident buffer of 10 000 frames
+    single = None
+    if rank == 0 and args.workload == "c2" and args.mask == "c2":
+        one = plan.batch(make_buffers(1, 4321), mask)
+        for _ in range(5):
+            one.run()
+        one.sync()
+        single = FRAMES_PER_BUFFER / (one.run_timed(50) / 50 * 1e-3)
+        one.close()
+
     if rank == 0:
         launch_ms = ev_ms / args.steps
         achieved = bytes_per_frame * frames / (launch_ms * 1e-3) / 1e9
@@ -210,6 +220,7 @@ def main():
                              if args.mask == "c2" else f"{args.mask} descriptor set, {args.buffers} x {FRAMES_PER_BUFFER} frames"),
                 "frames_per_gpu_per_step": frames,
                 "files_per_gpu_per_step": n_bufs,
+                "single_10k_frame_buffer_frames_per_s": single,
                 "pcm": "f32 resident in HBM",
                 "parallelism": f"replicas x{world} (buffers sharded, no collective)",
             },

@@ -44,6 +44,7 @@ EXPORTS = [
     "afx_extract_batch", "afx_batch_create", "afx_batch_total_frames", "afx_batch_run",
     "afx_batch_sync", "afx_batch_run_timed", "afx_batch_fetch", "afx_batch_fetch_statistics", "afx_batch_destroy",
     "afx_algorithmic_bytes_per_frame", "afx_batch_create_from_raw", "afx_batch_fetch_samples",
+    "afx_host_alloc", "afx_host_free",
 ]
 RAW_I16, RAW_I24, RAW_F32 = 0, 1, 2
 
@@ -159,10 +160,31 @@ def load_library():
     L.afx_batch_destroy.restype = None
     L.afx_batch_create_from_raw.argtypes = [vp, ctypes.POINTER(_Raw), i32, u32, ctypes.POINTER(vp), ctypes.POINTER(_LoadInfo)]
     L.afx_batch_fetch_samples.argtypes = [vp, i32, vp, i64]
+    L.afx_host_alloc.restype = vp
+    L.afx_host_alloc.argtypes = [i64]
+    L.afx_host_free.argtypes = [vp]
+    L.afx_host_free.restype = None
     L.afx_algorithmic_bytes_per_frame.restype = i64
     L.afx_algorithmic_bytes_per_frame.argtypes = [vp, u32, i32]
     _lib = L
     return L
+
+
+def pinned_array(shape, dtype):
+    """numpy array in page-locked host memory (afx_host_alloc); keep the returned owner alive."""
+    L = load_library()
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    p = L.afx_host_alloc(max(n, 1))
+    if not p:
+        raise MemoryError("afx_host_alloc failed")
+
+    class _Owner:
+        def __del__(self, p=p, L=L):
+            L.afx_host_free(p)
+
+    buf = (ctypes.c_char * max(n, 1)).from_address(p)
+    arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+    return arr, _Owner()
 
 
 def _check(L, st):

@@ -873,6 +873,15 @@ void afx_batch_destroy(afx_batch* b) {
   delete b;
 }
 
+void* afx_host_alloc(int64_t bytes) {
+  void* p = nullptr;
+  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+  return p;
+}
+void afx_host_free(void* p) {
+  if (p) hipHostFree(p);
+}
+
 int afx_extract_batch(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask, afx_out* out) {
   if (!out) return fail(AFX_ERR_INVALID_ARG, "null output");
   afx_batch* b = nullptr;

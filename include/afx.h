@@ -226,6 +226,11 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
 /* the normalised samples of buffer `buf` (its analysed prefix) for the CPU-resident neighbours */
 int afx_batch_fetch_samples(afx_batch* batch, int32_t buf, double* dst, int64_t n);
 
+/* Page-locked host memory for PCM and result arrays: transfers from / to such buffers run at the
+ * host link's rate (pageable memory is staged by the runtime at a fraction of it). */
+void* afx_host_alloc(int64_t bytes);
+void afx_host_free(void* p);
+
 /* static facts for roofline accounting (bytes the algorithm must move per frame for `mask`) */
 int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int32_t pcm_dtype);
 

@@ -12,3 +12,18 @@ for secs, nrep in ((2.0, 200), (20.0, 50)):
             plan.extract([x], mask)
         dt = (time.perf_counter() - t0) / nrep
         print(f"one file of {secs:4.1f} s, {name:4s}: {dt*1e3:7.3f} ms per afx_extract_batch call  ({1/dt:7.0f} files/s)")
+
+# PCIe-inclusive rate of a 10k-frame buffer from pageable and from page-locked host memory
+from afec_amd.capi import pinned_array
+plan0 = afx.Plan(max_analysis_ms=0)
+n = 2048 + 1024 * 9999
+x = rng.uniform(-1, 1, n).astype(np.float32)
+xp, owner = pinned_array((n,), np.float32)
+xp[:] = x
+for name, buf in (("pageable", x), ("pinned", xp)):
+    plan0.extract([buf], afx.D_C2)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        plan0.extract([buf], afx.D_C2)
+    dt = (time.perf_counter() - t0) / 10
+    print(f"10k-frame buffer from {name:8s} host memory: {dt*1e3:6.2f} ms per call = {10000/dt/1e6:5.2f} M frames/s incl. H2D/D2H")

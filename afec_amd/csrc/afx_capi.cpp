@@ -884,13 +884,60 @@ void afx_host_free(void* p) {
 
 int afx_extract_batch(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask, afx_out* out) {
   if (!out) return fail(AFX_ERR_INVALID_ARG, "null output");
-  afx_batch* b = nullptr;
-  int st = afx_batch_create(plan, bufs, n_bufs, mask, &b);
-  if (st != AFX_OK) return st;
-  st = afx_batch_run(b);
-  if (st == AFX_OK) st = afx_batch_fetch(b, out);
-  afx_batch_destroy(b);
-  return st;
+  if (!plan || n_bufs < 0 || (n_bufs > 0 && !bufs)) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  // Large calls (a crawler handing over 10^5 files) are cut into groups of buffers of at most
+  // kSplitFrames frames so that the device workspace (8 KiB of magnitudes per frame when the band
+  // descriptors are on) stays bounded; results land at the right rows of the caller's arrays.
+  constexpr int64_t kSplitFrames = 1 << 19;
+  int64_t total = 0;
+  for (int i = 0; i < n_bufs; ++i) total += (bufs[i].n_samples > 0) ? num_frames(plan, bufs[i].n_samples) : 0;
+  if (total <= kSplitFrames || n_bufs <= 1) {
+    afx_batch* b = nullptr;
+    int st = afx_batch_create(plan, bufs, n_bufs, mask, &b);
+    if (st != AFX_OK) return st;
+    st = afx_batch_run(b);
+    if (st == AFX_OK) st = afx_batch_fetch(b, out);
+    afx_batch_destroy(b);
+    return st;
+  }
+  struct Col { double* afx_out::*field; int width; };
+  static const Col cols[] = {
+      {&afx_out::mfcc, 14}, {&afx_out::spectral_rms, 1}, {&afx_out::spectral_centroid, 1}, {&afx_out::spectral_spread, 1},
+      {&afx_out::spectral_skewness, 1}, {&afx_out::spectral_kurtosis, 1}, {&afx_out::spectral_rolloff, 1},
+      {&afx_out::spectral_flatness, 1}, {&afx_out::spectral_flux, 1}, {&afx_out::spectrum_bands, 28}, {&afx_out::sub_rms, 14},
+      {&afx_out::sub_flatness, 14}, {&afx_out::sub_flux, 14}, {&afx_out::sub_complexity, 14}, {&afx_out::sub_contrast, 14},
+      {&afx_out::spectral_contrast, 1}, {&afx_out::amplitude_peak, 1}, {&afx_out::amplitude_rms, 1}, {&afx_out::magnitude, 1024}};
+  int64_t row0 = 0;
+  int32_t first = 0;
+  if (out->frame_offset) out->frame_offset[0] = 0;
+  while (first < n_bufs) {
+    int32_t last = first;
+    int64_t group = 0;
+    while (last < n_bufs) {
+      const int64_t f = (bufs[last].n_samples > 0) ? num_frames(plan, bufs[last].n_samples) : 0;
+      if (last > first && group + f > kSplitFrames) break;
+      group += f;
+      ++last;
+    }
+    afx_out part = *out;
+    for (const Col& c : cols)
+      if (out->*(c.field)) part.*(c.field) = out->*(c.field) + row0 * c.width;
+    std::vector<int64_t> off((size_t)(last - first) + 1);
+    part.frame_offset = off.data();
+    part.buf_status = out->buf_status ? out->buf_status + first : nullptr;
+    afx_batch* b = nullptr;
+    int st = afx_batch_create(plan, bufs + first, last - first, mask, &b);
+    if (st != AFX_OK) return st;
+    st = afx_batch_run(b);
+    if (st == AFX_OK) st = afx_batch_fetch(b, &part);
+    afx_batch_destroy(b);
+    if (st != AFX_OK) return st;
+    if (out->frame_offset)
+      for (int32_t i = first; i < last; ++i) out->frame_offset[i + 1] = row0 + off[(size_t)(i - first) + 1];
+    row0 += off.back();
+    first = last;
+  }
+  return AFX_OK;
 }
 
 }  // extern "C"

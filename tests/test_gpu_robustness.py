@@ -92,3 +92,24 @@ def test_pcie_inclusive_one_shot_rate_is_reported():
     print(f"one-shot afx_extract_batch, 10k frames incl. H2D/D2H and allocation: {rate / 1e6:.2f} M frames/s")
     assert rate > 1e5
     plan.close()
+
+
+def test_large_call_is_split_internally_and_matches_small_calls():
+    """afx_extract_batch cuts calls of more than 2^19 frames into groups of buffers."""
+    rng = np.random.default_rng(44)
+    base = [rng.uniform(-1, 1, 2048 + 1024 * int(n)).astype(np.float32) for n in (700, 1, 859, 300, 0, 512)]
+    bufs = [base[i % len(base)] for i in range(1400)] + [np.zeros(10, np.float32)]   # ~550k frames
+    plan = afx.Plan()
+    mask = afx.D_MFCC | afx.D_SPECTRAL_FLUX | afx.D_SPECTRAL_ROLLOFF
+    big = plan.extract(bufs, mask)
+    ref = plan.extract(base, mask)
+    assert big["frame_offset"][-1] > (1 << 19)
+    assert big["buf_status"].tolist() == [0] * len(bufs)
+    roff = ref["frame_offset"]
+    for i in (0, 1, 5, 6, 700, 1393, 1399):
+        j = i % len(base)
+        a, b = big["frame_offset"][i], big["frame_offset"][i + 1]
+        assert b - a == roff[j + 1] - roff[j]
+        for k in ("mfcc", "spectral_flux", "spectral_rolloff"):
+            np.testing.assert_array_equal(big[k][a:b], ref[k][roff[j]:roff[j + 1]])
+    plan.close()

@@ -495,6 +495,188 @@ int64_t afx_oracle_run_mfcc(const afx_oracle* o, const double* x, int64_t n_samp
   return frames;
 }
 
+/* ---- stateful neighbours ---------------------------------------------------- */
+
+/* TStatistics::Peaks, Stat.cpp:140-232: boundary peaks, interior peaks after a strict climb, plateaus
+ * report their middle bin and their first value, everything strictly above the threshold. */
+int afx_oracle_peaks(const double* a, int n, double thr, int* bins, double* vals) {
+  int count = 0, i = 0, j;
+  if (n <= 2) return 0;
+  if (a[0] > a[1] && a[0] > thr) { bins[count] = 0; vals[count++] = a[0]; }
+  for (;;) {
+    while (i + 1 < n - 1 && a[i] >= a[i + 1]) ++i;
+    while (i + 1 < n - 1 && a[i] < a[i + 1]) ++i;
+    j = i;
+    while (j + 1 < n - 1 && a[j] == a[j + 1]) ++j;
+    if (j + 1 < n - 1 && a[j + 1] < a[j] && a[j] > thr) {
+      bins[count] = (j != i) ? (i + j) / 2 : j;
+      vals[count++] = (j != i) ? a[i] : a[j];
+    }
+    i = j;
+    if (i + 1 >= n - 1) {
+      if (i == n - 2 && a[i - 1] < a[i] && a[i + 1] < a[i] && a[i] > thr) { bins[count] = i; vals[count++] = a[i]; }
+      break;
+    }
+  }
+  if (a[n - 1] > a[n - 2] && a[n - 1] > thr) { bins[count] = n - 1; vals[count++] = a[n - 1]; }
+  return count;
+}
+
+/* aubio_silence_detection, Aubio/Dist/src/mathutils.c:345-357, 605-615 */
+static int au_silent(const double* x, int n, double threshold_db) {
+  double e = 0.0;
+  int i;
+  for (i = 0; i < n; ++i) e += x[i] * x[i];
+  return 10.0 * log10(e / n) < threshold_db;
+}
+
+/* CalcAmplitudeEnvelope, SA.cpp:1787-1804; TEnvelopeDetector kFast, Envelopes.cpp:55-70, Envelopes.inl:14-18
+ * (MUnDenormalize is empty on x64, InlineMath.h:36-53) */
+static double hop_envelope(const afx_oracle* o, const double* x) {
+  const double coef = pow(0.01, 1000.0 / (8.0 * (double)o->sample_rate));
+  double env = 0.0, top = 0.0;
+  int i;
+  for (i = 0; i < o->hop; ++i) {
+    const double in = fabs(x[i]);
+    env = in + coef * (env - in);
+    if (env > top) top = env;
+  }
+  return top;
+}
+
+/* aubio_pitchyinfast_do, Aubio/Dist/src/pitch/pitchyinfast.c:81-170, with r_t(tau) = sum_{j<W} x[j] x[j+tau]
+ * summed directly instead of through aubio's FFT; then aubio_pitch_do_yinfast + aubio_pitch_do,
+ * pitch.c:399-406, 450-462.  yin[] is W = fft/2 long; returns the frequency.
+ * QUIRK (part of the reference's results, reproduced): with aubio's Ooura back end -- the one the
+ * reference builds on Linux (Aubio/Linux/build.sh: no FFTW, no IPP) and on macOS (Aubio/Mac/config.h) --
+ * aubio_fft_rdo_complex rescales the inverse rdft by 1/N where Ooura needs 2/N (spectral/fft.c:464-476),
+ * so the correlation comes back exactly halved and the "difference function" is
+ * sqdiff(tau) - r_t(tau), not sqdiff(tau) - 2 r_t(tau). */
+static double yinfast_pitch(const afx_oracle* o, const double* x, double tol, double* yin, double* confidence) {
+  const int B = o->fft, W = B / 2;
+  int tau, j, period_i = -1;
+  double s0 = 0.0, run, tmp2 = 0.0, period;
+  for (j = 0; j < W; ++j) s0 += x[j] * x[j];
+  run = s0;
+  for (tau = 0; tau < W; ++tau) {
+    double r = 0.0;
+    if (tau > 0) { run -= x[tau - 1] * x[tau - 1]; run += x[W + tau - 1] * x[W + tau - 1]; }
+    for (j = 0; j < W; ++j) r += x[j] * x[j + tau];
+    yin[tau] = (run + s0) - 2.0 * (0.5 * r);
+  }
+  yin[0] = 1.0;
+  for (tau = 1; tau < W; ++tau) {
+    tmp2 += yin[tau];
+    if (tmp2 != 0) yin[tau] *= tau / tmp2; else yin[tau] = 1.0;
+    if (tau > 4 && yin[tau - 3] < tol && yin[tau - 3] < yin[tau - 2]) { period_i = tau - 3; break; }
+  }
+  if (period_i < 0) { /* fvec_min_elem, mathutils.c:250-265: the last of equal minima */
+    double m = yin[0];
+    period_i = 0;
+    for (j = 0; j < W; ++j) if (!(m < yin[j])) { period_i = j; m = yin[j]; }
+  }
+  /* fvec_quadratic_peak_pos, mathutils.c:494-506 */
+  if (period_i == 0 || period_i == W - 1) period = period_i;
+  else {
+    const double a = yin[period_i - 1], b = yin[period_i], c = yin[period_i + 1];
+    period = period_i + 0.5 * (a - c) / (a - 2.0 * b + c);
+  }
+  *confidence = 1.0 - yin[(unsigned)period];   /* peak_pos is a uint_t, pitchyinfast.c:38, 160-169 */
+  {
+    double f = (period > 0) ? o->sample_rate / (period + 0.) : 0.0;
+    if (au_silent(x, B, -48.0)) f = 0.0;
+    return f;
+  }
+}
+
+/* CalcAutoCorrelation, SA.cpp:2312-2398; TAutocorrelation::Calc, Autocorrelation.cpp:62-106 */
+static double auto_correlation(const afx_oracle* o, const double* x, int64_t remaining_in) {
+  const int min_period = ms_to_samples(o->sample_rate, 0.8f);
+  const int seek_width = ms_to_samples(o->sample_rate, 12.0f);
+  const int max_seek = o->fft / 2;
+  int remaining = (int)remaining_in, i, j, seek_off, period, width;
+  const double* start = x; const double* end;
+  double best = 0.0, r0 = 0.0;
+  for (i = 0; i < (remaining < max_seek ? remaining : max_seek) - 1; ++i)
+    if (x[i + 1] > x[i]) { start = x + i; remaining -= i; break; }
+  seek_off = remaining < min_period ? remaining : min_period;
+  end = start + seek_off;
+  for (i = 0; i < ((remaining - seek_off) < max_seek ? (remaining - seek_off) : max_seek) - 1; ++i)
+    if (start[seek_off + i + 1] > start[seek_off + i]) { end = start + seek_off + i; break; }
+  period = (int)(end - start);
+  if (!remaining || period >= remaining) return 0.0;
+  width = remaining < seek_width ? remaining : seek_width;
+  for (j = 0; j < width; ++j) r0 += start[j] * start[j];
+  for (i = period / 2; i < width; ++i) {
+    double r = 0.0;
+    for (j = 0; j < width - i; ++j) r += start[j] * start[j + i];
+    if (r0 != 0) r /= r0;
+    if (r > best) best = r;
+  }
+  return best;
+}
+
+int64_t afx_oracle_run_neighbours(const afx_oracle* o, const double* x, int64_t n_samples, int apply_cap,
+                                  double* records) {
+  const int64_t frames = afx_oracle_num_frames(o, n_samples, apply_cap);
+  const int n = o->fft, half = n / 2;
+  double* re = (double*)malloc(sizeof(double) * n * 8);
+  double* im = re + n; double* mag = im + n; double* wh = mag + n; double* pk = wh + n;
+  double* follow = pk + n; double* yin = follow + n; double* pval = yin + n;
+  int* pbin = (int*)malloc(sizeof(int) * n);
+  /* new_aubio_spectral_whitening + set_relax_time(22), awhitening.c:53-87, SA.cpp:805-809:
+   * r_decay = pow(0.001, (hop / (float)rate) / relax), floor 1e-4, followers start at the floor */
+  const double decay = pow(0.001, (double)((float)o->hop / (float)o->sample_rate) / 22.0);
+  const double floor_v = 1.e-4;
+  int64_t f;
+  int i;
+  for (i = 0; i <= half; ++i) follow[i] = floor_v;
+  for (f = 0; f < frames; ++f) {
+    const double* fx = x + f * o->hop;
+    double* out = records + (size_t)f * AFXN_RECORD;
+    double mx = 0.0, f0, conf, safe = 0.0;
+    int npk, silent, count = 0;
+    stft_frame(o, fx, re, im, mag);
+    /* aubio_spectral_whitening_do, awhitening.c:41-51 (bins 0..fft/2, the last one is the cleared upper half) */
+    for (i = 0; i <= half; ++i) {
+      double t = decay * follow[i];
+      if (t < floor_v) t = floor_v;
+      follow[i] = mag[i] > t ? mag[i] : t;
+      wh[i] = mag[i] / follow[i];
+    }
+    memcpy(out + AFXN_WHITE, wh, sizeof(double) * half);
+    /* SCreatePeakSpectrum, SA.cpp:95-123, threshold MPeakThreshold = 0.25 of the maximum */
+    mx = afx_oracle_max(wh, half);
+    npk = afx_oracle_peaks(wh, half, 0.25 * mx, pbin, pval);
+    memset(pk, 0, sizeof(double) * n);
+    for (i = 0; i < npk; ++i) pk[pbin[i]] = pval[i];
+    silent = au_silent(fx, o->hop, -48.0);               /* SA.cpp:865-868 */
+    out[AFXN_SILENCE] = silent ? 1.0 : 0.0;
+    out[AFXN_ENVELOPE] = hop_envelope(o, fx);
+    /* SA.cpp:876-917 */
+    f0 = yinfast_pitch(o, fx, 0.75, yin, &conf);
+    conf = conf / 0.25;
+    conf = conf < 0.0 ? 0.0 : (conf > 1.0 ? 1.0 : conf);
+    if (f0 > 0.0 && conf > 0.2) safe = f0;
+    else if (!silent) {
+      const double cb = afx_oracle_centroid(mag, half);
+      safe = (double)o->sample_rate / (double)o->fft * (cb > 0.0 ? cb : 0.0);
+    }
+    out[AFXN_F0] = f0; out[AFXN_F0_CONF] = conf; out[AFXN_F0_FAILSAFE] = safe;
+    out[AFXN_AUTOCORR] = auto_correlation(o, fx, n_samples - f * o->hop);   /* SA.cpp:943-944 */
+    /* CalcSpectralComplexity, SA.cpp:1937-1947: non-zero bins of the peak spectrum in the analysis range */
+    for (i = 0; i < o->bin_count; ++i) count += pk[o->first_bin + i] != 0.0;
+    out[AFXN_COMPLEXITY] = count;
+    /* xtract_spectral_inharmonicity / xtract_harmonic_spectrum / xtract_tristimulus_* read their
+     * frequencies from the upper half of the fft-sized buffer (Xt/src/scalar.c:304-326, 638-661,
+     * vector.c:540-579), which SA.cpp:844-845 clears: every partial sits at 0 Hz, the harmonic spectrum
+     * is empty, and all four descriptors are 0 (0/0 -> NaN -> 0 for inharmonicity, SA.cpp:1963-1964). */
+    out[AFXN_INHARM] = out[AFXN_TRI1] = out[AFXN_TRI2] = out[AFXN_TRI3] = 0.0;
+  }
+  free(re); free(pbin);
+  return frames;
+}
+
 /* ---- LoadSample (SA:484-718), decoded interleaved PCM in, normalised mono double out ---- */
 
 static float to_16bit_float(const void* pcm, int format, int64_t idx) {

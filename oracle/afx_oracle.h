@@ -42,6 +42,20 @@ int64_t afx_oracle_run(const afx_oracle*, const double* x, int64_t n_samples, in
  * mfcc = [frames][14]; returns frames */
 int64_t afx_oracle_run_mfcc(const afx_oracle*, const double* x, int64_t n_samples, double* mfcc);
 
+/* ---- stateful neighbours of the loop (SampleAnalyser.cpp:849-927, 942-964) ----
+ * PINNED against oracle/_ref/ref_driver `neighbours`, which runs the reference's own aubio
+ * (whitening, silence, yinfast pitch), TEnvelopeDetector, TAutocorrelation and LibXtract objects.
+ * record = silence, envelope, f0, f0 confidence, fail-safe f0, autocorrelation, spectral complexity,
+ * inharmonicity, tristimulus 1..3, whitened spectrum [fft/2]. */
+enum {
+  AFXN_SILENCE = 0, AFXN_ENVELOPE, AFXN_F0, AFXN_F0_CONF, AFXN_F0_FAILSAFE, AFXN_AUTOCORR,
+  AFXN_COMPLEXITY, AFXN_INHARM, AFXN_TRI1, AFXN_TRI2, AFXN_TRI3, AFXN_WHITE, AFXN_RECORD = AFXN_WHITE + 1024
+};
+int64_t afx_oracle_run_neighbours(const afx_oracle*, const double* x, int64_t n_samples, int apply_cap,
+                                  double* records);
+/* TStatistics::Peaks (Statistics.cpp:140-232): bins/vals sized n; returns the number of peaks */
+int afx_oracle_peaks(const double* x, int n, double threshold, int* bins, double* vals);
+
 /* TStatistics restatements exposed for the reference's own known-answer tests */
 double afx_oracle_sum(const double* x, int n);
 double afx_oracle_mean(const double* x, int n);

@@ -14,6 +14,7 @@
 // Usage:
 //   ref_driver tables  <out.bin>                 window[2048] + mel[14][1024] doubles
 //   ref_driver frames  <in.bin> <out.bin> [cap]  per-frame records (see kRecord)
+//   ref_driver neighbours <in.bin> <out.bin> [cap]  per-frame records of the stateful neighbours (kNeigh)
 //   ref_driver time    <n_frames> <seed>         C2 subset timing (STFT + MFCC), prints frames/s
 //
 // in.bin : int64 n_bufs ; per buffer: int64 n_samples, double[n_samples]
@@ -35,6 +36,11 @@ extern "C" {
 #include "AudioTypes/Source/OouraFFT8g.h"
 #include "AudioTypes/Export/AudioMath.h"
 #include "FeatureExtraction/Export/Statistics.h"
+#include "AudioTypes/Export/Envelopes.h"
+#include "FeatureExtraction/Source/Autocorrelation.h"
+extern "C" {
+#include "aubio.h"   // 3rdParty/Aubio/Dist/src, smpl_t = double (HAVE_AUBIO_DOUBLE, as Export/Aubio.h sets it)
+}
 
 static const int kSampleRate = 44100, kFft = 2048, kHop = 1024;
 static const int kNumCep = 14, kNumBands = 28, kNumSub = 14;
@@ -241,6 +247,161 @@ static int CmdFrames(const char* in, const char* outp, bool cap) {
   return 0;
 }
 
+// ---- the stateful neighbours of the loop: SampleAnalyser.cpp:849-927, 942-964 ----
+// record: silence, envelope, f0, f0 confidence, fail-safe f0, autocorrelation, spectral complexity,
+// inharmonicity, tristimulus 1..3, then the whitened spectrum [1024] (stage debugging)
+enum { nSilence = 0, nEnvelope, nF0, nF0Conf, nF0FailSafe, nAutoCorr, nComplexity, nInharm, nTri1, nTri2, nTri3,
+       nWhite, kNeigh = nWhite + 1024 };
+
+// TStatistics::Peaks (Statistics.cpp:140-232) returns a TList, which needs CoreTypes' allocator and does not
+// link here; its scan is restated (pinned by the reference's own vector, TestStatistics.cpp:16-33, in
+// `ref_driver peakstest`).  Writes value at the reported bin for every peak above the threshold.
+static int PeakScan(const double* a, int n, double thr, int* bins, double* vals) {
+  int count = 0;
+  if (n <= 2) return 0;
+  if (a[0] > a[1] && a[0] > thr) { bins[count] = 0; vals[count++] = a[0]; }
+  int i = 0;
+  for (;;) {
+    while (i + 1 < n - 1 && a[i] >= a[i + 1]) ++i;      // descend
+    while (i + 1 < n - 1 && a[i] < a[i + 1]) ++i;       // climb
+    int j = i;
+    while (j + 1 < n - 1 && a[j] == a[j + 1]) ++j;      // plateau
+    if (j + 1 < n - 1 && a[j + 1] < a[j] && a[j] > thr) {
+      bins[count] = (j != i) ? (i + j) / 2 : j;
+      vals[count++] = (j != i) ? a[i] : a[j];
+    }
+    i = j;
+    if (i + 1 >= n - 1) {
+      if (i == n - 2 && a[i - 1] < a[i] && a[i + 1] < a[i] && a[i] > thr) { bins[count] = i; vals[count++] = a[i]; }
+      break;
+    }
+  }
+  if (a[n - 1] > a[n - 2] && a[n - 1] > thr) { bins[count] = n - 1; vals[count++] = a[n - 1]; }
+  return count;
+}
+
+static int CmdPeaksTest() {
+  const double seq[] = { 1, 2, 2, 2, 0, 5, 6 };
+  int bins[8]; double vals[8];
+  for (double thr : { 0.0, 2.0 }) {
+    const int c = PeakScan(seq, 7, thr, bins, vals);
+    printf("thr=%g:", thr);
+    for (int i = 0; i < c; ++i) printf(" (%d,%g)", bins[i], vals[i]);
+    printf("\n");
+  }
+  return 0;
+}
+
+// CalcAutoCorrelation (SampleAnalyser.cpp:2312-2398): member body restated, TAutocorrelation::Calc is the
+// reference's object
+static double AutoCorrelation(const double* x, int remaining) {
+  const int min_period = TAudioMath::MsToSamples(kSampleRate, 0.8f);
+  const int seek_width = TAudioMath::MsToSamples(kSampleRate, 12.0f);
+  const int max_seek = kFft / 2;
+  const double* start = x;
+  for (int i = 0; i < std::min(remaining, max_seek) - 1; ++i)
+    if (x[i + 1] > x[i]) { start = x + i; remaining -= i; break; }
+  const int seek_off = std::min(remaining, min_period);
+  const double* end = start + seek_off;
+  for (int i = 0; i < std::min(remaining - seek_off, max_seek) - 1; ++i)
+    if (start[seek_off + i + 1] > start[seek_off + i]) { end = start + seek_off + i; break; }
+  const int period = (int)(end - start);
+  if (!remaining || period >= remaining) return 0.0;
+  const int width = std::min(remaining, seek_width);
+  std::vector<double> r(width, 0.0);
+  TAutocorrelation::Calc(start, width, r.data(), width);
+  double best = 0.0;
+  for (int i = period / 2; i < width; ++i) best = std::max(best, r[i]);
+  return best;
+}
+
+static int CmdNeighbours(const char* in, const char* outp, bool cap) {
+  TRef R;
+  FILE* fi = fopen(in, "rb"); if (!fi) return 1;
+  int64_t nb = 0; if (fread(&nb, 8, 1, fi) != 1) return 1;
+  std::vector<double> recs;
+  int64_t total = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    int64_t ns = 0; if (fread(&ns, 8, 1, fi) != 1) return 1;
+    std::vector<double> x((size_t)ns);
+    if (ns && fread(x.data(), 8, (size_t)ns, fi) != (size_t)ns) return 1;
+    int64_t len = ns;
+    if (cap) len = std::min<int64_t>(len, TAudioMath::MsToSamples(kSampleRate, 1000 * 20));
+    // SampleAnalyser.cpp:798-809
+    aubio_pitch_t* pitch = new_aubio_pitch("yinfast", kFft, kHop, kSampleRate);
+    aubio_pitch_set_tolerance(pitch, 0.75);
+    aubio_pitch_set_silence(pitch, -48.0);
+    aubio_pitch_set_unit(pitch, "freq");
+    aubio_spectral_whitening_t* white = new_aubio_spectral_whitening(kFft, kHop, kSampleRate);
+    aubio_spectral_whitening_set_relax_time(white, 22);
+    std::vector<double> mag(kFft, 0.0), wh(kFft, 0.0), peak(kFft, 0.0), harm(kFft, 0.0);
+    std::vector<int> pbin(kFft); std::vector<double> pval(kFft);
+    for (int64_t n = 0; (n + kFft - 1) < len; n += kHop) {
+      recs.resize((size_t)(total + 1) * kNeigh);
+      double* out = recs.data() + (size_t)total * kNeigh;
+      R.Stft(x.data() + n, mag.data());
+      fvec_t hop; hop.length = kHop; hop.data = x.data() + n;
+      fvec_t frame; frame.length = kFft; frame.data = x.data() + n;
+      // whitened spectrum (849-858)
+      wh = mag;
+      cvec_t grain; grain.length = kFft / 2; grain.norm = wh.data(); grain.phas = NULL;
+      aubio_spectral_whitening_do(white, &grain);
+      memcpy(out + nWhite, wh.data(), 1024 * sizeof(double));
+      // peak spectrum (95-123, 861-862)
+      const double thr = 0.25 * TStatistics::Max(wh.data(), kFft / 2);
+      const int npk = PeakScan(wh.data(), kFft / 2, thr, pbin.data(), pval.data());
+      peak = wh;
+      for (int i = 0; i < kFft / 2; ++i) peak[i] = 0.0;
+      for (int i = 0; i < npk; ++i) peak[pbin[i]] = pval[i];
+      // silence (865-868)
+      const bool silent = aubio_silence_detection(&hop, -48.0) == 1;
+      out[nSilence] = silent ? 1.0 : 0.0;
+      // envelope (1787-1804)
+      {
+        TEnvelopeDetector det(TEnvelopeDetector::kFast, 8.0, kSampleRate);
+        double env = 0.0, top = 0.0;
+        for (int i = 0; i < kHop; ++i) { det.Run(TMathT<double>::Abs(hop.data[i]), env); top = MMax(top, env); }
+        out[nEnvelope] = top;
+      }
+      // F0 (876-917)
+      double f0 = 0.0, conf = 0.0, safe = 0.0;
+      {
+        fvec_t po; po.length = 1; po.data = &f0;
+        aubio_pitch_do(pitch, &frame, &po);
+        conf = MClip(aubio_pitch_get_confidence(pitch) / 0.25, 0.0, 1.0);
+        if (f0 > 0.0 && conf > 0.2) safe = f0;
+        else if (!silent) {
+          const double cb = TStatistics::Centroid(mag.data(), kFft / 2);
+          safe = (double)kSampleRate / (double)kFft * MMax(cb, 0.0);
+        }
+      }
+      out[nF0] = f0; out[nF0Conf] = conf; out[nF0FailSafe] = safe;
+      // harmonic spectrum (920-927)
+      { double a[4] = { 0 }; a[0] = safe; a[1] = 0.5; xtract_harmonic_spectrum(peak.data(), kFft, a, harm.data()); }
+      // autocorrelation (943-944)
+      out[nAutoCorr] = AutoCorrelation(x.data() + n, (int)(ns - n));
+      // complexity (1937-1947), inharmonicity (1951-1971), tristimulus (1975-2003)
+      { double c = 0.0; xtract_nonzero_count(peak.data() + R.mFirstBin, R.mBinCount, NULL, &c); out[nComplexity] = NanToZero(c); }
+      out[nInharm] = out[nTri1] = out[nTri2] = out[nTri3] = 0.0;
+      if (safe > 0.0 && conf > 0.0) {
+        double v = 0.0; xtract_spectral_inharmonicity(peak.data(), kFft, &safe, &v); out[nInharm] = NanToZero(v);
+        xtract_tristimulus_1(harm.data(), kFft, &safe, &out[nTri1]);
+        xtract_tristimulus_2(harm.data(), kFft, &safe, &out[nTri2]);
+        xtract_tristimulus_3(harm.data(), kFft, &safe, &out[nTri3]);
+      }
+      ++total;
+    }
+    del_aubio_pitch(pitch);
+    del_aubio_spectral_whitening(white);
+  }
+  fclose(fi);
+  FILE* fo = fopen(outp, "wb"); if (!fo) return 1;
+  fwrite(&total, 8, 1, fo);
+  fwrite(recs.data(), 8, recs.size(), fo);
+  fclose(fo);
+  return 0;
+}
+
 // C2 subset timing: window -> FFT -> magnitude -> xtract_mfcc on uniform noise.
 static int CmdTime(int64_t nframes, unsigned seed) {
   TRef R;
@@ -266,7 +427,9 @@ static int CmdTime(int64_t nframes, unsigned seed) {
 int main(int argc, char** argv) {
   if (argc >= 3 && !strcmp(argv[1], "tables")) return CmdTables(argv[2]);
   if (argc >= 4 && !strcmp(argv[1], "frames")) return CmdFrames(argv[2], argv[3], argc >= 5 && atoi(argv[4]) != 0);
+  if (argc >= 4 && !strcmp(argv[1], "neighbours")) return CmdNeighbours(argv[2], argv[3], argc >= 5 && atoi(argv[4]) != 0);
+  if (argc >= 2 && !strcmp(argv[1], "peakstest")) return CmdPeaksTest();
   if (argc >= 4 && !strcmp(argv[1], "time")) return CmdTime(atoll(argv[2]), (unsigned)atoi(argv[3]));
-  fprintf(stderr, "usage: ref_driver tables|frames|time ...\n");
+  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|peakstest|time ...\n");
   return 2;
 }

@@ -25,6 +25,14 @@ FIELDS = {
     "amplitude_rms": (1146, 1147),
 }
 
+NEIGH_RECORD = 1035
+# neighbours record layout (oracle/afx_oracle.h AFXN_*)
+NEIGH_FIELDS = {
+    "amplitude_silence": 0, "amplitude_envelope": 1, "f0": 2, "f0_confidence": 3, "failsafe_f0": 4,
+    "auto_correlation": 5, "spectral_complexity": 6, "spectral_inharmonicity": 7,
+    "tristimulus1": 8, "tristimulus2": 9, "tristimulus3": 10,
+}
+
 _lib = None
 
 
@@ -51,6 +59,12 @@ def lib():
         L.afx_oracle_run.restype = ctypes.c_int64
         L.afx_oracle_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
                                      ctypes.c_void_p]
+        L.afx_oracle_run_neighbours.restype = ctypes.c_int64
+        L.afx_oracle_run_neighbours.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                                ctypes.c_void_p]
+        L.afx_oracle_peaks.restype = ctypes.c_int
+        L.afx_oracle_peaks.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
+                                       ctypes.c_void_p]
         L.afx_oracle_run_mfcc.restype = ctypes.c_int64
         L.afx_oracle_run_mfcc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                           ctypes.c_void_p]
@@ -133,6 +147,15 @@ class Oracle:
             self.L.afx_oracle_run(self.h, x.ctypes.data, x.size, int(cap), out.ctypes.data)
         return out
 
+    def run_neighbours(self, x, cap=False):
+        """[frames][NEIGH_RECORD]: the 11 scalars of NEIGH_FIELDS, then the whitened spectrum [1024]."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        nf = self.num_frames(x.size, cap)
+        out = np.zeros((nf, NEIGH_RECORD), dtype=np.float64)
+        if nf:
+            self.L.afx_oracle_run_neighbours(self.h, x.ctypes.data, x.size, int(cap), out.ctypes.data)
+        return out
+
     def run_mfcc(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         nf = self.num_frames(x.size, False)
@@ -164,3 +187,12 @@ def calc_statistics(x, init=None):
     out = np.zeros(13) if init is None else _vec(init).copy()
     lib().afx_oracle_calc_statistics(x.ctypes.data if x.size else None, x.size, out.ctypes.data)
     return out
+
+
+def peaks(x, threshold):
+    """TStatistics::Peaks restatement -> list of (bin, value)."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    bins = np.zeros(max(x.size, 1), dtype=np.int32)
+    vals = np.zeros(max(x.size, 1), dtype=np.float64)
+    c = lib().afx_oracle_peaks(x.ctypes.data, x.size, float(threshold), bins.ctypes.data, vals.ctypes.data)
+    return [(int(bins[i]), float(vals[i])) for i in range(c)]

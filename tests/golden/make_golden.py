@@ -47,7 +47,36 @@ def signals():
     return {k: v.astype(np.float32) for k, v in s.items()}
 
 
-def run_ref(bufs, cap=0):
+def long_signals():
+    """Longer inputs for the stateful neighbours (whitening follower, pitch): name -> float32 signal."""
+    rng = np.random.default_rng(20261004)
+    n = FFT + 59 * HOP
+    t = np.arange(n, dtype=np.float64)
+    s = {}
+    # decaying harmonic notes at changing pitches, short gaps of silence in between
+    notes = np.zeros(n)
+    at = 0
+    for f0, dur in [(196.0, 9000), (261.6, 7000), (329.6, 12000), (98.0, 14000), (523.3, 8000), (147.0, 12000)]:
+        if at >= n:
+            break
+        m = min(dur, n - at)
+        tt = np.arange(m) / SR
+        tone = sum((0.6 / h) * np.sin(2 * np.pi * f0 * h * tt) for h in range(1, 6))
+        notes[at:at + m] += 0.5 * np.exp(-tt / 0.12) * tone
+        at += dur + 1500
+    s["notes"] = notes
+    # amplitude-modulated coloured noise
+    white = rng.uniform(-1.0, 1.0, n)
+    col = np.zeros(n)
+    acc = 0.0
+    for i in range(n):
+        acc = 0.92 * acc + 0.08 * white[i]
+        col[i] = acc
+    s["amnoise"] = 2.5 * col * (0.55 + 0.45 * np.sin(2 * np.pi * 3.0 * t / SR))
+    return {k: v.astype(np.float32) for k, v in s.items()}
+
+
+def run_ref(bufs, cap=0, mode="frames", record=1147):
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
         with open(fin, "wb") as f:
@@ -56,10 +85,10 @@ def run_ref(bufs, cap=0):
                 b = np.asarray(b, dtype=np.float64)
                 f.write(struct.pack("<q", b.size))
                 f.write(b.tobytes())
-        subprocess.check_call([REF, "frames", fin, fout, str(int(cap))])
+        subprocess.check_call([REF, mode, fin, fout, str(int(cap))])
         raw = open(fout, "rb").read()
     n = struct.unpack("<q", raw[:8])[0]
-    return np.frombuffer(raw[8:], dtype=np.float64).reshape(n, 1147).copy()
+    return np.frombuffer(raw[8:], dtype=np.float64).reshape(n, record).copy()
 
 
 def main():
@@ -72,6 +101,19 @@ def main():
         out["in_" + name] = x
         out["ref_" + name] = rec
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "frames.npz"), **out)
+
+    # stateful neighbours: 11 scalars + whitened spectrum per frame; the long signals keep
+    # the scalars only
+    out = {}
+    for name, x in signals().items():
+        rec = run_ref([x.astype(np.float64)], mode="neighbours", record=1035)
+        assert rec.shape == (NFRAMES, 1035), rec.shape
+        out["ref_" + name] = rec
+    for name, x in long_signals().items():
+        rec = run_ref([x.astype(np.float64)], mode="neighbours", record=1035)
+        out["in_" + name] = x
+        out["ref_" + name] = rec[:, :11].copy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "neighbours.npz"), **out)
 
     # tables
     with tempfile.TemporaryDirectory() as d:
@@ -89,7 +131,7 @@ def main():
         rows.append((n, cap, rec.shape[0]))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "framecount.npz"),
                         rows=np.array(rows, dtype=np.int64))
-    print("wrote tests/golden/{frames,tables,framecount}.npz")
+    print("wrote tests/golden/{frames,neighbours,tables,framecount}.npz")
 
 
 if __name__ == "__main__":

@@ -164,3 +164,54 @@ def test_oracle_matches_live_reference(oracle):
     for field, (a, b) in FIELDS.items():
         if field != "mag":
             _tol.check(field, got[:, a:b], ref[:, a:b], ORACLE_RTOL, ORACLE_ATOL.get(field, 1e-15))
+
+
+# ---- stateful neighbours --------------------------------------------------------
+
+# an impulse has an exactly flat spectrum: the whitened spectrum's local maxima are rounding noise
+NEIGH_ILL_CONDITIONED = {("impulse", "spectral_complexity")}
+
+
+def neighbour_names():
+    z = np.load(os.path.join(GOLD, "neighbours.npz"))
+    return sorted(k[4:] for k in z.files if k.startswith("ref_"))
+
+
+def neighbour_input(name):
+    z = np.load(os.path.join(GOLD, "neighbours.npz"))
+    if "in_" + name in z.files:
+        return z["in_" + name].astype(np.float64)
+    return np.load(os.path.join(GOLD, "frames.npz"))["in_" + name].astype(np.float64)
+
+
+@pytest.mark.parametrize("name", neighbour_names())
+def test_oracle_neighbours_match_reference_golden(oracle, name):
+    """whitening / peaks / silence / envelope / yinfast pitch / autocorrelation against the reference's
+    own aubio, TEnvelopeDetector, TAutocorrelation and LibXtract objects."""
+    ref = np.load(os.path.join(GOLD, "neighbours.npz"))["ref_" + name]
+    got = oracle.run_neighbours(neighbour_input(name))
+    assert got.shape[0] == ref.shape[0]
+    if ref.shape[1] > 11:
+        _tol.check_mag(got[:, 11:], ref[:, 11:], 1e-11, what=name + " whitened ")
+    for field, col in _oracle.NEIGH_FIELDS.items():
+        if (name, field) in NEIGH_ILL_CONDITIONED:
+            continue
+        _tol.check(field, got[:, col], ref[:, col], 1e-9, 1e-12, what=name + " ")
+
+
+def test_peaks_known_answer_from_reference_test():
+    """TestStatistics.cpp:16-33."""
+    seq = [1, 2, 2, 2, 0, 5, 6]
+    assert _oracle.peaks(seq, 0) == [(2, 2.0), (6, 6.0)]
+    assert _oracle.peaks(seq, 2) == [(6, 6.0)]
+    assert _oracle.peaks([1, 2], 0) == []
+    assert _oracle.peaks([3, 1, 2, 1, 5], 0) == [(0, 3.0), (2, 2.0), (4, 5.0)]
+
+
+def test_neighbour_descriptors_that_are_identically_zero(oracle):
+    """LibXtract reads partial frequencies from the cleared upper half of the spectrum buffer (SURVEY 8a note):
+    inharmonicity and tristimulus are 0 for every frame of every golden signal in the reference's output."""
+    z = np.load(os.path.join(GOLD, "neighbours.npz"))
+    for k in z.files:
+        if k.startswith("ref_"):
+            assert not z[k][:, 7:11].any(), k

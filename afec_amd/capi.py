@@ -28,12 +28,22 @@ D_AMPLITUDE_PEAK = 1 << 11
 D_AMPLITUDE_RMS = 1 << 12
 D_MAGNITUDE = 1 << 13
 D_STATISTICS = 1 << 14
+# neighbours of the spectral set
+D_AMPLITUDE_SILENCE = 1 << 15
+D_AMPLITUDE_ENVELOPE = 1 << 16
+D_SPECTRAL_COMPLEXITY = 1 << 17
+D_AUTO_CORRELATION = 1 << 18
+D_F0 = 1 << 19
+D_SPECTRAL_INHARMONICITY = 1 << 20
+D_TRISTIMULUS = 1 << 21
 NUM_STATISTICS = 13
 STAT_NAMES = ["min", "max", "median", "mean", "gmean", "variance", "centroid", "spread", "skewness",
               "kurtosis", "flatness", "dmean", "dvariance"]
 D_C2 = D_MFCC
 D_SPECTRAL_STATS = 0x1FE
 D_ALL_LOW_LEVEL = 0x1FFF
+D_NEIGHBOURS = 0x3F8000
+D_ALL_PER_FRAME = D_ALL_LOW_LEVEL | D_NEIGHBOURS
 PRECISION_F64, PRECISION_F32 = 0, 1
 PCM_F32, PCM_F64 = 0, 1
 
@@ -55,6 +65,9 @@ OUT_FIELDS = [
     ("spectral_flatness", 1), ("spectral_flux", 1), ("spectrum_bands", 28), ("sub_rms", 14),
     ("sub_flatness", 14), ("sub_flux", 14), ("sub_complexity", 14), ("sub_contrast", 14),
     ("spectral_contrast", 1), ("amplitude_peak", 1), ("amplitude_rms", 1), ("magnitude", 1024),
+    ("amplitude_silence", 1), ("amplitude_envelope", 1), ("spectral_complexity", 1), ("auto_correlation", 1),
+    ("f0", 1), ("f0_confidence", 1), ("failsafe_f0", 1), ("spectral_inharmonicity", 1),
+    ("tristimulus1", 1), ("tristimulus2", 1), ("tristimulus3", 1),
 ]
 FIELD_MASK = {
     "mfcc": D_MFCC, "spectral_rms": D_SPECTRAL_RMS, "spectral_centroid": D_SPECTRAL_CENTROID,
@@ -65,6 +78,11 @@ FIELD_MASK = {
     "sub_flux": D_BAND_FEATURES, "sub_complexity": D_BAND_FEATURES, "sub_contrast": D_BAND_FEATURES,
     "spectral_contrast": D_BAND_FEATURES, "amplitude_peak": D_AMPLITUDE_PEAK,
     "amplitude_rms": D_AMPLITUDE_RMS, "magnitude": D_MAGNITUDE,
+    "amplitude_silence": D_AMPLITUDE_SILENCE, "amplitude_envelope": D_AMPLITUDE_ENVELOPE,
+    "spectral_complexity": D_SPECTRAL_COMPLEXITY, "auto_correlation": D_AUTO_CORRELATION,
+    "f0": D_F0, "f0_confidence": D_F0, "failsafe_f0": D_F0,
+    "spectral_inharmonicity": D_SPECTRAL_INHARMONICITY,
+    "tristimulus1": D_TRISTIMULUS, "tristimulus2": D_TRISTIMULUS, "tristimulus3": D_TRISTIMULUS,
 }
 
 

@@ -120,6 +120,10 @@ struct DeviceTables {
   void* post = nullptr;
   void* melw = nullptr;
   double* dct = nullptr;
+  // double-precision FFT tables for the time-domain neighbours (alias t1/t2/post in the f64 mode)
+  void* t1_f64 = nullptr;
+  void* t2_f64 = nullptr;
+  void* post_f64 = nullptr;
 };
 
 }  // namespace
@@ -134,8 +138,10 @@ struct Workspace {
   };
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  Buf pcm, chunks, rec, mag, prev, foff, stats;
-  size_t bytes() const { return pcm.cap + chunks.cap + rec.cap + mag.cap + prev.cap + foff.cap + stats.cap; }
+  Buf pcm, chunks, rem, rec, mag, prev, foff, stats, cfirst, follower;
+  size_t bytes() const {
+    return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + prev.cap + foff.cap + stats.cap + cfirst.cap + follower.cap;
+  }
 };
 
 struct afx_plan {
@@ -165,6 +171,10 @@ struct afx_batch {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   void* d_pcm = nullptr;
   afx::Chunk* d_chunks = nullptr;
+  afx::ChunkRemaining* d_rem = nullptr;
+  int32_t* d_chunk_first = nullptr;
+  double* d_follower = nullptr;
+  int chunk_frames = 0;
   double* d_rec = nullptr;
   double* d_mag = nullptr;
   int32_t* d_prev = nullptr;
@@ -208,6 +218,33 @@ int upload_tables_typed(afx_plan* p) {
   HIP_TRY(up(&p->dev.t1, t1.data(), t1.size() * sizeof(C)));
   HIP_TRY(up(&p->dev.t2, t2.data(), t2.size() * sizeof(C)));
   HIP_TRY(up(&p->dev.post, post.data(), post.size() * sizeof(C)));
+  if (sizeof(T) == 8) {
+    p->dev.t1_f64 = p->dev.t1; p->dev.t2_f64 = p->dev.t2; p->dev.post_f64 = p->dev.post;
+  }
+  return AFX_OK;
+}
+
+// the pitch / autocorrelation kernels always run in double
+int upload_double_twiddles(afx_plan* p) {
+  using C = cpx<double>;
+  std::vector<C> t1(64), t2(1024), post(1024);
+  for (int n = 0; n < 1024; ++n) post[n] = twiddle<double>(n, 2048);
+  for (int jh = 0; jh < 4; ++jh)
+    for (int m2 = 0; m2 < 4; ++m2)
+      for (int jl = 0; jl < 4; ++jl) t1[16 * jh + 4 * m2 + jl] = twiddle<double>((long long)m2 * (4 * jh + jl), 64);
+  for (int g = 0; g < 16; ++g)
+    for (int lane = 0; lane < 64; ++lane) {
+      const int j2 = g >> 2, jl = g & 3, jh = lane >> 4, n2 = lane & 15;
+      t2[64 * g + lane] = twiddle<double>((long long)n2 * (4 * jh + jl + 16 * j2), 1024);
+    }
+  auto up = [](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  HIP_TRY(up(&p->dev.t1_f64, t1.data(), t1.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.t2_f64, t2.data(), t2.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.post_f64, post.data(), post.size() * sizeof(C)));
   return AFX_OK;
 }
 
@@ -215,6 +252,7 @@ int upload_tables(afx_plan* p) {
   int st = (p->desc.precision == AFX_PRECISION_F64) ? upload_tables_typed<double>(p)
                                                     : upload_tables_typed<float>(p);
   if (st != AFX_OK) return st;
+  if (p->desc.precision != AFX_PRECISION_F64 && (st = upload_double_twiddles(p)) != AFX_OK) return st;
   // packed mel rows: one 64-lane row per (r, f) pair the static cover lists, in the kernel's precision
   std::vector<double> melw((size_t)afx::kMelPairs * 64, 0.0);
   int idx = 0;
@@ -243,6 +281,7 @@ int upload_tables(afx_plan* p) {
 }
 
 void free_tables(afx_plan* p) {
+  if (p->dev.t1_f64 != p->dev.t1) { hipFree(p->dev.t1_f64); hipFree(p->dev.t2_f64); hipFree(p->dev.post_f64); }
   hipFree(p->dev.win); hipFree(p->dev.t1); hipFree(p->dev.t2); hipFree(p->dev.post);
   hipFree(p->dev.melw); hipFree(p->dev.dct);
   p->dev = DeviceTables{};
@@ -250,7 +289,7 @@ void free_tables(afx_plan* p) {
 
 void ws_free(Workspace* w) {
   if (!w) return;
-  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rec, &w->mag, &w->prev, &w->foff, &w->stats}) hipFree(b->p);
+  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->prev, &w->foff, &w->stats, &w->cfirst, &w->follower}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->stream) hipStreamDestroy(w->stream);
@@ -303,35 +342,71 @@ hipError_t ws_reserve(Workspace::Buf& b, size_t bytes) {
   return hipSuccess;
 }
 
+// Every per-frame series of the ABI: where it lives in afx_out / afx_stats_out / the device record, its
+// width, and the mask bit that selects it.  The order is the record order.
+struct FieldDesc {
+  double* afx_out::*out;
+  double* afx_stats_out::*stat;
+  int32_t afx::RecordLayout::*off;
+  int width;
+  uint32_t bit;
+};
+#define AFX_FIELD(name, lay, width, bit) {&afx_out::name, &afx_stats_out::name, &afx::RecordLayout::lay, width, bit}
+const FieldDesc kFields[] = {
+    AFX_FIELD(mfcc, mfcc, 14, AFX_D_MFCC),
+    AFX_FIELD(spectral_rms, srms, 1, AFX_D_SPECTRAL_RMS),
+    AFX_FIELD(spectral_centroid, centroid, 1, AFX_D_SPECTRAL_CENTROID),
+    AFX_FIELD(spectral_spread, spread, 1, AFX_D_SPECTRAL_SPREAD),
+    AFX_FIELD(spectral_skewness, skew, 1, AFX_D_SPECTRAL_SKEWNESS),
+    AFX_FIELD(spectral_kurtosis, kurt, 1, AFX_D_SPECTRAL_KURTOSIS),
+    AFX_FIELD(spectral_rolloff, rolloff, 1, AFX_D_SPECTRAL_ROLLOFF),
+    AFX_FIELD(spectral_flatness, flatness, 1, AFX_D_SPECTRAL_FLATNESS),
+    AFX_FIELD(spectral_flux, flux, 1, AFX_D_SPECTRAL_FLUX),
+    AFX_FIELD(spectrum_bands, bands, 28, AFX_D_SPECTRUM_BANDS),
+    AFX_FIELD(amplitude_peak, amp_peak, 1, AFX_D_AMPLITUDE_PEAK),
+    AFX_FIELD(amplitude_rms, amp_rms, 1, AFX_D_AMPLITUDE_RMS),
+    AFX_FIELD(sub_rms, sub_rms, 14, AFX_D_BAND_FEATURES),
+    AFX_FIELD(sub_flatness, sub_flat, 14, AFX_D_BAND_FEATURES),
+    AFX_FIELD(sub_flux, sub_flux, 14, AFX_D_BAND_FEATURES),
+    AFX_FIELD(sub_complexity, sub_cplx, 14, AFX_D_BAND_FEATURES),
+    AFX_FIELD(sub_contrast, sub_contrast, 14, AFX_D_BAND_FEATURES),
+    AFX_FIELD(spectral_contrast, contrast, 1, AFX_D_BAND_FEATURES),
+    AFX_FIELD(amplitude_silence, silence, 1, AFX_D_AMPLITUDE_SILENCE),
+    AFX_FIELD(amplitude_envelope, envelope, 1, AFX_D_AMPLITUDE_ENVELOPE),
+    AFX_FIELD(spectral_complexity, complexity, 1, AFX_D_SPECTRAL_COMPLEXITY),
+    AFX_FIELD(auto_correlation, autocorr, 1, AFX_D_AUTO_CORRELATION),
+    AFX_FIELD(f0, f0, 1, AFX_D_F0),
+    AFX_FIELD(f0_confidence, f0_conf, 1, AFX_D_F0),
+    AFX_FIELD(failsafe_f0, f0_safe, 1, AFX_D_F0),
+    AFX_FIELD(spectral_inharmonicity, inharm, 1, AFX_D_SPECTRAL_INHARMONICITY),
+    AFX_FIELD(tristimulus1, tri1, 1, AFX_D_TRISTIMULUS),
+    AFX_FIELD(tristimulus2, tri2, 1, AFX_D_TRISTIMULUS),
+    AFX_FIELD(tristimulus3, tri3, 1, AFX_D_TRISTIMULUS),
+};
+#undef AFX_FIELD
+
 afx::RecordLayout make_layout(uint32_t mask) {
-  afx::RecordLayout l;
-  int32_t* f = &l.mfcc;
-  for (int i = 0; i < 18; ++i) f[i] = -1;
+  afx::RecordLayout l{};
   int off = 0;
-  auto take = [&](bool on, int32_t& field, int width) {
-    if (on) { field = off; off += width; }
-  };
-  take(mask & AFX_D_MFCC, l.mfcc, 14);
-  take(mask & AFX_D_SPECTRAL_RMS, l.srms, 1);
-  take(mask & AFX_D_SPECTRAL_CENTROID, l.centroid, 1);
-  take(mask & AFX_D_SPECTRAL_SPREAD, l.spread, 1);
-  take(mask & AFX_D_SPECTRAL_SKEWNESS, l.skew, 1);
-  take(mask & AFX_D_SPECTRAL_KURTOSIS, l.kurt, 1);
-  take(mask & AFX_D_SPECTRAL_ROLLOFF, l.rolloff, 1);
-  take(mask & AFX_D_SPECTRAL_FLATNESS, l.flatness, 1);
-  take(mask & AFX_D_SPECTRAL_FLUX, l.flux, 1);
-  take(mask & AFX_D_SPECTRUM_BANDS, l.bands, 28);
-  take(mask & AFX_D_AMPLITUDE_PEAK, l.amp_peak, 1);
-  take(mask & AFX_D_AMPLITUDE_RMS, l.amp_rms, 1);
-  const bool bf = (mask & AFX_D_BAND_FEATURES) != 0;
-  take(bf, l.sub_rms, 14);
-  take(bf, l.sub_flat, 14);
-  take(bf, l.sub_flux, 14);
-  take(bf, l.sub_cplx, 14);
-  take(bf, l.sub_contrast, 14);
-  take(bf, l.contrast, 1);
+  for (const FieldDesc& f : kFields) {
+    l.*(f.off) = -1;
+    if (mask & f.bit) { l.*(f.off) = off; off += f.width; }
+  }
   l.stride = off;
   return l;
+}
+
+// which kernels a descriptor mask needs
+constexpr uint32_t kSpectralBits = AFX_D_ALL_LOW_LEVEL | AFX_D_MAGNITUDE;
+constexpr uint32_t kNeedsMagnitudes = AFX_D_MAGNITUDE | AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX |
+                                      AFX_D_SPECTRAL_COMPLEXITY | AFX_D_F0;
+constexpr uint32_t kWhitenBits = AFX_D_SPECTRAL_COMPLEXITY | AFX_D_F0 | AFX_D_SPECTRAL_INHARMONICITY | AFX_D_TRISTIMULUS;
+constexpr uint32_t kTimeBits = AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE | AFX_D_AUTO_CORRELATION | AFX_D_F0;
+// the frame kernel sees the spectral bits; storing the magnitudes is its AFX_D_MAGNITUDE path
+uint32_t frames_mask(uint32_t mask) {
+  uint32_t m = mask & kSpectralBits;
+  if (mask & kNeedsMagnitudes) m |= AFX_D_MAGNITUDE;
+  return m;
 }
 
 int64_t num_frames(const afx_plan* p, int64_t n_samples) {
@@ -478,8 +553,10 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   b->mask = mask;
   b->n_bufs = n_bufs;
   b->lay = make_layout(mask);
-  // flux and the sub-band descriptors are computed from the stored magnitudes by the second kernel
-  b->mag_wanted = (mask & (AFX_D_MAGNITUDE | AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) != 0;
+  // flux, the sub-band descriptors and the whitened-spectrum neighbours are computed from the stored
+  // magnitudes by later kernels
+  b->mag_wanted = (mask & kNeedsMagnitudes) != 0;
+  const uint32_t fmask = frames_mask(mask);
   b->frame_offset.assign((size_t)n_bufs + 1, 0);
   b->buf_status = status;
   b->pcm_dtype = dtype;
@@ -496,6 +573,9 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     const int64_t f = num_frames(plan, lengths[i]);
     if (f > 0) {
       b->used[i] = (f - 1) * plan->desc.hop_size + plan->desc.fft_size;
+      // the second rising-slope search of CalcAutoCorrelation (SampleAnalyser.cpp:2343-2356) may look up to
+      // 33 samples past the last frame when the buffer has them
+      if (mask & AFX_D_AUTO_CORRELATION) b->used[i] = std::min<int64_t>(lengths[i], b->used[i] + 64);
       b->arena_off[i] = arena;
       arena += (b->used[i] + 3) & ~(int64_t)3;
       frames += f;
@@ -509,7 +589,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   // amortise the 2048-sample lead-in of each chunk
   // K is picked to minimise (rounds of the wave slots) x (frames per chunk + lead-in): long chunks for
   // big batches, one round of short chunks when the batch barely fills the chip
-  const int64_t slots = (int64_t)plan->cu_count * afx::frames_waves_per_block(mask);
+  const int64_t slots = (int64_t)plan->cu_count * afx::frames_waves_per_block(fmask);
   int K = 32;
   {
     double best = 1e300;
@@ -521,9 +601,14 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     }
   }
   std::vector<afx::Chunk> chunks;
+  std::vector<afx::ChunkRemaining> remaining;
+  std::vector<int32_t> chunk_first((size_t)n_bufs, 0);
+  b->chunk_frames = K;
   for (int i = 0; i < n_bufs; ++i) {
     const int64_t f = b->frame_offset[i + 1] - b->frame_offset[i];
+    chunk_first[(size_t)i] = (int32_t)chunks.size();
     for (int64_t f0 = 0; f0 < f; f0 += K) {
+      remaining.push_back((afx::ChunkRemaining)std::min<int64_t>(lengths[i] - f0 * plan->desc.hop_size, 1 << 30));
       afx::Chunk c;
       const bool first = (f0 == 0);
       c.sample_off = b->arena_off[i] + f0 * plan->desc.hop_size;
@@ -536,7 +621,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   b->n_chunks = (int)chunks.size();
   // one workgroup per CU (its LDS holds the shared tables plus one exchange plane per wave);
   // waves walk the chunk list with a grid stride
-  const int waves_per_block = afx::frames_waves_per_block(mask);
+  const int waves_per_block = afx::frames_waves_per_block(fmask);
   b->grid_blocks = (int)std::min<int64_t>((b->n_chunks + waves_per_block - 1) / waves_per_block,
                                           (int64_t)plan->cu_count);
   if (b->grid_blocks < 1) b->grid_blocks = 1;
@@ -559,6 +644,18 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     b->d_chunks = (afx::Chunk*)w.chunks.p;
     if ((e = hipMemcpyAsync(b->d_chunks, chunks.data(), chunks.size() * sizeof(afx::Chunk), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(chunks)"));
   }
+  if (b->n_chunks > 0 && (mask & kTimeBits)) {
+    if ((e = ws_reserve(w.rem, remaining.size() * sizeof(afx::ChunkRemaining))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(remaining)"));
+    b->d_rem = (afx::ChunkRemaining*)w.rem.p;
+    if ((e = hipMemcpyAsync(b->d_rem, remaining.data(), remaining.size() * sizeof(afx::ChunkRemaining), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(remaining)"));
+  }
+  if (b->n_chunks > 0 && (mask & AFX_D_SPECTRAL_COMPLEXITY)) {
+    if ((e = ws_reserve(w.cfirst, chunk_first.size() * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(chunk_first)"));
+    b->d_chunk_first = (int32_t*)w.cfirst.p;
+    if ((e = hipMemcpyAsync(b->d_chunk_first, chunk_first.data(), chunk_first.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(chunk_first)"));
+    if ((e = ws_reserve(w.follower, (size_t)b->n_chunks * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(follower)"));
+    b->d_follower = (double*)w.follower.p;
+  }
   if (frames > 0 && b->lay.stride > 0) {
     if ((e = ws_reserve(w.rec, (size_t)frames * b->lay.stride * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rec)"));
     b->d_rec = (double*)w.rec.p;
@@ -578,10 +675,12 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     if ((e = hipMemcpyAsync(b->d_prev, prev.data(), prev.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(prev)"));
     if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
   }
-  if (want_stats && n_bufs > 0 && b->lay.stride > 0) {
+  if ((want_stats || (mask & kWhitenBits)) && n_bufs > 0 && b->lay.stride > 0) {
     if ((e = ws_reserve(w.foff, b->frame_offset.size() * sizeof(int64_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(frame_offset)"));
     b->d_frame_offset = (int64_t*)w.foff.p;
     if ((e = hipMemcpyAsync(b->d_frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(frame_offset)"));
+  }
+  if (want_stats && n_bufs > 0 && b->lay.stride > 0) {
     if ((e = ws_reserve(w.stats, (size_t)n_bufs * b->lay.stride * 13 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stats)"));
     b->d_stats = (double*)w.stats.p;
   }
@@ -592,7 +691,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
 
 bool mask_ok(uint32_t mask) {
   return (mask & ~(uint32_t)AFX_D_STATISTICS) != 0 &&
-         !(mask & ~(uint32_t)(AFX_D_ALL_LOW_LEVEL | AFX_D_MAGNITUDE | AFX_D_STATISTICS));
+         !(mask & ~(uint32_t)(AFX_D_ALL_PER_FRAME | AFX_D_MAGNITUDE | AFX_D_STATISTICS));
 }
 
 }  // namespace
@@ -749,22 +848,45 @@ int afx_batch_run(afx_batch* b) {
     }
     return AFX_OK;
   }
-  afx::FrameArgs a{};
-  a.pcm = b->d_pcm;
-  a.chunks = b->d_chunks;
-  a.n_chunks = b->n_chunks;
-  a.mask = b->mask;
-  a.rec = b->d_rec;
-  a.lay = b->lay;
-  a.mag_out = b->d_mag;
   const DeviceTables& t = b->plan->dev;
-  a.win = t.win; a.t1 = t.t1; a.t2 = t.t2; a.post = t.post; a.melw = t.melw; a.dct = t.dct;
-  HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
+  if (frames_mask(b->mask)) {
+    afx::FrameArgs a{};
+    a.pcm = b->d_pcm;
+    a.chunks = b->d_chunks;
+    a.n_chunks = b->n_chunks;
+    a.mask = frames_mask(b->mask);
+    a.rec = b->d_rec;
+    a.lay = b->lay;
+    a.mag_out = b->d_mag;
+    a.win = t.win; a.t1 = t.t1; a.t2 = t.t2; a.post = t.post; a.melw = t.melw; a.dct = t.dct;
+    HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
+  }
   if (b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) {
     afx::BandArgs ba{};
     ba.mag = b->d_mag; ba.prev = b->d_prev; ba.n_frames = b->total_frames; ba.rec = b->d_rec; ba.lay = b->lay;
     ba.flags = ((b->mask & AFX_D_BAND_FEATURES) ? afx::kBandsFeatures : 0) | ((b->mask & AFX_D_SPECTRAL_FLUX) ? afx::kBandsFlux : 0);
     HIP_TRY(afx::launch_bands(ba, b->stream));
+  }
+  if (b->mask & kTimeBits) {
+    afx::TimeArgs ta{};
+    ta.pcm = b->d_pcm; ta.chunks = b->d_chunks; ta.remaining = b->d_rem; ta.n_chunks = b->n_chunks;
+    ta.pcm_dtype = b->pcm_dtype; ta.rec = b->d_rec; ta.lay = b->lay;
+    ta.t1 = t.t1_f64; ta.t2 = t.t2_f64; ta.post = t.post_f64;
+    if (b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) HIP_TRY(afx::launch_hop(ta, b->stream));
+    if (b->mask & AFX_D_AUTO_CORRELATION) HIP_TRY(afx::launch_acorr(ta, b->stream));
+    if (b->mask & AFX_D_F0) HIP_TRY(afx::launch_pitch(ta, b->stream));
+  }
+  if (b->mask & kWhitenBits) {
+    afx::WhitenArgs wa{};
+    wa.mag = b->d_mag; wa.frame_offset = b->d_frame_offset; wa.n_bufs = b->n_bufs; wa.mask = b->mask;
+    wa.chunk_first = b->d_chunk_first; wa.chunks = b->d_chunks; wa.n_chunks = b->n_chunks;
+    wa.chunk_frames = b->chunk_frames; wa.follower = b->d_follower;
+    wa.rec = b->d_rec; wa.lay = b->lay;
+    // new_aubio_spectral_whitening + set_relax_time(MSpectralWhiteningDecay = 22): awhitening.c:53-87,
+    // SampleAnalyser.cpp:44, 805-809
+    wa.decay = std::pow(0.001, (double)((float)b->plan->desc.hop_size / (float)b->plan->desc.sample_rate) / 22.0);
+    wa.floor_value = 1.e-4;
+    HIP_TRY(afx::launch_whiten(wa, b->stream));
   }
   if (b->d_stats) {
     afx::StatsArgs sa{};
@@ -805,15 +927,8 @@ int afx_batch_fetch(afx_batch* b, afx_out* out) {
   if (F == 0) return AFX_OK;
   const afx::RecordLayout& l = b->lay;
   struct Field { double* dst; int32_t off; int width; };
-  const Field fields[] = {
-      {out->mfcc, l.mfcc, 14}, {out->spectral_rms, l.srms, 1}, {out->spectral_centroid, l.centroid, 1},
-      {out->spectral_spread, l.spread, 1}, {out->spectral_skewness, l.skew, 1},
-      {out->spectral_kurtosis, l.kurt, 1}, {out->spectral_rolloff, l.rolloff, 1},
-      {out->spectral_flatness, l.flatness, 1}, {out->spectral_flux, l.flux, 1},
-      {out->spectrum_bands, l.bands, 28}, {out->amplitude_peak, l.amp_peak, 1},
-      {out->amplitude_rms, l.amp_rms, 1}, {out->sub_rms, l.sub_rms, 14}, {out->sub_flatness, l.sub_flat, 14},
-      {out->sub_flux, l.sub_flux, 14}, {out->sub_complexity, l.sub_cplx, 14},
-      {out->sub_contrast, l.sub_contrast, 14}, {out->spectral_contrast, l.contrast, 1}};
+  std::vector<Field> fields;
+  for (const FieldDesc& d : kFields) fields.push_back(Field{out->*(d.out), l.*(d.off), d.width});
   for (const Field& f : fields)
     if (f.dst && f.off < 0) return fail(AFX_ERR_INVALID_ARG, "output requested that is not in the batch mask");
   if (out->magnitude && !(b->mask & AFX_D_MAGNITUDE)) return fail(AFX_ERR_INVALID_ARG, "magnitude not in the batch mask");
@@ -841,15 +956,8 @@ int afx_batch_fetch_statistics(afx_batch* b, afx_stats_out* out) {
   std::vector<double> st((size_t)b->n_bufs * l.stride * 13);
   HIP_TRY(hipMemcpy(st.data(), b->d_stats, st.size() * sizeof(double), hipMemcpyDeviceToHost));
   struct Field { double* dst; int32_t off; int width; };
-  const Field fields[] = {
-      {out->mfcc, l.mfcc, 14}, {out->spectral_rms, l.srms, 1}, {out->spectral_centroid, l.centroid, 1},
-      {out->spectral_spread, l.spread, 1}, {out->spectral_skewness, l.skew, 1},
-      {out->spectral_kurtosis, l.kurt, 1}, {out->spectral_rolloff, l.rolloff, 1},
-      {out->spectral_flatness, l.flatness, 1}, {out->spectral_flux, l.flux, 1},
-      {out->spectrum_bands, l.bands, 28}, {out->amplitude_peak, l.amp_peak, 1},
-      {out->amplitude_rms, l.amp_rms, 1}, {out->sub_rms, l.sub_rms, 14}, {out->sub_flatness, l.sub_flat, 14},
-      {out->sub_flux, l.sub_flux, 14}, {out->sub_complexity, l.sub_cplx, 14},
-      {out->sub_contrast, l.sub_contrast, 14}, {out->spectral_contrast, l.contrast, 1}};
+  std::vector<Field> fields;
+  for (const FieldDesc& d : kFields) fields.push_back(Field{out->*(d.stat), l.*(d.off), d.width});
   for (const Field& f : fields) {
     if (!f.dst) continue;
     if (f.off < 0) return fail(AFX_ERR_INVALID_ARG, "statistics requested for a series that is not in the batch mask");
@@ -901,12 +1009,9 @@ int afx_extract_batch(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint3
     return st;
   }
   struct Col { double* afx_out::*field; int width; };
-  static const Col cols[] = {
-      {&afx_out::mfcc, 14}, {&afx_out::spectral_rms, 1}, {&afx_out::spectral_centroid, 1}, {&afx_out::spectral_spread, 1},
-      {&afx_out::spectral_skewness, 1}, {&afx_out::spectral_kurtosis, 1}, {&afx_out::spectral_rolloff, 1},
-      {&afx_out::spectral_flatness, 1}, {&afx_out::spectral_flux, 1}, {&afx_out::spectrum_bands, 28}, {&afx_out::sub_rms, 14},
-      {&afx_out::sub_flatness, 14}, {&afx_out::sub_flux, 14}, {&afx_out::sub_complexity, 14}, {&afx_out::sub_contrast, 14},
-      {&afx_out::spectral_contrast, 1}, {&afx_out::amplitude_peak, 1}, {&afx_out::amplitude_rms, 1}, {&afx_out::magnitude, 1024}};
+  std::vector<Col> cols;
+  for (const FieldDesc& d : kFields) cols.push_back(Col{d.out, d.width});
+  cols.push_back(Col{&afx_out::magnitude, 1024});
   int64_t row0 = 0;
   int32_t first = 0;
   if (out->frame_offset) out->frame_offset[0] = 0;

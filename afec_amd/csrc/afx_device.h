@@ -13,6 +13,13 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// cooperative copy of a constant table into LDS (bytes a multiple of 16)
+__device__ __forceinline__ void copy_lds_table(unsigned char* dst, const void* src, int bytes, int tid, int nthreads) {
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+  uint4* d = reinterpret_cast<uint4*>(dst);
+  for (int i = tid; i < bytes / 16; i += nthreads) d[i] = s[i];
+}
+
 // ---- cross-lane helpers on doubles: DPP inside a 16-lane row, permlane swaps across rows ----
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {

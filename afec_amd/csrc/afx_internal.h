@@ -66,6 +66,9 @@ struct Chunk {
   int16_t nframes;     // emitted frames
   int16_t flags;
 };
+// companion of Chunk for the time-domain kernels: samples of the buffer from the chunk's first frame on
+// (TSampleData::mData.Size() - n, SampleAnalyser.cpp:943), saturated at 2^30
+using ChunkRemaining = int32_t;
 enum { kChunkFirstOfBuffer = 1 };
 
 // per-frame output record: offsets in doubles, -1 = not selected
@@ -73,6 +76,8 @@ struct RecordLayout {
   int32_t stride;
   int32_t mfcc, srms, centroid, spread, skew, kurt, rolloff, flatness, flux, bands, amp_peak,
       amp_rms, sub_rms, sub_flat, sub_flux, sub_cplx, sub_contrast, contrast;
+  // neighbours
+  int32_t silence, envelope, complexity, autocorr, f0, f0_conf, f0_safe, inharm, tri1, tri2, tri3;
 };
 
 struct FrameArgs {
@@ -108,6 +113,42 @@ struct BandArgs {
 };
 enum { kBandsFeatures = 1, kBandsFlux = 2 };
 hipError_t launch_bands(const BandArgs& a, hipStream_t stream);
+
+// ---- neighbours of the spectral set ----
+// time-domain descriptors of every frame, one wave per chunk (afx_time.hip)
+struct TimeArgs {
+  const void* pcm;
+  const Chunk* chunks;
+  const ChunkRemaining* remaining;
+  int32_t n_chunks;
+  int32_t pcm_dtype;      // AFX_PCM_*
+  double* rec;
+  RecordLayout lay;
+  const void* t1;         // the double FFT tables of FrameArgs
+  const void* t2;
+  const void* post;
+};
+hipError_t launch_hop(const TimeArgs& a, hipStream_t stream);      // silence flag, envelope
+hipError_t launch_acorr(const TimeArgs& a, hipStream_t stream);    // auto_correlation
+hipError_t launch_pitch(const TimeArgs& a, hipStream_t stream);    // f0, f0 confidence (aubio yinfast)
+
+// whitening follower over the frames of each buffer + peak spectrum + fail-safe f0 (afx_whiten.hip), from
+// the stored magnitudes; runs after launch_pitch.  Two kernels: the follower recurrence alone, one wave per
+// (buffer, 64 bins), leaves its state at every chunk start; then one wave per chunk does the per-frame work.
+struct WhitenArgs {
+  const double* mag;            // [F][1024]
+  const int64_t* frame_offset;  // [n_bufs + 1], device
+  const int32_t* chunk_first;   // [n_bufs]: index of the buffer's first chunk
+  const Chunk* chunks;
+  int32_t n_bufs, n_chunks;
+  int32_t chunk_frames;         // frames per chunk (the last chunk of a buffer may be shorter)
+  uint32_t mask;                // AFX_D_* bits
+  double* rec;
+  RecordLayout lay;
+  double* follower;             // [n_chunks][1024] follower state at the chunk's first frame
+  double decay, floor_value;    // aubio_spectral_whitening: r_decay, floor
+};
+hipError_t launch_whiten(const WhitenArgs& a, hipStream_t stream);
 
 // per-buffer statistics of every record column (TStatistics::Calc, Statistics.cpp:12-90)
 struct StatsArgs {

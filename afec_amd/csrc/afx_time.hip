@@ -1,0 +1,530 @@
+// afec_amd/csrc/afx_time.hip -- time-domain neighbours of the spectral loop, gfx950.
+//
+// Per frame, from the PCM arena (one wave per chunk of consecutive frames, like the frame kernel):
+//
+//   hop_kernel    amplitude_silence   aubio_silence_detection on the hop, Aubio mathutils.c:345-357, 605-615
+//                 amplitude_envelope  TEnvelopeDetector kFast over the hop, SampleAnalyser.cpp (SA) 1787-1804
+//   acorr_kernel  auto_correlation    CalcAutoCorrelation, SA:2312-2398 (TAutocorrelation::Calc)
+//   pitch_kernel  f0, f0_confidence   aubio yinfast, Aubio pitch/pitchyinfast.c:81-170, pitch.c:399-462,
+//                                     SA:876-896 (the fail-safe f0 needs the spectrum: afx_whiten.hip)
+//
+// The two correlations are computed through the in-register 1024-point complex FFT of afx_fft.h: a real
+// 2048-point transform is the complex transform of z[m] = x[2m] + i x[2m+1] plus the even/odd untangle,
+// X[k] = E[k] + w^k O[k], X[1024-k] = conj(E[k] - w^k O[k]); the inverse of a Hermitian spectrum runs the
+// same steps backwards.  All arithmetic is double whatever the plan's STFT precision.
+//
+// Layouts: "strided" element = lane + 64 r (FFT in/out), "blocked" element = 16 lane + i (prefix sums,
+// first-index searches).  Changes of layout go through the wave's LDS plane with one pad slot per 16.
+
+#include <hip/hip_runtime.h>
+
+#include "afx_internal.h"
+#include "afx_device.h"
+#include "afx_fft.h"
+
+namespace afx {
+namespace {
+
+constexpr int kTimeWaves = 8;
+constexpr int kPadSlots = 1088;                 // 1024 + 64 pads, >= kPlaneSlots
+constexpr int kTimePlaneBytes = kPadSlots * 8;
+constexpr int kLdsT2 = 0, kLdsPost = 16384, kLdsPlanes = 32768;
+constexpr int kTimeLdsBytes = kLdsPlanes + kTimeWaves * kTimePlaneBytes;
+
+__device__ __forceinline__ int pad_slot(int e) { return e + (e >> 4); }
+
+// x[i] = p[i], i < 16, p 16-byte aligned
+__device__ __forceinline__ void load16(const float* p, double (&x)[16]) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float4 v = q[j];
+    x[4 * j] = (double)v.x; x[4 * j + 1] = (double)v.y; x[4 * j + 2] = (double)v.z; x[4 * j + 3] = (double)v.w;
+  }
+}
+__device__ __forceinline__ void load16(const double* p, double (&x)[16]) {
+  const double2* q = reinterpret_cast<const double2*>(p);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const double2 v = q[j];
+    x[2 * j] = v.x; x[2 * j + 1] = v.y;
+  }
+}
+
+__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
+__device__ __forceinline__ int wave_min_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+
+// aubio_silence_detection: 10 log10(mean x^2) < threshold (mathutils.c:605-615)
+__device__ __forceinline__ bool au_silent(double sum_sq, int n, double threshold_db) {
+  return 10.0 * log10(sum_sq / (double)n) < threshold_db;
+}
+
+// ---------------------------------------------------------------------------------------------
+// hop kernel: silence flag + envelope maximum of the hop (first 1024 samples of the frame)
+// ---------------------------------------------------------------------------------------------
+template <typename TIn>
+__global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int wave_stride = gridDim.x * 4;
+  const TIn* const pcm = reinterpret_cast<const TIn*>(a.pcm);
+
+  // TEnvelopeDetector(kFast, MEnvelopeTimeInMs = 8, rate): mCoef = pow(0.01, 1000 / (ms rate)), Envelopes.cpp:55-70.
+  // env_i = in_i + c (env_{i-1} - in_i) is affine in env_{i-1} with slope c: a lane runs its 16 samples from
+  // 0, the carries are an affine scan over the lanes (slope c^16), and env_i = local_i + c^(i+1) carry.
+  const double coef = pow(0.01, 1000.0 / (8.0 * (double)kSampleRate));
+  double cpow[17];
+  cpow[0] = 1.0;
+#pragma unroll
+  for (int i = 1; i <= 16; ++i) cpow[i] = cpow[i - 1] * coef;
+
+  for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
+    const Chunk ch = a.chunks[ci];
+    for (int fi = 0; fi < ch.nframes; ++fi) {
+      double x[16];
+      load16(pcm + ch.sample_off + (int64_t)fi * kHop + 16 * lane, x);
+      double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
+
+      double e = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) e += x[i] * x[i];
+      e = wave_sum(e);
+
+      double loc[16], env = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const double in = fabs(x[i]);
+        env = in + coef * (env - in);        // TEnvelopeDetector::Run, Envelopes.inl:14-18
+        loc[i] = env;
+      }
+      double carry = env, slope = cpow[16];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const double t = __shfl_up(carry, o);
+        if (lane >= o) carry = fma(slope, t, carry);
+        slope *= slope;
+      }
+      double in_carry = __shfl_up(carry, 1);
+      if (lane == 0) in_carry = 0.0;
+      double top = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) top = fmax(top, fma(cpow[i + 1], in_carry, loc[i]));
+      top = wave_max(top);
+
+      if (lane == 0) {
+        if (a.lay.silence >= 0) rec[a.lay.silence] = au_silent(e, kHop, -48.0) ? 1.0 : 0.0;   // SA:865-868
+        if (a.lay.envelope >= 0) rec[a.lay.envelope] = top;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// FFT plumbing shared by the correlation kernels
+// ---------------------------------------------------------------------------------------------
+struct TimeCtx {
+  const cx<double>* t1;     // global, + 16 (lane >> 4)
+  const cx<double>* t2;     // LDS, + lane
+  const cx<double>* post;   // LDS, + lane: w2048^(lane + 64 r) at [64 r]
+  unsigned char* plane;
+  double* plane_d;
+  unsigned plane_rd_addr;
+  int lane, partner;
+};
+
+__device__ __forceinline__ TimeCtx time_setup(const TimeArgs& a, unsigned char* lds_raw) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  copy_lds_table(lds_raw + kLdsT2, a.t2, 16384, threadIdx.x, kTimeWaves * 64);
+  copy_lds_table(lds_raw + kLdsPost, a.post, 16384, threadIdx.x, kTimeWaves * 64);
+  __syncthreads();
+  TimeCtx c;
+  c.t1 = reinterpret_cast<const cx<double>*>(a.t1) + 16 * (lane >> 4);
+  c.t2 = reinterpret_cast<const cx<double>*>(lds_raw + kLdsT2) + lane;
+  c.post = reinterpret_cast<const cx<double>*>(lds_raw + kLdsPost) + lane;
+  c.plane = lds_raw + kLdsPlanes + wave * kTimePlaneBytes;
+  c.plane_d = reinterpret_cast<double*>(c.plane);
+  c.plane_rd_addr = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)lds_raw + kLdsPlanes +
+                    wave * kTimePlaneBytes + 8u * lane;
+  c.lane = lane;
+  c.partner = (64 - lane) & 63;
+  return c;
+}
+
+__device__ __forceinline__ void fft(cx<double> (&v)[16], const TimeCtx& c) {
+  fft1024<double>(v, c.t1, c.t2, c.plane, c.plane_rd_addr, c.lane);
+}
+
+// Z[1024 - k] for k = lane + 64 r (Z is 1024-periodic)
+__device__ __forceinline__ cx<double> partner_of(const cx<double> (&v)[16], int r, const TimeCtx& c) {
+  cx<double> p{__shfl(v[15 - r].re, c.partner), __shfl(v[15 - r].im, c.partner)};
+  if (c.lane == 0) p = v[(16 - r) & 15];
+  return p;
+}
+
+// even/odd parts (times 2) of the 2048-point spectrum of the real sequence packed into z:
+// 2 E[k] = Z[k] + conj(Z[1024-k]),  2 O[k] = -i (Z[k] - conj(Z[1024-k]))
+__device__ __forceinline__ void even_odd(cx<double> z, cx<double> p, cx<double>& e, cx<double>& o) {
+  e = {z.re + p.re, z.im - p.im};
+  o = {z.im + p.im, p.re - z.re};
+}
+
+// ---------------------------------------------------------------------------------------------
+// auto_correlation (SA:2312-2398)
+// ---------------------------------------------------------------------------------------------
+template <typename TIn>
+__global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a) {
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const TimeCtx c = time_setup(a, lds_raw);
+  const int lane = c.lane;
+  const int wave_global = blockIdx.x * kTimeWaves + (threadIdx.x >> 6);
+  const int wave_stride = gridDim.x * kTimeWaves;
+  const TIn* const pcm = reinterpret_cast<const TIn*>(a.pcm);
+  // TAudioMath::MsToSamples(44100, 0.8f) = 35, (44100, 12.0f) = 529 (float maths, AudioMath.inl:127-130)
+  constexpr int kMinPeriod = 35, kSeekWidth = 529, kMaxSeek = kFft / 2;
+  constexpr int kBig = 1 << 30;
+
+  for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
+    const Chunk ch = a.chunks[ci];
+    const int remaining0 = a.remaining[ci];
+    for (int fi = 0; fi < ch.nframes; ++fi) {
+      const TIn* const x = pcm + ch.sample_off + (int64_t)fi * kHop;
+      int remaining = remaining0 - fi * kHop;          // mData.Size() - n, >= 2048 for an emitted frame
+      double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
+
+      // first rising step in [0, min(remaining, 1024) - 1)  (SA:2328-2341)
+      int start = 0;
+      {
+        const int bound = min(remaining, kMaxSeek) - 1;
+        double v[16];
+        load16(x + 16 * lane, v);
+        double nxt = __shfl_down(v[0], 1);
+        if (lane == 63) nxt = (double)x[kMaxSeek];
+        int first = kBig;
+#pragma unroll
+        for (int i = 15; i >= 0; --i) {
+          const double hi = (i == 15) ? nxt : v[i + 1];
+          if (hi > v[i] && 16 * lane + i < bound) first = 16 * lane + i;
+        }
+        first = wave_min_i(first);
+        if (first != kBig) { start = first; remaining -= first; }
+      }
+      // next rising step after the minimum period (SA:2343-2356)
+      const int seek_off = min(remaining, kMinPeriod);
+      int period = seek_off;
+      {
+        const int bound = min(remaining - seek_off, kMaxSeek) - 1;
+        const TIn* const y = x + start + seek_off;
+        double v[17];
+#pragma unroll
+        for (int i = 0; i < 17; ++i) {
+          const int j = 16 * lane + i;
+          v[i] = (j <= bound) ? (double)y[j] : 0.0;    // y[bound] = x[start + remaining - 1 .. ] at most
+        }
+        int first = kBig;
+#pragma unroll
+        for (int i = 15; i >= 0; --i)
+          if (v[i + 1] > v[i] && 16 * lane + i < bound) first = 16 * lane + i;
+        first = wave_min_i(first);
+        if (first != kBig) period = seek_off + first;
+      }
+      double best = 0.0;
+      if (remaining != 0 && period < remaining) {
+        const int width = min(remaining, kSeekWidth);
+        const TIn* const s = x + start;
+        // r[i] = sum_j s[j] s[j+i] through the 2048-point transform of the zero-padded segment
+        cx<double> v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int j = 2 * (64 * r + lane);
+          v[r] = {0.0, 0.0};
+          if (r < 5) v[r] = {(j < width) ? (double)s[j] : 0.0, (j + 1 < width) ? (double)s[j + 1] : 0.0};
+        }
+        fft(v, c);
+        // power spectrum P[k] = |X[k]|^2, P[1024-k] = |E - w O|^2, then the packed spectrum of the inverse:
+        // Zc = Ec + i Oc, Ec = (P + P')/2, Oc = (P - P')/2 conj(w^k); constant factors dropped (r is used
+        // relative to r[0] only)
+        cx<double> g[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const cx<double> p = partner_of(v, r, c);
+          cx<double> e, o;
+          even_odd(v[r], p, e, o);
+          const cx<double> w = c.post[64 * r];
+          const cx<double> wo = cmul(w, o);
+          const double xr = e.re + wo.re, xi = e.im + wo.im, yr = e.re - wo.re, yi = e.im - wo.im;
+          const double pk = xr * xr + xi * xi, pp = yr * yr + yi * yi;
+          const double ec = pk + pp, h = pk - pp;
+          g[r] = {ec + h * w.im, -(h * w.re)};           // conj(Zc)
+        }
+        fft(g, c);
+        // r[2m] = Re F[m], r[2m+1] = -Im F[m], m = lane + 64 r
+        const double r0 = read_lane<0>(g[0].re);
+        double top = -1.0e300;
+        const int from = period / 2;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+          const int j = 2 * (64 * r + lane);
+          if (j >= from && j < width) top = fmax(top, g[r].re);
+          if (j + 1 >= from && j + 1 < width) top = fmax(top, -g[r].im);
+        }
+        top = wave_max(top);
+        if (r0 != 0.0) top /= r0;                        // Autocorrelation.cpp:97-105
+        best = fmax(0.0, top);
+      }
+      if (lane == 0) rec[a.lay.autocorr] = best;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// f0 + confidence: aubio yinfast on the 2048-sample frame
+// ---------------------------------------------------------------------------------------------
+template <typename TIn>
+struct PairOf;
+template <>
+struct PairOf<float> { using type = float2; };
+template <>
+struct PairOf<double> { using type = double2; };
+
+template <typename TIn>
+__global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a) {
+  using Pair = typename PairOf<TIn>::type;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const TimeCtx c = time_setup(a, lds_raw);
+  const int lane = c.lane;
+  const int wave_global = blockIdx.x * kTimeWaves + (threadIdx.x >> 6);
+  const int wave_stride = gridDim.x * kTimeWaves;
+  const TIn* const pcm = reinterpret_cast<const TIn*>(a.pcm);
+  constexpr int W = kFft / 2;
+  constexpr double kTol = 0.75;                 // MPitchTolerance, SA:62, 801
+  constexpr int kBig = 1 << 30;
+
+  for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
+    const Chunk ch = a.chunks[ci];
+    for (int fi = 0; fi < ch.nframes; ++fi) {
+      const TIn* const x = pcm + ch.sample_off + (int64_t)fi * kHop;
+      double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
+
+      // ---- r_t(tau) = sum_{j<W} x[j] x[j+tau], tau < W: spectra of the frame and of its first half ----
+      cx<double> zx[16], zu[16];
+      {
+        const Pair* src = reinterpret_cast<const Pair*>(x) + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const Pair p = src[64 * r];
+          zx[r] = {(double)p.x, (double)p.y};
+          zu[r] = (r < 8) ? zx[r] : cx<double>{0.0, 0.0};
+        }
+      }
+      fft(zx, c);
+      fft(zu, c);
+      cx<double> g[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const cx<double> px = partner_of(zx, r, c), pu = partner_of(zu, r, c);
+        const cx<double> w = c.post[64 * r];
+        cx<double> e, o;
+        even_odd(zx[r], px, e, o);
+        cx<double> wo = cmul(w, o);
+        const cx<double> X{0.5 * (e.re + wo.re), 0.5 * (e.im + wo.im)};
+        const cx<double> Xp{0.5 * (e.re - wo.re), -0.5 * (e.im - wo.im)};   // X[1024-k] = conj(E - w O)
+        even_odd(zu[r], pu, e, o);
+        wo = cmul(w, o);
+        const cx<double> U{0.5 * (e.re + wo.re), 0.5 * (e.im + wo.im)};
+        const cx<double> Up{0.5 * (e.re - wo.re), -0.5 * (e.im - wo.im)};
+        // C = conj(U) X at k and at 1024-k
+        const cx<double> C{U.re * X.re + U.im * X.im, U.re * X.im - U.im * X.re};
+        const cx<double> Cp{Up.re * Xp.re + Up.im * Xp.im, Up.re * Xp.im - Up.im * Xp.re};
+        // packed spectrum of the inverse: Zc = Ec + i Oc, Ec = (C + conj(C'))/2, Oc = (C - conj(C'))/2 conj(w^k)
+        const cx<double> ec{0.5 * (C.re + Cp.re), 0.5 * (C.im - Cp.im)};
+        const cx<double> d{0.5 * (C.re - Cp.re), 0.5 * (C.im + Cp.im)};
+        const cx<double> oc{d.re * w.re + d.im * w.im, d.im * w.re - d.re * w.im};
+        g[r] = {ec.re - oc.im, -(ec.im + oc.re)};      // conj(Zc)
+      }
+      fft(g, c);
+      // c[2m] = Re F[m] / 1024, c[2m+1] = -Im F[m] / 1024, m = lane + 64 r; tau < 1024 <=> r < 8.
+      // To the blocked layout through the plane.
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int t = 2 * (64 * r + lane);
+        c.plane_d[pad_slot(t)] = g[r].re * (1.0 / 1024.0);
+        c.plane_d[pad_slot(t) + 1] = -g[r].im * (1.0 / 1024.0);
+      }
+      wave_lds_fence();
+      double corr[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) corr[i] = c.plane_d[17 * lane + i];
+      wave_lds_fence();
+
+      // ---- squared-difference terms (pitchyinfast.c:96-117) ----
+      double xa[16], xb[16];
+      load16(x + 16 * lane, xa);
+      load16(x + W + 16 * lane, xb);
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        xa[i] *= xa[i];
+        xb[i] *= xb[i];
+        s0 += xa[i];
+        s1 += xb[i];
+      }
+      s0 = wave_sum(s0);
+      s1 = wave_sum(s1);
+      // sqdiff[tau] = sum_{j<W} x[j+tau]^2 + sum_{j<W} x[j]^2 = 2 s0 + sum_{j<tau} (x[W+j]^2 - x[j]^2)
+      double yin[16], run = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        yin[i] = run;
+        run += xb[i] - xa[i];
+      }
+      const double before = wave_scan_incl(run, lane) - run;
+      // aubio's Ooura back end returns the inverse transform halved (spectral/fft.c:464-476: scale 1/N where
+      // rdft needs 2/N), so "sqdiff - 2 r_t" is sqdiff - r_t in the reference's results
+#pragma unroll
+      for (int i = 0; i < 16; ++i) yin[i] = (2.0 * s0 + (before + yin[i])) - 2.0 * (0.5 * corr[i]);
+
+      // ---- cumulative mean normalisation (pitchyinfast.c:146-153) ----
+      double cum[16];
+      run = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        if (16 * lane + i > 0) run += yin[i];
+        cum[i] = run;
+      }
+      const double cum_before = wave_scan_incl(run, lane) - run;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int tau = 16 * lane + i;
+        const double tmp2 = cum_before + cum[i];
+        yin[i] = (tau == 0) ? 1.0 : ((tmp2 != 0) ? yin[i] * ((double)tau / tmp2) : 1.0);
+      }
+
+      // ---- first dip below the tolerance, else the (last) global minimum (pitchyinfast.c:154-163) ----
+      double nxt = __shfl_down(yin[0], 1);
+      int first = kBig;
+#pragma unroll
+      for (int i = 15; i >= 0; --i) {
+        const int p = 16 * lane + i;
+        const double hi = (i == 15) ? nxt : yin[i + 1];
+        if (p >= 2 && p + 3 < W && yin[i] < kTol && yin[i] < hi) first = p;
+      }
+      first = wave_min_i(first);
+      int pos = first;
+      if (first == kBig) {
+        double m = yin[0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) m = fmin(m, yin[i]);
+        m = wave_min(m);
+        int last = -1;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+          if (yin[i] == m) last = 16 * lane + i;
+        pos = wave_max_i(last);
+        if (pos < 0) pos = 0;
+      }
+      // fvec_quadratic_peak_pos (mathutils.c:494-506) and the confidence read back from the normalised buffer
+      wave_lds_fence();
+#pragma unroll
+      for (int i = 0; i < 16; ++i) c.plane_d[17 * lane + i] = yin[i];
+      wave_lds_fence();
+      double period = (double)pos;
+      if (pos != 0 && pos != W - 1) {
+        const double y0 = c.plane_d[pad_slot(pos - 1)], y1 = c.plane_d[pad_slot(pos)], y2 = c.plane_d[pad_slot(pos + 1)];
+        period = (double)pos + 0.5 * (y0 - y2) / (y0 - 2.0 * y1 + y2);
+      }
+      // o->peak_pos is a uint_t (pitchyinfast.c:38, 160-169); out-of-range casts are undefined there, clamped here
+      int at = (period >= 0.0 && period < (double)W) ? (int)period : (period < 0.0 ? 0 : W - 1);
+      if (!(period == period)) at = 0;
+      const double conf_raw = 1.0 - c.plane_d[pad_slot(at)];
+      wave_lds_fence();
+      double f0 = (period > 0.0) ? (double)kSampleRate / (period + 0.) : 0.0;       // pitch.c:450-462
+      if (au_silent(s0 + s1, kFft, -48.0)) f0 = 0.0;                                 // pitch.c:399-406
+      // SA:886-895: confidence / MMaxPitchConfidenceValue clipped to [0, 1]
+      double conf = conf_raw / 0.25;
+      conf = (conf < 0.0) ? 0.0 : (conf > 1.0 ? 1.0 : conf);
+      if (!(conf == conf)) conf = 0.0;
+      if (lane == 0) {
+        rec[a.lay.f0] = nan_to_zero(f0);
+        rec[a.lay.f0_conf] = conf;
+        // hop silence (SA:865-868) parked in the fail-safe slot for afx_whiten.hip, which replaces it
+        rec[a.lay.f0_safe] = au_silent(s0, kHop, -48.0) ? 1.0 : 0.0;
+      }
+    }
+  }
+}
+
+template <typename K>
+hipError_t raise_lds_limit(K kernel, bool (&done)[16]) {
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       kTimeLdsBytes);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16) done[dev] = true;
+  }
+  return hipSuccess;
+}
+
+int time_grid(int n_chunks, int waves) {
+  int cus = 256;
+  int dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  const int want = (n_chunks + waves - 1) / waves;
+  return want < cus ? (want < 1 ? 1 : want) : cus;
+}
+
+}  // namespace
+
+hipError_t launch_hop(const TimeArgs& a, hipStream_t stream) {
+  if (a.n_chunks <= 0) return hipSuccess;
+  const int grid = (a.n_chunks + 3) / 4 < 2048 ? (a.n_chunks + 3) / 4 : 2048;
+  if (a.pcm_dtype == 0) hipLaunchKernelGGL(hop_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(hop_kernel<double>, dim3(grid), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_acorr(const TimeArgs& a, hipStream_t stream) {
+  if (a.n_chunks <= 0) return hipSuccess;
+  static bool done_f[16] = {}, done_d[16] = {};
+  const int grid = time_grid(a.n_chunks, kTimeWaves);
+  hipError_t e;
+  if (a.pcm_dtype == 0) {
+    if ((e = raise_lds_limit(acorr_kernel<float>, done_f)) != hipSuccess) return e;
+    hipLaunchKernelGGL(acorr_kernel<float>, dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+  } else {
+    if ((e = raise_lds_limit(acorr_kernel<double>, done_d)) != hipSuccess) return e;
+    hipLaunchKernelGGL(acorr_kernel<double>, dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+  }
+  return hipGetLastError();
+}
+
+hipError_t launch_pitch(const TimeArgs& a, hipStream_t stream) {
+  if (a.n_chunks <= 0) return hipSuccess;
+  static bool done_f[16] = {}, done_d[16] = {};
+  const int grid = time_grid(a.n_chunks, kTimeWaves);
+  hipError_t e;
+  if (a.pcm_dtype == 0) {
+    if ((e = raise_lds_limit(pitch_kernel<float>, done_f)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pitch_kernel<float>, dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+  } else {
+    if ((e = raise_lds_limit(pitch_kernel<double>, done_d)) != hipSuccess) return e;
+    hipLaunchKernelGGL(pitch_kernel<double>, dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--buffers", type=int, default=64, help="10k-frame buffers per GPU per step")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--mask", default="c2", choices=["c2", "stats", "all"])
+    ap.add_argument("--mask", default="c2", choices=["c2", "stats", "all", "frame", "neighbours"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
                     help="c2: --buffers x 10k-frame buffers (headline); c3: 1000 synthetic 2.0 s files, full "
                          "low-level set + per-file statistics (BASELINE.json configs[2])")
@@ -158,13 +158,13 @@ def main():
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
     mask = {"c2": afx.D_C2, "stats": afx.D_MFCC | afx.D_SPECTRAL_STATS,
-            "all": afx.D_ALL_LOW_LEVEL}[args.mask]
+            "all": afx.D_ALL_LOW_LEVEL, "frame": afx.D_ALL_PER_FRAME, "neighbours": afx.D_NEIGHBOURS}[args.mask]
     precision = afx.PRECISION_F64 if args.precision == "f64" else afx.PRECISION_F32
     # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)
     device = int(os.environ.get("AFX_BENCH_DEVICE", local))
     plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0)
     if args.workload == "c3":
-        mask = afx.D_ALL_LOW_LEVEL | afx.D_STATISTICS
+        mask = (afx.D_ALL_PER_FRAME if args.mask in ("frame", "neighbours") else afx.D_ALL_LOW_LEVEL) | afx.D_STATISTICS
         bufs = make_c3_files(1000, 1234 + rank)
     else:
         bufs = make_buffers(args.buffers, 1234 + rank)

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define AFX_VERSION 1
+#define AFX_VERSION 2
 
 /* ---- status codes (replace TReadableException on this path, SampleAnalyser.cpp:397-408) ---- */
 enum {
@@ -69,9 +69,21 @@ enum {
   AFX_D_STATISTICS = 1u << 14,       /* additionally reduce every selected series of every buffer to
                                         the 13 values of TStatistics::Calc (Statistics.cpp:12-90),
                                         as TSampleAnalyser::CalcStatistics does (SampleAnalyser.cpp:2402) */
+  /* the loop's neighbours of the spectral set: time-domain and whitened-spectrum
+   * descriptors of the same frames, SampleAnalyser.cpp:849-927, 942-964 */
+  AFX_D_AMPLITUDE_SILENCE = 1u << 15,    /* amplitude_silence   [F]  :865-868 (aubio_silence_detection, -48 dB) */
+  AFX_D_AMPLITUDE_ENVELOPE = 1u << 16,   /* amplitude_envelope  [F]  :1787-1804 (TEnvelopeDetector kFast, 8 ms) */
+  AFX_D_SPECTRAL_COMPLEXITY = 1u << 17,  /* spectral_complexity [F]  :849-862, 1937-1947 (adaptive whitening,
+                                            peak spectrum, peaks inside the analysis range)  */
+  AFX_D_AUTO_CORRELATION = 1u << 18,     /* auto_correlation    [F]  :2312-2398 */
+  AFX_D_F0 = 1u << 19,                   /* f0, f0_confidence, failsafe_f0 [F] each  :876-917 (aubio yinfast) */
+  AFX_D_SPECTRAL_INHARMONICITY = 1u << 20, /* spectral_inharmonicity [F]  :1951-1971 */
+  AFX_D_TRISTIMULUS = 1u << 21,          /* tristimulus1..3     [F] each  :1975-2003 */
   AFX_D_C2 = AFX_D_MFCC,
   AFX_D_SPECTRAL_STATS = 0x1FEu,     /* bits 1..8 */
-  AFX_D_ALL_LOW_LEVEL = 0x1FFFu      /* everything except the raw magnitudes */
+  AFX_D_ALL_LOW_LEVEL = 0x1FFFu,     /* the spectral set of SURVEY 8(a), everything except the raw magnitudes */
+  AFX_D_NEIGHBOURS = 0x3F8000u,      /* bits 15..21 */
+  AFX_D_ALL_PER_FRAME = 0x3F9FFFu    /* AFX_D_ALL_LOW_LEVEL | AFX_D_NEIGHBOURS */
 };
 #define AFX_NUM_CEPSTRUM 14 /* kNumberOfCepstrumCoefficients, SampleDescriptors.h:464 */
 #define AFX_NUM_BANDS 28    /* kNumberOfSpectrumBands                                  */
@@ -135,6 +147,17 @@ typedef struct {
   double* amplitude_peak;    /* [F]       */
   double* amplitude_rms;     /* [F]       */
   double* magnitude;         /* [F][1024] */
+  double* amplitude_silence; /* [F], 1.0 = silent hop */
+  double* amplitude_envelope;
+  double* spectral_complexity;
+  double* auto_correlation;
+  double* f0;                /* Hz, 0 when the frame is silent or no period was found */
+  double* f0_confidence;     /* 0..1 */
+  double* failsafe_f0;
+  double* spectral_inharmonicity;
+  double* tristimulus1;
+  double* tristimulus2;
+  double* tristimulus3;
   int64_t* frame_offset;     /* [n_bufs+1], optional */
   int32_t* buf_status;       /* [n_bufs], optional: AFX_OK or AFX_ERR_BAD_BUFFER (one bad buffer
                                 does not fail the batch, cf. SampleAnalyser.cpp:368-408)      */
@@ -169,6 +192,17 @@ typedef struct {
   double* spectral_contrast; /* [n_bufs][13]     */
   double* amplitude_peak;
   double* amplitude_rms;
+  double* amplitude_silence;
+  double* amplitude_envelope;
+  double* spectral_complexity;
+  double* auto_correlation;
+  double* f0;
+  double* f0_confidence;
+  double* failsafe_f0;
+  double* spectral_inharmonicity;
+  double* tristimulus1;
+  double* tristimulus2;
+  double* tristimulus3;
   int32_t* stats_status;     /* [n_bufs], optional */
 } afx_stats_out;
 

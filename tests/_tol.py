@@ -53,3 +53,16 @@ def check_mag(got, ref, rel_to_max=1e-12, what=""):
     scale = np.maximum(ref.max(axis=-1, keepdims=True), 1e-300)
     err = np.abs(got - ref) / scale
     assert np.all(err <= rel_to_max), f"{what}mag: max err/max-bin = {err.max():.3e} > {rel_to_max}"
+
+
+# ---- neighbours of the spectral set: (rtol, atol) against the oracle / reference goldens ----
+# Flags and counts are exact.  f0 / confidence come from a 1024-lag correlation computed through FFTs on
+# the GPU and by direct summation in the oracle (aubio: FFT); the values agree to ~1e-12 of the frame
+# energy, the period after parabolic interpolation to ~1e-9.
+NEIGH_TOL = {
+    "amplitude_silence": (0.0, 0.0), "amplitude_envelope": (1e-9, 1e-15),
+    "spectral_complexity": (0.0, 0.0), "auto_correlation": (1e-6, 1e-9),
+    "f0": (1e-6, 1e-9), "f0_confidence": (1e-6, 1e-7), "failsafe_f0": (1e-6, 1e-9),
+    "spectral_inharmonicity": (0.0, 0.0), "tristimulus1": (0.0, 0.0), "tristimulus2": (0.0, 0.0),
+    "tristimulus3": (0.0, 0.0),
+}

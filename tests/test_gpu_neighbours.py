@@ -1,0 +1,190 @@
+"""GPU parity of the loop's stateful neighbours: silence flag, envelope, whitening ->
+peak spectrum -> spectral complexity, autocorrelation, yinfast f0 / confidence / fail-safe f0, and the
+descriptors the reference's data flow makes identically zero -- through the C-ABI, against the goldens
+produced by the reference's own aubio / TEnvelopeDetector / TAutocorrelation / LibXtract objects and
+against the oracle on seeded batches."""
+import os
+
+import numpy as np
+import pytest
+
+import afec_amd as afx
+from tests import _oracle, _tol
+from tests._oracle import NEIGH_FIELDS, Oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+# an impulse has an exactly flat spectrum: the whitened spectrum's local maxima are rounding noise
+ILL_CONDITIONED = {("impulse", "spectral_complexity")}
+
+
+@pytest.fixture(scope="module")
+def plan():
+    p = afx.Plan(max_analysis_ms=0)
+    yield p
+    p.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle()
+
+
+def neighbour_names():
+    z = np.load(os.path.join(GOLD, "neighbours.npz"))
+    return sorted(k[4:] for k in z.files if k.startswith("ref_"))
+
+
+def neighbour_input(name):
+    z = np.load(os.path.join(GOLD, "neighbours.npz"))
+    if "in_" + name in z.files:
+        return z["in_" + name]
+    return np.load(os.path.join(GOLD, "frames.npz"))["in_" + name]
+
+
+def compare(res, ref, what, skip=()):
+    for field, col in NEIGH_FIELDS.items():
+        if field not in res or field in skip:
+            continue
+        rtol, atol = _tol.NEIGH_TOL[field]
+        _tol.check(field, res[field], ref[:, col], rtol, atol, what=what)
+
+
+@pytest.mark.parametrize("name", neighbour_names())
+def test_golden_neighbours(plan, name):
+    x = neighbour_input(name)            # float32, fed bit-identically to both sides
+    ref = np.load(os.path.join(GOLD, "neighbours.npz"))["ref_" + name]
+    res = plan.extract([x], afx.D_NEIGHBOURS)
+    assert res["frame_offset"][-1] == ref.shape[0]
+    compare(res, ref, name + " ", skip={f for (n, f) in ILL_CONDITIONED if n == name})
+
+
+def seeded_buffers(rng):
+    sr = 44100.0
+    out = []
+    for n, kind in [(2048 + 1024 * 7, "noise"), (5000, "tone"), (2048, "mix"), (40000, "notes"), (1500, "short"),
+                    (2048 + 1024 * 30 + 333, "am"), (9000, "quiet")]:
+        t = np.arange(n) / sr
+        if kind == "noise":
+            x = rng.uniform(-1, 1, n)
+        elif kind == "tone":
+            x = 0.8 * np.sin(2 * np.pi * 523.25 * t + 0.3)
+        elif kind == "mix":
+            x = 0.5 * np.sin(2 * np.pi * 220 * t) + 0.2 * rng.standard_normal(n)
+        elif kind == "notes":
+            x = np.zeros(n)
+            for k, f0 in enumerate([130.8, 311.1, 87.3, 440.0]):
+                a = k * 10000
+                m = min(9000, n - a)
+                tt = np.arange(m) / sr
+                x[a:a + m] += 0.6 * np.exp(-tt / 0.08) * (np.sin(2 * np.pi * f0 * tt) + 0.5 * np.sin(4 * np.pi * f0 * tt))
+        elif kind == "am":
+            x = 0.7 * rng.standard_normal(n) * (0.5 + 0.5 * np.sin(2 * np.pi * 2.0 * t)) ** 4
+        elif kind == "quiet":
+            x = 2e-3 * rng.standard_normal(n)
+        else:
+            x = rng.uniform(-1, 1, n)
+        out.append(x)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_ragged_batch_against_oracle(plan, oracle, dtype):
+    """several buffers of different lengths (one below a frame) in one call; every neighbour, both PCM types"""
+    rng = np.random.default_rng(11)
+    bufs = [b.astype(dtype) for b in seeded_buffers(rng)]
+    res = plan.extract(bufs, afx.D_NEIGHBOURS)
+    ref = np.concatenate([oracle.run_neighbours(b.astype(np.float64)) for b in bufs])
+    assert res["frame_offset"][-1] == ref.shape[0]
+    compare(res, ref, f"{np.dtype(dtype).name} ")
+
+
+def test_neighbours_together_with_the_spectral_set(plan, oracle):
+    """mask = everything per frame: the spectral descriptors are unchanged by the extra kernels"""
+    rng = np.random.default_rng(12)
+    bufs = [b.astype(np.float32) for b in seeded_buffers(rng)[:4]]
+    res = plan.extract(bufs, afx.D_ALL_PER_FRAME)
+    only = plan.extract(bufs, afx.D_ALL_LOW_LEVEL)
+    for k, v in only.items():
+        np.testing.assert_array_equal(res[k], v, err_msg=k)
+    ref = np.concatenate([oracle.run_neighbours(b.astype(np.float64)) for b in bufs])
+    compare(res, ref, "all ")
+
+
+@pytest.mark.parametrize("bit,fields", [
+    (afx.D_AMPLITUDE_SILENCE, ["amplitude_silence"]), (afx.D_AMPLITUDE_ENVELOPE, ["amplitude_envelope"]),
+    (afx.D_SPECTRAL_COMPLEXITY, ["spectral_complexity"]), (afx.D_AUTO_CORRELATION, ["auto_correlation"]),
+    (afx.D_F0, ["f0", "f0_confidence", "failsafe_f0"]), (afx.D_SPECTRAL_INHARMONICITY, ["spectral_inharmonicity"]),
+    (afx.D_TRISTIMULUS, ["tristimulus1", "tristimulus2", "tristimulus3"])])
+def test_each_neighbour_bit_alone(plan, oracle, bit, fields):
+    rng = np.random.default_rng(13)
+    bufs = [b.astype(np.float32) for b in seeded_buffers(rng)[:3]]
+    res = plan.extract(bufs, bit)
+    ref = np.concatenate([oracle.run_neighbours(b.astype(np.float64)) for b in bufs])
+    assert sorted(k for k in res if k not in ("frame_offset", "buf_status")) == sorted(fields)
+    compare(res, ref, "single bit ")
+
+
+def test_whitening_follower_is_per_buffer_state(plan):
+    """the follower restarts with every buffer (a new aubio object per file, SampleAnalyser.cpp:805-809): a
+    buffer analysed alone and behind a loud one gives the same complexity series"""
+    rng = np.random.default_rng(14)
+    loud = rng.uniform(-1, 1, 2048 + 1024 * 12).astype(np.float32)
+    soft = (0.01 * rng.standard_normal(2048 + 1024 * 12)).astype(np.float32)
+    alone = plan.extract([soft], afx.D_SPECTRAL_COMPLEXITY)["spectral_complexity"]
+    both = plan.extract([loud, soft], afx.D_SPECTRAL_COMPLEXITY)
+    np.testing.assert_array_equal(both["spectral_complexity"][both["frame_offset"][1]:], alone)
+
+
+def test_autocorrelation_looks_past_the_last_frame_when_the_buffer_has_more(plan, oracle):
+    """CalcAutoCorrelation's second rising-slope search may read up to 33 samples past the frame
+    (remaining = size - n, SampleAnalyser.cpp:943): a falling ramp after a late first rise forces it"""
+    n = 2048 + 1024 + 700                       # 2 frames, 700 samples beyond the last one
+    x = np.linspace(1.0, -1.0, n)               # falling everywhere, except for two upward steps:
+    x[2025:] += 0.01                            # sample 1000 of the last frame (its first rise), and
+    x[3077:] += 0.01                            # 5 samples past that frame's end (found by the second search)
+    res = plan.extract([x.astype(np.float64)], afx.D_AUTO_CORRELATION)
+    ref = oracle.run_neighbours(x)
+    _tol.check("auto_correlation", res["auto_correlation"], ref[:, NEIGH_FIELDS["auto_correlation"]], 1e-6, 1e-9)
+    # and the same frames without the tail give another answer for the last frame (the step is not seen)
+    cut = oracle.run_neighbours(x[:3072])
+    assert abs(cut[1, NEIGH_FIELDS["auto_correlation"]] - ref[1, NEIGH_FIELDS["auto_correlation"]]) > 1e-6
+
+
+def test_statistics_of_the_neighbour_series(plan, oracle):
+    rng = np.random.default_rng(15)
+    bufs = [b.astype(np.float32) for b in seeded_buffers(rng)[:4]]
+    mask = afx.D_NEIGHBOURS | afx.D_STATISTICS
+    b = plan.batch(bufs, mask)
+    b.run()
+    res, st = b.fetch(), b.fetch_statistics()
+    b.close()
+    off = res["frame_offset"]
+    for i in range(len(bufs)):
+        for field in NEIGH_FIELDS:
+            series = res[field][off[i]:off[i + 1]]
+            want = _oracle.calc_statistics(series)
+            got = st[field][i]
+            if off[i + 1] - off[i] >= 2:
+                # the GPU series itself is the input of both sides: only the reduction is compared
+                skip_ill = abs(series.sum()) < 1e-6 * np.abs(series).sum() if series.size else True
+                for j, name in enumerate(afx.STAT_NAMES):
+                    if skip_ill and name in ("centroid", "spread", "skewness", "kurtosis", "flatness"):
+                        continue
+                    assert abs(got[j] - want[j]) <= 1e-9 * abs(want[j]) + 1e-12, (i, field, name, got[j], want[j])
+
+
+def test_from_raw_front_end_feeds_the_neighbours(plan, oracle):
+    rng = np.random.default_rng(16)
+    t = np.arange(30000) / 44100.0
+    pcm = (0.4 * np.sin(2 * np.pi * 330 * t) * np.exp(-t / 0.2) + 0.01 * rng.standard_normal(t.size))
+    raw = np.round(pcm * 20000).astype(np.int16)
+    b, infos = plan.batch_from_raw([(raw, 1)], afx.D_NEIGHBOURS)
+    b.run()
+    res = b.fetch()
+    mono, info = _oracle.load_sample(raw, 1)
+    b.close()
+    ref = oracle.run_neighbours(mono)
+    assert res["frame_offset"][-1] == ref.shape[0]
+    compare(res, ref, "from_raw ")

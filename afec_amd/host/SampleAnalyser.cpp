@@ -119,6 +119,9 @@ template struct TFramedVectorData<14>;
 template struct TFramedVectorData<28>;
 
 void TSampleDescriptors::CalcStatistics() {
+  for (TFramedScalarData* p : {&mAmplitudeSilence, &mAmplitudeEnvelope, &mF0, &mF0Confidence, &mFailSafeF0, &mAutoCorrelation,
+                               &mSpectralComplexity, &mSpectralInharmonicity, &mTristimulus1, &mTristimulus2, &mTristimulus3})
+    p->CalcStatistics();
   for (TFramedScalarData* p : {&mAmplitudePeak, &mAmplitudeRms, &mSpectralRms, &mSpectralCentroid, &mSpectralRolloff,
                                &mSpectralSpread, &mSpectralSkewness, &mSpectralKurtosis, &mSpectralFlatness,
                                &mSpectralContrast, &mSpectralFlux})
@@ -164,7 +167,8 @@ std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
   const size_t F = (size_t)Total;
   std::vector<double> Mfcc(F * 14), Bands(F * 28), SubRms(F * 14), SubFlat(F * 14), SubFlux(F * 14), SubCplx(F * 14),
       SubContrast(F * 14), Rms(F), Cen(F), Spr(F), Skew(F), Kurt(F), Roll(F), Flat(F), Flux(F), Contrast(F), Peak(F),
-      ARms(F);
+      ARms(F), Silence(F), Envelope(F), F0(F), F0Conf(F), F0Safe(F), AutoCorr(F), Complexity(F), Inharm(F), Tri1(F), Tri2(F),
+      Tri3(F);
   std::vector<int64_t> Offset((size_t)n + 1);
   std::vector<int32_t> BufStatus((size_t)n);
   afx_out Out = {};
@@ -174,8 +178,12 @@ std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
   Out.spectral_spread = Spr.data(); Out.spectral_skewness = Skew.data(); Out.spectral_kurtosis = Kurt.data();
   Out.spectral_rolloff = Roll.data(); Out.spectral_flatness = Flat.data(); Out.spectral_flux = Flux.data();
   Out.spectral_contrast = Contrast.data(); Out.amplitude_peak = Peak.data(); Out.amplitude_rms = ARms.data();
+  Out.amplitude_silence = Silence.data(); Out.amplitude_envelope = Envelope.data(); Out.f0 = F0.data();
+  Out.f0_confidence = F0Conf.data(); Out.failsafe_f0 = F0Safe.data(); Out.auto_correlation = AutoCorr.data();
+  Out.spectral_complexity = Complexity.data(); Out.spectral_inharmonicity = Inharm.data();
+  Out.tristimulus1 = Tri1.data(); Out.tristimulus2 = Tri2.data(); Out.tristimulus3 = Tri3.data();
   Out.frame_offset = Offset.data(); Out.buf_status = BufStatus.data();
-  const int Status = afx_extract_batch(mpPlan, Buffers.data(), n, AFX_D_ALL_LOW_LEVEL, &Out);
+  const int Status = afx_extract_batch(mpPlan, Buffers.data(), n, AFX_D_ALL_PER_FRAME, &Out);
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
 
   std::vector<TSampleDescriptors> Results((size_t)n);
@@ -195,6 +203,10 @@ std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
     Fill(R.mSpectralSkewness, &Skew[f0], nf); Fill(R.mSpectralKurtosis, &Kurt[f0], nf);
     Fill(R.mSpectralRolloff, &Roll[f0], nf); Fill(R.mSpectralFlatness, &Flat[f0], nf); Fill(R.mSpectralFlux, &Flux[f0], nf);
     Fill(R.mSpectralContrast, &Contrast[f0], nf); Fill(R.mAmplitudePeak, &Peak[f0], nf); Fill(R.mAmplitudeRms, &ARms[f0], nf);
+    Fill(R.mAmplitudeSilence, &Silence[f0], nf); Fill(R.mAmplitudeEnvelope, &Envelope[f0], nf); Fill(R.mF0, &F0[f0], nf);
+    Fill(R.mF0Confidence, &F0Conf[f0], nf); Fill(R.mFailSafeF0, &F0Safe[f0], nf); Fill(R.mAutoCorrelation, &AutoCorr[f0], nf);
+    Fill(R.mSpectralComplexity, &Complexity[f0], nf); Fill(R.mSpectralInharmonicity, &Inharm[f0], nf);
+    Fill(R.mTristimulus1, &Tri1[f0], nf); Fill(R.mTristimulus2, &Tri2[f0], nf); Fill(R.mTristimulus3, &Tri3[f0], nf);
     R.CalcStatistics();
   }
   return Results;

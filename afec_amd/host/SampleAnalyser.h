@@ -45,7 +45,9 @@ struct TFramedVectorData {
 struct TSampleDescriptors {
   enum { kNumberOfSpectrumSubBands = 14, kNumberOfSpectrumBands = 28, kNumberOfCepstrumCoefficients = 14 };
 
-  TFramedScalarData mAmplitudePeak, mAmplitudeRms;
+  TFramedScalarData mAmplitudeSilence, mAmplitudePeak, mAmplitudeRms, mAmplitudeEnvelope;
+  TFramedScalarData mF0, mF0Confidence, mFailSafeF0, mAutoCorrelation;
+  TFramedScalarData mSpectralComplexity, mSpectralInharmonicity, mTristimulus1, mTristimulus2, mTristimulus3;
   TFramedScalarData mSpectralRms, mSpectralCentroid, mSpectralRolloff, mSpectralSpread, mSpectralSkewness,
       mSpectralKurtosis, mSpectralFlatness, mSpectralContrast, mSpectralFlux;
   TFramedVectorData<kNumberOfSpectrumSubBands> mSpectralRmsBands, mSpectralFlatnessBands, mSpectralFluxBands,

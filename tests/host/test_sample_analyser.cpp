@@ -88,6 +88,24 @@ static int TestAnalyse() {
       CHECK_EQUAL_EPSILON(R.mSpectralFlux.mValues[f], r[AFXO_FLUX], 1e-4 * std::fabs(r[AFXO_FLUX]) + 1e-7);
       CHECK(R.mAmplitudePeak.mValues[f] == r[AFXO_AMP_PEAK]);
     }
+    // the loop's neighbours
+    {
+      std::vector<double> nrec((size_t)nf * AFXN_RECORD);
+      afx_oracle_run_neighbours(o, Inputs[i]->data(), (int64_t)Inputs[i]->size(), 1, nrec.data());
+      CHECK((int64_t)R.mF0.mValues.size() == nf);
+      for (int64_t f = 0; f < nf; ++f) {
+        const double* r = &nrec[(size_t)f * AFXN_RECORD];
+        CHECK(R.mAmplitudeSilence.mValues[f] == r[AFXN_SILENCE]);
+        CHECK_EQUAL_EPSILON(R.mAmplitudeEnvelope.mValues[f], r[AFXN_ENVELOPE], 1e-9 * r[AFXN_ENVELOPE]);
+        CHECK_EQUAL_EPSILON(R.mF0.mValues[f], r[AFXN_F0], 1e-6 * r[AFXN_F0] + 1e-9);
+        CHECK_EQUAL_EPSILON(R.mF0Confidence.mValues[f], r[AFXN_F0_CONF], 1e-6);
+        CHECK_EQUAL_EPSILON(R.mFailSafeF0.mValues[f], r[AFXN_F0_FAILSAFE], 1e-6 * r[AFXN_F0_FAILSAFE] + 1e-9);
+        CHECK_EQUAL_EPSILON(R.mAutoCorrelation.mValues[f], r[AFXN_AUTOCORR], 1e-8);
+        CHECK(R.mSpectralComplexity.mValues[f] == r[AFXN_COMPLEXITY]);
+        CHECK(R.mSpectralInharmonicity.mValues[f] == 0.0 && R.mTristimulus1.mValues[f] == 0.0 &&
+              R.mTristimulus2.mValues[f] == 0.0 && R.mTristimulus3.mValues[f] == 0.0);
+      }
+    }
     // per-file statistics of one series against the oracle's TStatistics::Calc
     std::vector<double> series((size_t)nf);
     for (int64_t f = 0; f < nf; ++f) series[(size_t)f] = rec[(size_t)f * AFXO_RECORD + AFXO_CENTROID];

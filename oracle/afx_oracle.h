@@ -77,8 +77,9 @@ double afx_oracle_lin_to_db(double v);
 void afx_oracle_calc_statistics(const double* x, int n, double* out13);
 
 /* ---- LoadSample front end (SampleAnalyser.cpp:484-718) on already-decoded interleaved PCM ----
- * PARITY UNPINNED for this function: SampleAnalyser.cpp does not build here (aubio, Shark, CoreTypes)
- * and the reference's tests hold no value-level fixture for it; it is a line-by-line restatement.
+ * PINNED against oracle/_ref/ref_driver `load` (tests/golden/load.npz, bit-exact): SampleAnalyser.cpp itself
+ * does not build here (Shark, LightGBM, CoreTypes), so the driver restates the member's flow around the
+ * reference's own TSampleConverter conversions, TMathT<float>::GetMinMax, TAudioMath::DbToLin and constants.
  * format: 0 = int16, 1 = packed little-endian int24, 2 = float32 (the reference's decoders turn all
  * of them into "16-bit floats", CoreFileFormats/Export/SampleConverter.h:446-449, 474-486, 529-533). */
 typedef struct {

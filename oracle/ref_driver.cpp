@@ -15,6 +15,7 @@
 //   ref_driver tables  <out.bin>                 window[2048] + mel[14][1024] doubles
 //   ref_driver frames  <in.bin> <out.bin> [cap]  per-frame records (see kRecord)
 //   ref_driver neighbours <in.bin> <out.bin> [cap]  per-frame records of the stateful neighbours (kNeigh)
+//   ref_driver load    <in.bin> <out.bin>        LoadSample normalisation front end (SampleAnalyser.cpp:484-718)
 //   ref_driver time    <n_frames> <seed>         C2 subset timing (STFT + MFCC), prints frames/s
 //
 // in.bin : int64 n_bufs ; per buffer: int64 n_samples, double[n_samples]
@@ -36,6 +37,9 @@ extern "C" {
 #include "AudioTypes/Source/OouraFFT8g.h"
 #include "AudioTypes/Export/AudioMath.h"
 #include "FeatureExtraction/Export/Statistics.h"
+#include "CoreTypes/Export/Array.h"
+#include "CoreFileFormats/Export/SampleConverter.h"
+#include "AudioTypes/Export/AudioTypes.h"
 #include "AudioTypes/Export/Envelopes.h"
 #include "FeatureExtraction/Source/Autocorrelation.h"
 extern "C" {
@@ -402,6 +406,80 @@ static int CmdNeighbours(const char* in, const char* outp, bool cap) {
   return 0;
 }
 
+// ---- LoadSample front end, SampleAnalyser.cpp:484-718 ----
+// The member body (decoder plumbing, TArray/TList buffers, logging) does not link here; its flow is restated
+// on already-decoded interleaved PCM, with the reference's own TSampleConverter conversions
+// (SampleConverter.h:446-449, 474-486, 529-533), TMathT<float>::GetMinMax, TAudioMath::DbToLin and constants.
+// in.bin : int32 format (0 int16, 1 packed int24, 2 float32), int32 channels, int64 frames, raw samples
+// out.bin: float peak, float rms, int32 data_offset, int32 lead, int32 trail, int32 pad, int64 n, double[n]
+static int CmdLoad(const char* in, const char* outp) {
+  FILE* fi = fopen(in, "rb"); if (!fi) return 1;
+  int32_t format = 0, channels = 0; int64_t frames = 0;
+  if (fread(&format, 4, 1, fi) != 1 || fread(&channels, 4, 1, fi) != 1 || fread(&frames, 8, 1, fi) != 1) return 1;
+  const size_t bps = format == 0 ? 2 : (format == 1 ? 3 : 4);
+  std::vector<unsigned char> raw((size_t)frames * channels * bps);
+  if (!raw.empty() && fread(raw.data(), 1, raw.size(), fi) != raw.size()) return 1;
+  fclose(fi);
+  // decoders hand "16-bit floats" per channel (WaveFile.cpp:384-410)
+  std::vector<std::vector<float> > chan((size_t)channels, std::vector<float>((size_t)frames));
+  for (int64_t n = 0; n < frames; ++n)
+    for (int c = 0; c < channels; ++c) {
+      const unsigned char* p = raw.data() + ((size_t)n * channels + c) * bps;
+      float v;
+      if (format == 0) { TInt16 s; memcpy(&s, p, 2); v = TSampleConverter::S16BitSignedTo16BitFloat(s); }
+      else if (format == 1) { TSampleConverter::T24Pack t; t.mFirst = (TInt8)p[0]; t.mSecond = (TInt8)p[1]; t.mThird = (TInt8)p[2];
+                              v = TSampleConverter::S24BitTo16BitFloat(t); }
+      else { float f; memcpy(&f, p, 4); v = TSampleConverter::S0To1FloatTo16BitFloat(f); }
+      chan[(size_t)c][(size_t)n] = v;
+    }
+  // mono mix-down (SampleAnalyser.cpp:534-556)
+  static const float sScaleFactor = M16BitSampleRange / 2.0f;
+  int NumberOfSampleChannels = channels;
+  const int NumberOfSampleFrames = (int)frames;
+  if (NumberOfSampleChannels > 1) {
+    float* pDestMonoBuffer = chan[0].data();
+    const float MixDownScaling = 1.0f / (float)NumberOfSampleChannels;
+    for (int n = 0; n < NumberOfSampleFrames; ++n) {
+      for (int c = 1; c < NumberOfSampleChannels; ++c) pDestMonoBuffer[n] += chan[(size_t)c][(size_t)n];
+      pDestMonoBuffer[n] *= MixDownScaling;
+    }
+    NumberOfSampleChannels = 1;
+  }
+  std::vector<float>& Buffer = chan[0];
+  // rms, peak, amplification (SampleAnalyser.cpp:610-640)
+  double RmsValue = 0.0;
+  for (int n = 0; n < NumberOfSampleFrames; ++n) RmsValue += TMathT<double>::Square(Buffer[(size_t)n] / sScaleFactor);
+  const float Rms = (float)MMin(1.0, ::sqrt(RmsValue / (NumberOfSampleChannels * NumberOfSampleFrames)));
+  float Min = Buffer[0], Max = Buffer[0];
+  TMathT<float>::GetMinMax(Min, Max, 0, NumberOfSampleFrames, Buffer.data());
+  const double MaxAmplitude = (double)MMax(TMathT<float>::Abs(Min), TMathT<float>::Abs(Max));
+  const float Peak = (float)MMin(1.0, MaxAmplitude / sScaleFactor);
+  const double Amplification = (MaxAmplitude > MEpsilon) ? sScaleFactor / MaxAmplitude : 1.0;
+  // silence trim (SampleAnalyser.cpp:646-670)
+  static const double sSilenceFloor = sScaleFactor * TAudioMath::DbToLin(-48.0);
+  int Lead = 0;
+  for (int f = 0; f < NumberOfSampleFrames; ++f, ++Lead)
+    if (TMathT<double>::Abs(Amplification * Buffer[(size_t)f]) > sSilenceFloor) break;
+  int Trail = 0;
+  for (int f = NumberOfSampleFrames - 1; f > Lead; --f, ++Trail)
+    if (TMathT<double>::Abs(Amplification * Buffer[(size_t)f]) > sSilenceFloor) break;
+  // padding (SampleAnalyser.cpp:679-718)
+  const int Audible = NumberOfSampleFrames - Lead - Trail;
+  int EndFrameOffset = 0;
+  if ((Audible % kFft) < kFft / 2) EndFrameOffset += kFft / 2;
+  int StartFrameOffset = 0;
+  if (Audible + EndFrameOffset < kFft) StartFrameOffset = kFft - Audible - EndFrameOffset;
+  std::vector<double> data((size_t)(Audible + StartFrameOffset + EndFrameOffset), 0.0);
+  const double FinalScaling = (double)Amplification / sScaleFactor;
+  for (int n = 0; n < Audible; ++n) data[(size_t)(n + StartFrameOffset)] = Buffer[(size_t)(n + Lead)] * FinalScaling;
+  FILE* fo = fopen(outp, "wb"); if (!fo) return 1;
+  const int32_t off = -Lead + StartFrameOffset, lead = Lead, trail = Trail, pad = 0; const int64_t n = (int64_t)data.size();
+  fwrite(&Peak, 4, 1, fo); fwrite(&Rms, 4, 1, fo); fwrite(&off, 4, 1, fo); fwrite(&lead, 4, 1, fo); fwrite(&trail, 4, 1, fo);
+  fwrite(&pad, 4, 1, fo); fwrite(&n, 8, 1, fo); fwrite(data.data(), 8, data.size(), fo);
+  fclose(fo);
+  return 0;
+}
+
 // C2 subset timing: window -> FFT -> magnitude -> xtract_mfcc on uniform noise.
 static int CmdTime(int64_t nframes, unsigned seed) {
   TRef R;
@@ -429,7 +507,8 @@ int main(int argc, char** argv) {
   if (argc >= 4 && !strcmp(argv[1], "frames")) return CmdFrames(argv[2], argv[3], argc >= 5 && atoi(argv[4]) != 0);
   if (argc >= 4 && !strcmp(argv[1], "neighbours")) return CmdNeighbours(argv[2], argv[3], argc >= 5 && atoi(argv[4]) != 0);
   if (argc >= 2 && !strcmp(argv[1], "peakstest")) return CmdPeaksTest();
+  if (argc >= 4 && !strcmp(argv[1], "load")) return CmdLoad(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "time")) return CmdTime(atoll(argv[2]), (unsigned)atoi(argv[3]));
-  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|peakstest|time ...\n");
+  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|load|peakstest|time ...\n");
   return 2;
 }

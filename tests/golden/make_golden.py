@@ -76,6 +76,47 @@ def long_signals():
     return {k: v.astype(np.float32) for k, v in s.items()}
 
 
+def raw_files():
+    """Decoded interleaved PCM for the LoadSample front end: name -> (array, channels).  int16, float32, or
+    uint8 holding packed little-endian int24."""
+    rng = np.random.default_rng(20261005)
+    t = np.arange(12000) / SR
+    tone = 0.4 * np.sin(2 * np.pi * 330.0 * t) * np.exp(-t / 0.1)
+    f = {}
+    lead = np.concatenate([np.zeros(700), tone, np.zeros(1300)])
+    f["i16_mono_trim"] = (np.round(lead * 20000).astype(np.int16), 1)
+    st = np.stack([tone, 0.8 * np.roll(tone, 7)], axis=1)
+    f["i16_stereo"] = (np.round(st * 30000).astype(np.int16).reshape(-1), 2)
+    v = np.round(0.6 * rng.uniform(-1, 1, 9000) * 8388607).astype(np.int32)
+    b = np.zeros((v.size, 3), dtype=np.uint8)
+    b[:, 0] = v & 0xFF; b[:, 1] = (v >> 8) & 0xFF; b[:, 2] = (v >> 16) & 0xFF
+    f["i24_mono"] = (b.reshape(-1), 1)
+    fl = np.stack([1.3 * tone, -0.9 * tone, 0.2 * rng.standard_normal(tone.size)], axis=1)   # clips above 1.0
+    f["f32_three_channels_clipping"] = (fl.astype(np.float32).reshape(-1), 3)
+    f["i16_short"] = (np.round(0.5 * np.sin(2 * np.pi * 1000 * np.arange(300) / SR) * 32767).astype(np.int16), 1)
+    f["i16_all_zero"] = (np.zeros(5000, dtype=np.int16), 1)
+    f["i16_quiet"] = (np.round(3.0 * rng.standard_normal(6000)).astype(np.int16), 1)      # amplification >> 1
+    f["i16_len_mod_fft_ge_half"] = (np.round(8000 * rng.uniform(-1, 1, 2048 * 2 + 1500)).astype(np.int16), 1)
+    return f
+
+
+def run_ref_load(data, channels):
+    data = np.ascontiguousarray(data)
+    fmt = {np.dtype(np.int16): 0, np.dtype(np.uint8): 1, np.dtype(np.float32): 2}[data.dtype]
+    frames = data.size // (channels * (3 if fmt == 1 else 1))
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<iiq", fmt, channels, frames))
+            f.write(data.tobytes())
+        subprocess.check_call([REF, "load", fin, fout])
+        raw = open(fout, "rb").read()
+    peak, rms, off, lead, trail, _, n = struct.unpack("<ffiiiiq", raw[:32])
+    x = np.frombuffer(raw[32:], dtype=np.float64).copy()
+    assert x.size == n
+    return np.array([peak, rms], dtype=np.float32), np.array([off, lead, trail, n], dtype=np.int64), x
+
+
 def run_ref(bufs, cap=0, mode="frames", record=1147):
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
@@ -115,6 +156,17 @@ def main():
         out["ref_" + name] = rec[:, :11].copy()
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "neighbours.npz"), **out)
 
+    # LoadSample front end
+    out = {}
+    for name, (data, channels) in raw_files().items():
+        pr, info, x = run_ref_load(data, channels)
+        out["raw_" + name] = data
+        out["channels_" + name] = np.array(channels)
+        out["peakrms_" + name] = pr
+        out["info_" + name] = info
+        out["data_" + name] = x
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "load.npz"), **out)
+
     # tables
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "t.bin")
@@ -131,7 +183,7 @@ def main():
         rows.append((n, cap, rec.shape[0]))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "framecount.npz"),
                         rows=np.array(rows, dtype=np.int64))
-    print("wrote tests/golden/{frames,neighbours,tables,framecount}.npz")
+    print("wrote tests/golden/{frames,neighbours,load,tables,framecount}.npz")
 
 
 if __name__ == "__main__":

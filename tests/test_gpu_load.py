@@ -69,6 +69,28 @@ def test_load_front_end_matches_oracle():
     plan.close()
 
 
+def test_load_front_end_matches_reference_golden():
+    """afx_batch_create_from_raw against tests/golden/load.npz (`ref_driver load`: the reference's converters and
+    maths around the restated LoadSample flow): samples, offsets and peak bit-exact; the rms sum is re-associated"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "load.npz"))
+    names = sorted(k[4:] for k in z.files if k.startswith("raw_"))
+    files = [(z["raw_" + n], int(z["channels_" + n])) for n in names]
+    plan = afx.Plan()
+    batch, infos = plan.batch_from_raw(files, afx.D_MFCC)
+    for i, n in enumerate(names):
+        off, lead, trail, size = z["info_" + n].tolist()
+        got = infos[i]
+        assert (got["data_offset"], got["silent_leading"], got["silent_trailing"], got["n_samples"]) == (off, lead, trail, size), n
+        assert np.float32(got["peak_value"]) == z["peakrms_" + n][0], n
+        assert abs(got["rms_value"] - z["peakrms_" + n][1]) <= 2e-7 * z["peakrms_" + n][1] + 1e-12, n
+        nf = plan.num_frames(size)
+        kept = (nf - 1) * 1024 + 2048 if nf > 0 else 0
+        np.testing.assert_array_equal(batch.fetch_samples(i, kept), z["data_" + n][:kept], err_msg=n)
+    batch.close()
+    plan.close()
+
+
 def test_load_front_end_rejects_bad_files_individually():
     rng = np.random.default_rng(32)
     good = (rng.uniform(-1, 1, 5000) * 20000).astype(np.int16)

@@ -215,3 +215,23 @@ def test_neighbour_descriptors_that_are_identically_zero(oracle):
     for k in z.files:
         if k.startswith("ref_"):
             assert not z[k][:, 7:11].any(), k
+
+
+# ---- LoadSample front end -------------------------------------------------------
+
+def load_names():
+    z = np.load(os.path.join(GOLD, "load.npz"))
+    return sorted(k[4:] for k in z.files if k.startswith("raw_"))
+
+
+@pytest.mark.parametrize("name", load_names())
+def test_oracle_load_sample_matches_reference_golden(name):
+    """conversion, mono mix, peak / rms, normalisation, -48 dB trim and padding against `ref_driver load`
+    (the reference's TSampleConverter / TMathT / TAudioMath arithmetic around the restated flow): bit-exact"""
+    z = np.load(os.path.join(GOLD, "load.npz"))
+    got, info = _oracle.load_sample(z["raw_" + name], int(z["channels_" + name]))
+    off, lead, trail, n = z["info_" + name].tolist()
+    assert (info["data_offset"], info["silent_leading"], info["silent_trailing"], info["n_samples"]) == (off, lead, trail, n)
+    assert np.float32(info["peak_value"]) == z["peakrms_" + name][0]
+    assert np.float32(info["rms_value"]) == z["peakrms_" + name][1]
+    np.testing.assert_array_equal(got, z["data_" + name])

@@ -58,8 +58,9 @@ def make_buffers(n_buffers, seed):
 
 
 def make_c3_files(n_files, seed):
-    """2.0 s mono files (88 200 samples -> 85 frames each): 1-3 sines, a decaying noise
-    burst, 50 ms of leading silence; peak-normalised like LoadSample's output."""
+    """2.0 s mono 16-bit PCM files (88 200 samples): 1-3 sines, a decaying noise burst,
+    50 ms of leading silence.  They go through the LoadSample front end on the GPU
+    (afx_batch_create_from_raw: normalisation, -48 dB trim, padding), outside the timed region."""
     rng = np.random.Generator(np.random.MT19937(seed))
     n = 88200
     t = np.arange(n, dtype=np.float64) / 44100.0
@@ -70,8 +71,8 @@ def make_c3_files(n_files, seed):
             x += rng.uniform(0.2, 0.6) * np.sin(2 * np.pi * rng.uniform(110.0, 4000.0) * t + rng.uniform(0, 6.28))
         x += rng.uniform(0.2, 0.8) * rng.uniform(-1, 1, n) * np.exp(-t / rng.uniform(0.05, 0.5))
         x[:2205] = 0.0
-        x /= np.max(np.abs(x))
-        files.append(x.astype(np.float32))
+        x *= rng.uniform(0.3, 0.95) / np.max(np.abs(x))
+        files.append(np.round(x * 32767.0).astype(np.int16))
     return files
 
 
@@ -166,13 +167,17 @@ def main():
     if args.workload == "c3":
         mask = (afx.D_ALL_PER_FRAME if args.mask in ("frame", "neighbours") else afx.D_ALL_LOW_LEVEL) | afx.D_STATISTICS
         bufs = make_c3_files(1000, 1234 + rank)
+        n_bufs = len(bufs)
+        batch, _ = plan.batch_from_raw([(b, 1) for b in bufs], mask)
+        pcm_kind = afx.PCM_F64
     else:
         bufs = make_buffers(args.buffers, 1234 + rank)
-    n_bufs = len(bufs)
-    batch = plan.batch(bufs, mask)
+        n_bufs = len(bufs)
+        batch = plan.batch(bufs, mask)
+        pcm_kind = afx.PCM_F32
     del bufs
     frames = batch.total_frames
-    bytes_per_frame = plan.bytes_per_frame(mask & ~afx.D_STATISTICS, afx.PCM_F32)
+    bytes_per_frame = plan.bytes_per_frame(mask & ~afx.D_STATISTICS, pcm_kind)
 
     for _ in range(args.warmup):
         batch.run()
@@ -213,15 +218,16 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {
-                "workload": (f"C3: full low-level descriptor set + per-file statistics, {n_bufs} synthetic 2.0 s "
-                             f"mono float32 files per GPU") if args.workload == "c3" else
+                "workload": (f"C3: {'every per-frame' if args.mask in ('frame', 'neighbours') else 'spectral'} low-level "
+                             f"descriptor set + per-file statistics, {n_bufs} synthetic 2.0 s mono 16-bit files per "
+                             f"GPU through the LoadSample front end") if args.workload == "c3" else
                             (f"C2 x{args.buffers}: 2048/1024 STFT + 14-coef MFCC, {args.buffers} mono float32 "
                              f"buffers of {FRAMES_PER_BUFFER} frames per GPU, U(-1,1) MT19937"
                              if args.mask == "c2" else f"{args.mask} descriptor set, {args.buffers} x {FRAMES_PER_BUFFER} frames"),
                 "frames_per_gpu_per_step": frames,
                 "files_per_gpu_per_step": n_bufs,
                 "single_10k_frame_buffer_frames_per_s": single,
-                "pcm": "f32 resident in HBM",
+                "pcm": "f32 resident in HBM" if pcm_kind == afx.PCM_F32 else "f64 (LoadSample output) resident in HBM",
                 "parallelism": f"replicas x{world} (buffers sharded, no collective)",
             },
             "roofline": {

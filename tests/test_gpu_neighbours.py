@@ -188,3 +188,61 @@ def test_from_raw_front_end_feeds_the_neighbours(plan, oracle):
     ref = oracle.run_neighbours(mono)
     assert res["frame_offset"][-1] == ref.shape[0]
     compare(res, ref, "from_raw ")
+
+
+def test_empty_and_short_inputs(plan):
+    res = plan.extract([], afx.D_NEIGHBOURS)
+    assert res["f0"].shape == (0,) and res["frame_offset"].tolist() == [0]
+    res = plan.extract([np.zeros(100, np.float32), np.zeros(2047, np.float32)], afx.D_ALL_PER_FRAME)
+    assert res["spectral_complexity"].shape == (0,) and res["frame_offset"].tolist() == [0, 0, 0]
+
+
+def test_exactly_one_frame_and_the_20s_cap(oracle):
+    """remaining = size - n reaches its minimum (2048) on a one-frame buffer; with the cap the buffer is longer
+    than its analysed prefix and CalcAutoCorrelation still sees the real size (SampleAnalyser.cpp:943)"""
+    rng = np.random.default_rng(21)
+    one = rng.uniform(-1, 1, 2048)
+    capped = afx.Plan(max_analysis_ms=20000)
+    res = capped.extract([one], afx.D_NEIGHBOURS)
+    compare(res, oracle.run_neighbours(one, cap=True), "one frame ")
+    long = (0.3 * rng.standard_normal(882000 + 5000)).astype(np.float32)      # 20 s + a bit
+    res = capped.extract([long], afx.D_AUTO_CORRELATION | afx.D_AMPLITUDE_SILENCE)
+    ref = oracle.run_neighbours(long.astype(np.float64), cap=True)
+    assert res["frame_offset"][-1] == ref.shape[0] == 860
+    compare(res, ref, "capped ")
+    capped.close()
+
+
+def test_f32_stft_mode_leaves_the_time_domain_neighbours_untouched(oracle):
+    """AFX_PRECISION_F32 only changes the STFT: pitch, autocorrelation, envelope and silence run in double and
+    are bit-identical; the whitened-spectrum count sees float magnitudes and stays within a few peaks"""
+    rng = np.random.default_rng(22)
+    bufs = [rng.uniform(-1, 1, 2048 + 1024 * 20).astype(np.float32), (0.2 * rng.standard_normal(30000)).astype(np.float32)]
+    p64, p32 = afx.Plan(max_analysis_ms=0), afx.Plan(max_analysis_ms=0, precision=afx.PRECISION_F32)
+    a, b = p64.extract(bufs, afx.D_NEIGHBOURS), p32.extract(bufs, afx.D_NEIGHBOURS)
+    for k in ("amplitude_silence", "amplitude_envelope", "auto_correlation", "f0", "f0_confidence"):
+        np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    np.testing.assert_allclose(b["failsafe_f0"], a["failsafe_f0"], rtol=1e-5)
+    assert np.max(np.abs(a["spectral_complexity"] - b["spectral_complexity"])) <= 3
+    p64.close()
+    p32.close()
+
+
+def test_non_finite_samples_do_not_poison_other_frames_or_buffers(plan, oracle):
+    """a NaN / Inf sample is garbage in the frames that contain it (as in the reference) and nowhere else"""
+    rng = np.random.default_rng(23)
+    good = rng.uniform(-1, 1, 2048 + 1024 * 6)
+    bad = good.copy()
+    bad[5000] = np.nan          # frames 3 and 4 contain sample 5000
+    bad[5001] = np.inf
+    res = plan.extract([bad, good], afx.D_NEIGHBOURS)
+    ref = oracle.run_neighbours(good)
+    off = res["frame_offset"]
+    clean = [0, 1, 2, 5, 6]
+    for field, col in NEIGH_FIELDS.items():
+        if field == "spectral_complexity":
+            continue            # the follower carries the poisoned frames forward, as the reference's would
+        rtol, atol = _tol.NEIGH_TOL[field]
+        _tol.check(field, res[field][off[0]:off[1]][clean], ref[clean, col], rtol, atol, what="frames without the NaN ")
+        _tol.check(field, res[field][off[1]:off[2]], ref[:, col], rtol, atol, what="second buffer ")
+    assert np.all(np.isfinite(res["spectral_complexity"]))

@@ -1,9 +1,10 @@
 // afec_amd/csrc/afx_bands.hip -- the 14 "sub-band" descriptors of
 // TSampleAnalyser::CalcSpectralBandFeatures (SampleAnalyser.cpp:2067-2308) on gfx950.
 //
-// One wave per frame, working from the magnitude spectrum the frame kernel left in HBM
-// ([F][1024] doubles, L2/MALL-resident between the two launches for realistic batch sizes) and
-// the previous frame's spectrum of the same buffer (flux).  Bands are laid out contiguously from
+// One wave per chunk of consecutive frames (the frame kernel's chunk table), working from the magnitude
+// spectra the frame kernel left in HBM ([F][1024] doubles, L2/MALL-resident between the two launches for
+// realistic batch sizes).  The previous frame's spectrum and band sums (flux) are carried in registers
+// from frame to frame; only a chunk's first frame reads its predecessor.  Bands are laid out contiguously from
 // bin 1 with the reference's bin counts (the drift from the nominal edges is intentional, see
 // SURVEY 8a/a15), so every membership test below is a compile-time range of k = 64 r + lane.
 //
@@ -38,10 +39,40 @@ __device__ __forceinline__ bool in_band(int b, int r, int lane) {
   const int k = 64 * r + lane;
   return k >= kSubStart[b] && k < kSubStart[b + 1];
 }
+// does band b cover every bin of row r?
+constexpr bool sub_covers(int b, int r) { return kSubStart[b] <= 64 * r && kSubStart[b + 1] - 1 >= 64 * r + 63; }
+// (band, row) pairs that touch, in band-major order
+constexpr int sub_pair_count() {
+  int n = 0;
+  for (int b = 0; b < kNumSub; ++b)
+    for (int r = 0; r < kRows; ++r) n += sub_touches(b, r) ? 1 : 0;
+  return n;
+}
+constexpr int kSubPairs = sub_pair_count();   // 25
+constexpr int sub_pair_index(int b, int r) {
+  int n = 0;
+  for (int bb = 0; bb < kNumSub; ++bb)
+    for (int rr = 0; rr < kRows; ++rr) {
+      if (bb == b && rr == r) return n;
+      n += sub_touches(bb, rr) ? 1 : 0;
+    }
+  return -1;
+}
+
+// v in the lanes whose bit is set in the wave-uniform mask m, 0.0 elsewhere: two v_cndmask_b32 reading the
+// mask from an SGPR pair.  The band-membership masks depend on the lane only, so they are built once per
+// wave (ballots) instead of two compares per (band, row) pair, quantity and frame.
+using mask64 = unsigned long long;
+__device__ __forceinline__ double keep_where(double v, mask64 m) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(v)), "s"(m));
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(v)), "s"(m));
+  return __hiloint2double(hi, lo);
+}
 
 // per-band sum of one value per row; lane L receives the total of band (L >> 2) & 15
 template <typename F>
-__device__ __forceinline__ double band_sum(F value_of_row, int lane) {
+__device__ __forceinline__ double band_sum(F value_of_row, const mask64 (&bm)[kSubPairs], int lane) {
   double acc[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
@@ -49,13 +80,13 @@ __device__ __forceinline__ double band_sum(F value_of_row, int lane) {
     if (b < kNumSub) {
 #pragma unroll
       for (int r = 0; r < kRows; ++r)
-        if (sub_touches(b, r)) acc[b] += in_band(b, r, lane) ? value_of_row(r) : 0.0;
+        if (sub_touches(b, r)) acc[b] += sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), bm[sub_pair_index(b, r)]);
     }
   }
   return wave_sum16(acc, lane);
 }
 template <typename F>
-__device__ __forceinline__ double band_max(F value_of_row, int lane) {
+__device__ __forceinline__ double band_max(F value_of_row, const mask64 (&bm)[kSubPairs], int lane) {
   double acc[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
@@ -63,7 +94,8 @@ __device__ __forceinline__ double band_max(F value_of_row, int lane) {
     if (b < kNumSub) {
 #pragma unroll
       for (int r = 0; r < kRows; ++r)
-        if (sub_touches(b, r)) acc[b] = fmax(acc[b], in_band(b, r, lane) ? value_of_row(r) : 0.0);
+        if (sub_touches(b, r))
+          acc[b] = fmax(acc[b], sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), bm[sub_pair_index(b, r)]));
     }
   }
   return wave_max16(acc, lane);
@@ -129,82 +161,130 @@ __device__ __forceinline__ void sort_level(u32 (&key)[16], int lane) {
 }
 
 __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
-  const int lane0 = threadIdx.x & 63;
-  const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int64_t stride = (int64_t)gridDim.x * 4;
+  const int lane = threadIdx.x & 63;
+  const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int stride = gridDim.x * 4;
   __shared__ double s_thr[4][16];
   __shared__ float s_sorted[4][1024];
   double* const thr = s_thr[threadIdx.x >> 6];
   float* const sorted = s_sorted[threadIdx.x >> 6];
 
-  for (int64_t f = wave0; f < a.n_frames; f += stride) {
-    // re-materialise the lane id every frame: keeps the hundreds of lane-range predicates below from
-    // being hoisted out of the loop into (spilled) SGPR pairs
-    int lane = lane0;
-    asm volatile("" : "+v"(lane));
-    const double* const cur = a.mag + f * kHalf;
-    const double* const prv = a.mag + (int64_t)a.prev[f] * kHalf;
-    double x[kRows], y[kRows];
+  // lane-only facts, once per wave: membership masks of the (band, row) pairs, the band of each of the
+  // lane's bins, the analysis-range masks of the first and last row
+  mask64 bm[kSubPairs];
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) {
-      x[r] = cur[64 * r + lane];
-      y[r] = prv[64 * r + lane];
-    }
+  for (int b = 0; b < kNumSub; ++b)
+#pragma unroll
+    for (int r = 0; r < kRows; ++r)
+      if (sub_touches(b, r)) bm[sub_pair_index(b, r)] = __ballot(in_band(b, r, lane));
+  int bid[kRows];
+#pragma unroll
+  for (int r = 0; r < kRows; ++r) {
+    bid[r] = 15;
+#pragma unroll
+    for (int b = 0; b < kNumSub; ++b)
+      if (sub_touches(b, r)) bid[r] = in_band(b, r, lane) ? b : bid[r];
+  }
+  const mask64 first_row_ok = __ballot(lane >= kFirstBin);                        // bins 1..63
+  const mask64 last_row_ok = __ballot(64 * (kRows - 1) + lane <= kLastBin);       // bins 704..738
 
-    // ---- spectral_flux: Pearson r with the previous frame over bins 1..738 (SA:1919-1933,
-    //      Statistics.cpp:604-638); frame 0 of a buffer is compared with itself (SA:937-940) ----
+  for (int ci = wave0; ci < a.n_chunks; ci += stride) {
+    const Chunk ch = a.chunks[ci];
+    double x[kRows], y[kRows];
+    {
+      // the frame before the chunk; the first frame of a buffer is compared with itself (SA:937-940)
+      const int64_t prow = (ch.flags & kChunkFirstOfBuffer) ? (int64_t)ch.frame0 : (int64_t)ch.frame0 - 1;
+      const double* const prv = a.mag + prow * kHalf;
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) y[r] = prv[64 * r + lane];
+    }
+    // sums of the previous frame, carried from frame to frame inside the chunk
+    double fb = 0.0, fbb = 0.0, sy = 0.0, syy = 0.0;
     if (a.flags & kBandsFlux) {
-      double fa = 0.0, fb = 0.0, faa = 0.0, fbb = 0.0, fab = 0.0;
 #pragma unroll
       for (int r = 0; r < kRows; ++r) {
-        const int k = 64 * r + lane;
-        const bool ok = k >= kFirstBin && k <= kLastBin;
-        const double p = ok ? x[r] : 0.0, q = ok ? y[r] : 0.0;
-        fa += p; fb += q; faa += p * p; fbb += q * q; fab += p * q;
+        const double q = (r == 0) ? keep_where(y[r], first_row_ok) : (r == kRows - 1 ? keep_where(y[r], last_row_ok) : y[r]);
+        fb += q; fbb += q * q;
       }
-      fa = wave_sum(fa); fb = wave_sum(fb); faa = wave_sum(faa); fbb = wave_sum(fbb); fab = wave_sum(fab);
+      fb = wave_sum(fb); fbb = wave_sum(fbb);
+    }
+    if (a.flags & kBandsFeatures) {
+      sy = band_sum([&](int r) { return y[r]; }, bm, lane);
+      syy = band_sum([&](int r) { return y[r] * y[r]; }, bm, lane);
+    }
+
+  for (int fi = 0; fi < ch.nframes; ++fi) {
+    // lane-only predicates other than the membership masks (reduction selects, sort directions, position
+    // ranges) are recomputed per frame from a re-materialised lane id: hoisted out of the loop they would
+    // all sit in SGPR pairs and spill
+    int lane_v = lane;
+    asm volatile("" : "+v"(lane_v));
+    const int64_t f = (int64_t)ch.frame0 + fi;
+    const double* const cur = a.mag + f * kHalf;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) x[r] = cur[64 * r + lane_v];
+
+    // ---- spectral_flux: Pearson r with the previous frame over bins 1..738 (SA:1919-1933,
+    //      Statistics.cpp:604-638) ----
+    if (a.flags & kBandsFlux) {
+      double fa = 0.0, faa = 0.0, fab = 0.0;
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        const double p = (r == 0) ? keep_where(x[r], first_row_ok) : (r == kRows - 1 ? keep_where(x[r], last_row_ok) : x[r]);
+        fa += p; faa += p * p; fab += p * y[r];     // y outside the range meets p = 0
+      }
+      fa = wave_sum(fa); faa = wave_sum(faa); fab = wave_sum(fab);
       const double n = (double)kBinCount;
       const double ma = fa / n, mb = fb / n;
       const double denom2 = (faa - ma * ma * n) * (fbb - mb * mb * n);
       const double num = fab - (ma * mb * n);
-      if (lane == 0) a.rec[f * a.lay.stride + a.lay.flux] = (fabs(denom2) > (double)1e-12f) ? num / sqrt(denom2) : 0.0;
+      if (lane_v == 0) a.rec[f * a.lay.stride + a.lay.flux] = (fabs(denom2) > (double)1e-12f) ? num / sqrt(denom2) : 0.0;
+      fb = fa; fbb = faa;
     }
-    if (!(a.flags & kBandsFeatures)) continue;
+    if (!(a.flags & kBandsFeatures)) {
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) y[r] = x[r];
+      continue;
+    }
 
     // ---- masked per-band sums: lane L ends up with band (L >> 2) & 15 ----
-    const double sx = band_sum([&](int r) { return x[r]; }, lane);
-    const double sxx = band_sum([&](int r) { return x[r] * x[r]; }, lane);
-    const double sy = band_sum([&](int r) { return y[r]; }, lane);
-    const double syy = band_sum([&](int r) { return y[r] * y[r]; }, lane);
-    const double sxy = band_sum([&](int r) { return x[r] * y[r]; }, lane);
+    const double sx = band_sum([&](int r) { return x[r]; }, bm, lane_v);
+    const double sxx = band_sum([&](int r) { return x[r] * x[r]; }, bm, lane_v);
+    const double sxy = band_sum([&](int r) { return x[r] * y[r]; }, bm, lane_v);
     // geometric mean: sum of log(|x| + 1e-20) (Statistics.cpp:417-455 keeps a running product and
     // takes logs only when it leaves [1e-64, 1e64]; same value up to rounding)
     double lg[kRows];
 #pragma unroll
     for (int r = 0; r < kRows; ++r) lg[r] = fast_log(fabs(x[r]) + 1e-20);
-    const double slog = band_sum([&](int r) { return lg[r]; }, lane);
-    const double bmax = band_max([&](int r) { return x[r]; }, lane);
+    const double slog = band_sum([&](int r) { return lg[r]; }, bm, lane_v);
+    const double bmax = band_max([&](int r) { return x[r]; }, bm, lane_v);
 
-    // ---- complexity: strict local maxima above 0.25 * band maximum (SA:2170-2197) ----
+    // ---- complexity: strict local maxima above 0.25 * band maximum (SA:2170-2197); counted on the scalar
+    //      unit: ballot of the peak flags of a row, masked per band, popcount ----
     wave_lds_fence();
-    if ((lane & 3) == 0) thr[lane >> 2] = bmax * 0.25;
+    if ((lane_v & 3) == 0) thr[lane_v >> 2] = bmax * 0.25;
     wave_lds_fence();
-    double pk[kRows];
+    int peaks[kNumSub];
+#pragma unroll
+    for (int b = 0; b < kNumSub; ++b) peaks[b] = 0;
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
-      const int k = 64 * r + lane;
-      int bid = -1;
-#pragma unroll
-      for (int b = 0; b < kNumSub; ++b)
-        if (sub_touches(b, r)) bid = in_band(b, r, lane) ? b : bid;
-      const double t = thr[bid < 0 ? 15 : bid];
+      const int k = 64 * r + lane_v;
+      const double t = thr[bid[r]];
       // neighbours in the unsorted spectrum, may reach into the adjacent band; bin 0 and 1023 never count
       const double left = (k > 0) ? cur[k - 1] : 0.0;
       const double right = cur[k + 1];
-      const bool peak = bid >= 0 && t > 0.0 && x[r] > t && k > 0 && x[r] > left && x[r] > right;
-      pk[r] = peak ? 1.0 : 0.0;
+      // bins outside every band: bin 0 (row 0) and 752..767 (last row)
+      const bool inside = (r == 0) ? (lane_v >= kSubStart[0]) : ((r == kRows - 1) ? (k < kSubStart[kNumSub]) : true);
+      const mask64 pk = __ballot(inside && t > 0.0 && x[r] > t && x[r] > left && x[r] > right);
+#pragma unroll
+      for (int b = 0; b < kNumSub; ++b)
+        if (sub_touches(b, r)) peaks[b] += __popcll(pk & bm[sub_pair_index(b, r)]);
     }
-    const double cplx = band_sum([&](int r) { return pk[r]; }, lane);
+    // hand every lane_v the count of its band ((lane_v >> 2) & 15) now: the scalar counters die before the sort
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < kNumSub; ++i) cnt = (((lane_v >> 2) & 15) == i) ? peaks[i] : cnt;
 
     // ---- contrast: sort (band, value) keys, then fixed position ranges ----
     // key = band << 27 | float bits >> 4 (rounded): 19 mantissa bits order the values, and the sums
@@ -213,23 +293,19 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       if (r < kRows) {
-        int bid = 15;
-#pragma unroll
-        for (int b = 0; b < kNumSub; ++b)
-          if (sub_touches(b, r)) bid = in_band(b, r, lane) ? b : bid;
         const u32 bits = __float_as_uint((float)fabs(x[r]));
-        key[r] = ((u32)bid << 27) | ((bits + 8u) >> 4);
+        key[r] = ((u32)bid[r] << 27) | ((bits + 8u) >> 4);
       } else {
         key[r] = 0x7FFFFFFFu;
       }
     }
-    sort_level<1024>(key, lane);
+    sort_level<1024>(key, lane_v);
     // sorted position p = 16 lane + i; stage the values in LDS in position order
     wave_lds_fence();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sorted[16 * lane + i] = __uint_as_float((key[i] & 0x07FFFFFFu) << 4);
+    for (int i = 0; i < 16; ++i) sorted[16 * lane_v + i] = __uint_as_float((key[i] & 0x07FFFFFFu) << 4);
     wave_lds_fence();
-    // band b sits at [pos0, pos0 + n): valley = first nn, peak = last nn (nn <= 86 -> two passes of 64 lanes)
+    // band b sits at [pos0, pos0 + n): valley = first nn, peak = last nn (nn <= 86 -> two passes of 64 lanes).
     double valley_acc[16], peak_acc[16];
 #pragma unroll
     for (int b = 0; b < 16; ++b) {
@@ -239,17 +315,17 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
         const int lo = sub_pos0(b), n = kSubN[b], nn = kSubNeigh[b];
 #pragma unroll
         for (int t0 = 0; t0 < nn; t0 += 64) {
-          const int t = t0 + lane;
+          const int t = t0 + lane_v;
           valley_acc[b] += (t < nn) ? (double)sorted[lo + (t < nn ? t : 0)] : 0.0;
           peak_acc[b] += (t < nn) ? (double)sorted[lo + n - nn + (t < nn ? t : 0)] : 0.0;
         }
       }
     }
-    const double vsum = wave_sum16(valley_acc, lane);
-    const double psum = wave_sum16(peak_acc, lane);
+    const double vsum = wave_sum16(valley_acc, lane_v);
+    const double psum = wave_sum16(peak_acc, lane_v);
 
-    // ---- per-band results: every lane finishes the band (lane >> 2) & 15 ----
-    const int b = (lane >> 2) & 15;
+    // ---- per-band results: every lane_v finishes the band (lane_v >> 2) & 15 ----
+    const int b = (lane_v >> 2) & 15;
     const bool valid = b < kNumSub;
     const int bb = valid ? b : 0;
     double nb = 1.0, nn = 1.0;
@@ -258,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       nb = (bb == i) ? (double)kSubN[i] : nb;
       nn = (bb == i) ? (double)kSubNeigh[i] : nn;
     }
+    const double cplx = (double)cnt;
     const double mean = (nb >= 2.0) ? sx / nb : sx;                    // TStatistics::Mean
     const double rms = sqrt(sxx / nb);                                 // SA:2154-2159
     const double gm = fast_exp(slog / nb);                             // Statistics.cpp:442
@@ -273,7 +350,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     const double contrast = -1.0 * fast_exp(fast_log(peakv / valley) / fast_log(mean + 1e-30));
 
     double* const rec = a.rec + f * a.lay.stride;
-    if (valid && (lane & 3) == 0) {
+    if (valid && (lane_v & 3) == 0) {
       rec[a.lay.sub_rms + b] = rms;
       rec[a.lay.sub_flat + b] = fdb;
       rec[a.lay.sub_flux + b] = flux;
@@ -284,16 +361,22 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     double csum = 0.0;
 #pragma unroll
     for (int i = 0; i < kNumSub; ++i) csum += __shfl(contrast, 4 * i);
-    if (lane == 0) rec[a.lay.contrast] = csum / (double)kNumSub;
+    if (lane_v == 0) rec[a.lay.contrast] = csum / (double)kNumSub;
+
+    // this frame is the next one's predecessor
+    sy = sx; syy = sxx;
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) y[r] = x[r];
+  }
   }
 }
 
 }  // namespace
 
 hipError_t launch_bands(const BandArgs& a, hipStream_t stream) {
-  if (a.n_frames <= 0) return hipSuccess;
-  const int64_t want = (a.n_frames + 3) / 4;
-  const int grid = (int)(want < 256 * 16 ? want : 256 * 16);
+  if (a.n_chunks <= 0) return hipSuccess;
+  const int want = (a.n_chunks + 3) / 4;
+  const int grid = want < 256 * 16 ? want : 256 * 16;
   hipLaunchKernelGGL(bands_kernel, dim3(grid), dim3(256), 0, stream, a);
   return hipGetLastError();
 }

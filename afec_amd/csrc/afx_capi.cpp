@@ -138,9 +138,9 @@ struct Workspace {
   };
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  Buf pcm, chunks, rem, rec, mag, prev, foff, stats, cfirst, follower;
+  Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower;
   size_t bytes() const {
-    return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + prev.cap + foff.cap + stats.cap + cfirst.cap + follower.cap;
+    return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap;
   }
 };
 
@@ -177,7 +177,6 @@ struct afx_batch {
   int chunk_frames = 0;
   double* d_rec = nullptr;
   double* d_mag = nullptr;
-  int32_t* d_prev = nullptr;
   int64_t* d_frame_offset = nullptr;
   double* d_stats = nullptr;
   std::vector<int64_t> arena_off, used;  // per buffer: start and length (samples) of its analysed prefix in d_pcm
@@ -289,7 +288,7 @@ void free_tables(afx_plan* p) {
 
 void ws_free(Workspace* w) {
   if (!w) return;
-  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->prev, &w->foff, &w->stats, &w->cfirst, &w->follower}) hipFree(b->p);
+  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->stream) hipStreamDestroy(w->stream);
@@ -664,17 +663,6 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     if ((e = ws_reserve(w.mag, (size_t)frames * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(mag)"));
     b->d_mag = (double*)w.mag.p;
   }
-  if (frames > 0 && (mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX))) {
-    std::vector<int32_t> prev((size_t)frames);
-    for (int i = 0; i < n_bufs; ++i)
-      for (int64_t f = b->frame_offset[i]; f < b->frame_offset[i + 1]; ++f)
-        prev[(size_t)f] = (int32_t)((f == b->frame_offset[i]) ? f : f - 1);  // SampleAnalyser.cpp:937-940
-    if ((e = ws_reserve(w.prev, prev.size() * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(prev)"));
-    b->d_prev = (int32_t*)w.prev.p;
-    // pageable source: the copy is complete (staged) when the call returns
-    if ((e = hipMemcpyAsync(b->d_prev, prev.data(), prev.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(prev)"));
-    if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
-  }
   if ((want_stats || (mask & kWhitenBits)) && n_bufs > 0 && b->lay.stride > 0) {
     if ((e = ws_reserve(w.foff, b->frame_offset.size() * sizeof(int64_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(frame_offset)"));
     b->d_frame_offset = (int64_t*)w.foff.p;
@@ -863,7 +851,7 @@ int afx_batch_run(afx_batch* b) {
   }
   if (b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) {
     afx::BandArgs ba{};
-    ba.mag = b->d_mag; ba.prev = b->d_prev; ba.n_frames = b->total_frames; ba.rec = b->d_rec; ba.lay = b->lay;
+    ba.mag = b->d_mag; ba.chunks = b->d_chunks; ba.n_chunks = b->n_chunks; ba.rec = b->d_rec; ba.lay = b->lay;
     ba.flags = ((b->mask & AFX_D_BAND_FEATURES) ? afx::kBandsFeatures : 0) | ((b->mask & AFX_D_SPECTRAL_FLUX) ? afx::kBandsFlux : 0);
     HIP_TRY(afx::launch_bands(ba, b->stream));
   }

@@ -105,8 +105,8 @@ int frames_feature_class(uint32_t mask);     // 0 = MFCC only, 1 = + statistics,
 // band-feature kernel (SampleAnalyser.cpp:2067-2308) working from stored magnitudes
 struct BandArgs {
   const double* mag;    // [F][1024]
-  const int32_t* prev;  // [F] row of the previous frame of the same buffer (own row for frame 0)
-  int64_t n_frames;
+  const Chunk* chunks;  // runs of consecutive frames of one buffer (kChunkFirstOfBuffer marks frame 0)
+  int32_t n_chunks;
   double* rec;          // same per-frame records the frame kernel writes
   RecordLayout lay;
   uint32_t flags;       // kBandsFeatures | kBandsFlux

@@ -14,124 +14,7 @@ namespace {
   throw TReadableException(std::string(What) + ": " + afx_status_str(Status) + " (" + afx_last_error() + ")");
 }
 
-// (float literal) MEpsilon, CoreTypes/Export/InlineMath.h:32
-const double kEpsilon = (double)1e-12f;
-
-double Sum(const double* pX, int n) { double s = 0.0; for (int i = 0; i < n; ++i) s += pX[i]; return s; }
-double Mean(const double* pX, int n) { return n >= 2 ? Sum(pX, n) / (double)n : (n == 1 ? pX[0] : 0.0); }
-double Variance(const double* pX, int n, double m) {
-  if (n < 2) return 0.0;
-  double r = 0.0;
-  for (int i = 0; i < n; ++i) r += (pX[i] - m) * (pX[i] - m);
-  return r / n;
-}
-double Median(const double* pX, int n) {       // lower median, Statistics.cpp:316-413
-  if (n < 2) return n == 1 ? pX[0] : 0.0;
-  std::vector<double> t(pX, pX + n);
-  std::nth_element(t.begin(), t.begin() + (n - 1) / 2, t.end());
-  return t[(n - 1) / 2];
-}
-double GeometricMean(const double* pX, int n) {  // Statistics.cpp:417-455
-  if (n < 2) return n == 1 ? pX[0] : 0.0;
-  double sumlog = 0.0, product = 1.0;
-  for (int i = 0; i < n; ++i) {
-    product *= (std::fabs(pX[i]) + 1e-20);
-    if (product > 1.e64 || product < 1.e-64) { sumlog += std::log(product); product = 1.0; }
-  }
-  return std::exp((sumlog + std::log(product)) / (double)n);
-}
-double Centroid(const double* pX, int n) {
-  const double s = Sum(pX, n);
-  if (s == 0.0) return 0.0;
-  double sc = 0.0;
-  for (int j = 0; j < n; ++j) sc += (double)j * pX[j];
-  return sc / s;
-}
-double Spread(const double* pX, int n, double c) {
-  const double s = Sum(pX, n);
-  if (s == 0.0) return 0.0;
-  double sc = 0.0;
-  for (int j = 0; j < n; ++j) { const double t = j - c; sc += t * t * pX[j]; }
-  return sc / s;
-}
-double Skewness(const double* pX, int n, double c, double v) {
-  if (!n || std::fabs(v) <= kEpsilon) return 0.0;
-  double r = 0.0;
-  for (int i = n; i--;) { const double t = (pX[i] - c) / v; r += t * t * t; }
-  return r / n;
-}
-double Kurtosis(const double* pX, int n, double c, double v) {
-  if (!n || std::fabs(v) <= kEpsilon) return 0.0;
-  double r = 0.0;
-  for (int i = n; i--;) { const double t = (pX[i] - c) / v; const double tt = t * t; r += tt * tt; }
-  return r / n - 3.0;
-}
-
 }  // namespace
-
-void TStatistics::Calc(double& Min, double& Max, double& Med, double& Mn, double& GeometricMn, double& Var,
-                       double& Cen, double& Spr, double& Skew, double& Kurt, double& Flat, double& AbsDMean,
-                       double& AbsDVariance, const double* pX, int Length) {
-  if (Length > 1) {
-    Min = *std::min_element(pX, pX + Length);
-    Max = *std::max_element(pX, pX + Length);
-    Med = Median(pX, Length);
-    Mn = Mean(pX, Length);
-    GeometricMn = GeometricMean(pX, Length);
-    Var = Variance(pX, Length, Mn);
-    Cen = Centroid(pX, Length);
-    Spr = Spread(pX, Length, Cen);
-    Skew = Skewness(pX, Length, Cen, Spr);
-    Kurt = Kurtosis(pX, Length, Cen, Spr);
-    Flat = (Mn == 0.0) ? 0.0 : GeometricMn / Mn;
-    if (Length > 2) {
-      std::vector<double> d(Length - 1);
-      for (int i = 0; i < Length - 1; ++i) d[i] = std::fabs(pX[i + 1] - pX[i]);
-      AbsDMean = Mean(d.data(), Length - 1);
-      AbsDVariance = Variance(d.data(), Length - 1, AbsDMean);
-    } else {
-      AbsDMean = 0.0;
-      AbsDVariance = 0.0;
-    }
-  } else if (Length > 0) {
-    Min = pX[0]; Max = pX[0]; Mn = pX[0]; Var = 0.0; AbsDMean = 0.0; AbsDVariance = 0.0;
-  } else {
-    Min = 0.0; Max = 0.0; Mn = 0.0; Var = 0.0; AbsDMean = 0.0; AbsDVariance = 0.0;
-  }
-}
-
-void TFramedScalarData::CalcStatistics() {
-  TStatistics::Calc(mMin, mMax, mMedian, mMean, mGeometricMean, mVariance, mCentroid, mSpread, mSkewness,
-                    mKurtosis, mFlatness, mDMean, mDVariance, mValues.data(), (int)mValues.size());
-}
-
-template <int W>
-void TFramedVectorData<W>::CalcStatistics() {
-  std::vector<double> band(mValues.size());
-  for (int b = 0; b < W; ++b) {
-    for (size_t f = 0; f < mValues.size(); ++f) band[f] = mValues[f][b];
-    TStatistics::Calc(mMin[b], mMax[b], mMedian[b], mMean[b], mGeometricMean[b], mVariance[b], mCentroid[b],
-                      mSpread[b], mSkewness[b], mKurtosis[b], mFlatness[b], mDMean[b], mDVariance[b], band.data(),
-                      (int)band.size());
-  }
-}
-template struct TFramedVectorData<14>;
-template struct TFramedVectorData<28>;
-
-void TSampleDescriptors::CalcStatistics() {
-  for (TFramedScalarData* p : {&mAmplitudeSilence, &mAmplitudeEnvelope, &mF0, &mF0Confidence, &mFailSafeF0, &mAutoCorrelation,
-                               &mSpectralComplexity, &mSpectralInharmonicity, &mTristimulus1, &mTristimulus2, &mTristimulus3})
-    p->CalcStatistics();
-  for (TFramedScalarData* p : {&mAmplitudePeak, &mAmplitudeRms, &mSpectralRms, &mSpectralCentroid, &mSpectralRolloff,
-                               &mSpectralSpread, &mSpectralSkewness, &mSpectralKurtosis, &mSpectralFlatness,
-                               &mSpectralContrast, &mSpectralFlux})
-    p->CalcStatistics();
-  for (auto* p : {&mSpectralRmsBands, &mSpectralFlatnessBands, &mSpectralFluxBands, &mSpectralComplexityBands,
-                  &mSpectralContrastBands})
-    p->CalcStatistics();
-  mSpectrumBands.CalcStatistics();
-  mCepstrumBands.CalcStatistics();
-}
 
 TSampleAnalyser::TSampleAnalyser(int SampleRate, int FftFrameSize, int HopFrameSize, int Device)
     : mpPlan(nullptr), mSampleRate(SampleRate), mFftFrameSize(FftFrameSize), mHopFrameSize(HopFrameSize) {
@@ -155,59 +38,122 @@ void Fill(TFramedVectorData<W>& Dst, const double* pSrc, int64_t Frames) {
 void Fill(TFramedScalarData& Dst, const double* pSrc, int64_t Frames) { Dst.mValues.assign(pSrc, pSrc + Frames); }
 }  // namespace
 
+namespace {
+// the 13 values of TStatistics::Calc in the order of AFX_S_* -> the members of the framed data
+void FillStatistics(TFramedScalarData& Dst, const double* pS) {
+  Dst.mMin = pS[AFX_S_MIN]; Dst.mMax = pS[AFX_S_MAX]; Dst.mMedian = pS[AFX_S_MEDIAN]; Dst.mMean = pS[AFX_S_MEAN];
+  Dst.mGeometricMean = pS[AFX_S_GMEAN]; Dst.mVariance = pS[AFX_S_VARIANCE]; Dst.mCentroid = pS[AFX_S_CENTROID];
+  Dst.mSpread = pS[AFX_S_SPREAD]; Dst.mSkewness = pS[AFX_S_SKEWNESS]; Dst.mKurtosis = pS[AFX_S_KURTOSIS];
+  Dst.mFlatness = pS[AFX_S_FLATNESS]; Dst.mDMean = pS[AFX_S_DMEAN]; Dst.mDVariance = pS[AFX_S_DVARIANCE];
+}
+template <int W>
+void FillStatistics(TFramedVectorData<W>& Dst, const double* pS) {
+  for (int b = 0; b < W; ++b) {
+    const double* p = pS + (size_t)b * AFX_NUM_STATISTICS;
+    Dst.mMin[b] = p[AFX_S_MIN]; Dst.mMax[b] = p[AFX_S_MAX]; Dst.mMedian[b] = p[AFX_S_MEDIAN]; Dst.mMean[b] = p[AFX_S_MEAN];
+    Dst.mGeometricMean[b] = p[AFX_S_GMEAN]; Dst.mVariance[b] = p[AFX_S_VARIANCE]; Dst.mCentroid[b] = p[AFX_S_CENTROID];
+    Dst.mSpread[b] = p[AFX_S_SPREAD]; Dst.mSkewness[b] = p[AFX_S_SKEWNESS]; Dst.mKurtosis[b] = p[AFX_S_KURTOSIS];
+    Dst.mFlatness[b] = p[AFX_S_FLATNESS]; Dst.mDMean[b] = p[AFX_S_DMEAN]; Dst.mDVariance[b] = p[AFX_S_DVARIANCE];
+  }
+}
+
+// one series of the ABI: per-frame values and per-buffer statistics, and where they go in TSampleDescriptors
+struct TScalarSeries {
+  double* afx_out::*mpOut;
+  double* afx_stats_out::*mpStat;
+  TFramedScalarData TSampleDescriptors::*mpDst;
+};
+template <int W>
+struct TVectorSeries {
+  double* afx_out::*mpOut;
+  double* afx_stats_out::*mpStat;
+  TFramedVectorData<W> TSampleDescriptors::*mpDst;
+};
+#define AFEC_SERIES(abi, member) {&afx_out::abi, &afx_stats_out::abi, &TSampleDescriptors::member}
+const TScalarSeries kScalarSeries[] = {
+    AFEC_SERIES(amplitude_silence, mAmplitudeSilence), AFEC_SERIES(amplitude_peak, mAmplitudePeak),
+    AFEC_SERIES(amplitude_rms, mAmplitudeRms), AFEC_SERIES(amplitude_envelope, mAmplitudeEnvelope),
+    AFEC_SERIES(spectral_rms, mSpectralRms), AFEC_SERIES(spectral_centroid, mSpectralCentroid),
+    AFEC_SERIES(spectral_rolloff, mSpectralRolloff), AFEC_SERIES(spectral_spread, mSpectralSpread),
+    AFEC_SERIES(spectral_skewness, mSpectralSkewness), AFEC_SERIES(spectral_kurtosis, mSpectralKurtosis),
+    AFEC_SERIES(spectral_flatness, mSpectralFlatness), AFEC_SERIES(spectral_inharmonicity, mSpectralInharmonicity),
+    AFEC_SERIES(spectral_complexity, mSpectralComplexity), AFEC_SERIES(spectral_contrast, mSpectralContrast),
+    AFEC_SERIES(spectral_flux, mSpectralFlux), AFEC_SERIES(f0, mF0), AFEC_SERIES(f0_confidence, mF0Confidence),
+    AFEC_SERIES(failsafe_f0, mFailSafeF0), AFEC_SERIES(tristimulus1, mTristimulus1),
+    AFEC_SERIES(tristimulus2, mTristimulus2), AFEC_SERIES(tristimulus3, mTristimulus3),
+    AFEC_SERIES(auto_correlation, mAutoCorrelation)};
+const TVectorSeries<14> kSubBandSeries[] = {
+    AFEC_SERIES(sub_rms, mSpectralRmsBands), AFEC_SERIES(sub_flatness, mSpectralFlatnessBands),
+    AFEC_SERIES(sub_flux, mSpectralFluxBands), AFEC_SERIES(sub_complexity, mSpectralComplexityBands),
+    AFEC_SERIES(sub_contrast, mSpectralContrastBands), AFEC_SERIES(mfcc, mCepstrumBands)};
+const TVectorSeries<28> kBandSeries[] = {AFEC_SERIES(spectrum_bands, mSpectrumBands)};
+#undef AFEC_SERIES
+
+struct TBatchGuard {
+  afx_batch* mpBatch = nullptr;
+  ~TBatchGuard() { afx_batch_destroy(mpBatch); }
+};
+}  // namespace
+
+// The whole of AnalyzeLowLevelDescriptors' loop (SampleAnalyser.cpp:814-976) and of CalcStatistics
+// (SampleAnalyser.cpp:1065, 2402-2412) runs on the GPU: every per-frame series and its 13 statistics come
+// back from one resident batch.
 std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
     const std::vector<const std::vector<double>*>& Samples, std::vector<std::string>* pFailed) const {
   const int32_t n = (int32_t)Samples.size();
   std::vector<afx_buf> Buffers((size_t)n);
-  int64_t Total = 0;
-  for (int32_t i = 0; i < n; ++i) {
-    Buffers[i] = {Samples[i]->data(), AFX_PCM_F64, 0, (int64_t)Samples[i]->size()};
-    Total += NumberOfFrames((int64_t)Samples[i]->size());
-  }
-  const size_t F = (size_t)Total;
-  std::vector<double> Mfcc(F * 14), Bands(F * 28), SubRms(F * 14), SubFlat(F * 14), SubFlux(F * 14), SubCplx(F * 14),
-      SubContrast(F * 14), Rms(F), Cen(F), Spr(F), Skew(F), Kurt(F), Roll(F), Flat(F), Flux(F), Contrast(F), Peak(F),
-      ARms(F), Silence(F), Envelope(F), F0(F), F0Conf(F), F0Safe(F), AutoCorr(F), Complexity(F), Inharm(F), Tri1(F), Tri2(F),
-      Tri3(F);
-  std::vector<int64_t> Offset((size_t)n + 1);
-  std::vector<int32_t> BufStatus((size_t)n);
+  for (int32_t i = 0; i < n; ++i) Buffers[i] = {Samples[i]->data(), AFX_PCM_F64, 0, (int64_t)Samples[i]->size()};
+
+  TBatchGuard Batch;
+  int Status = afx_batch_create(mpPlan, Buffers.data(), n, AFX_D_ALL_PER_FRAME | AFX_D_STATISTICS, &Batch.mpBatch);
+  if (Status == AFX_OK) Status = afx_batch_run(Batch.mpBatch);
+  if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
+  const size_t F = (size_t)afx_batch_total_frames(Batch.mpBatch);
+
+  // host arrays for every series: [F][W] values and [n][W][13] statistics
+  std::vector<std::vector<double>> Values, Stats;
   afx_out Out = {};
-  Out.mfcc = Mfcc.data(); Out.spectrum_bands = Bands.data(); Out.sub_rms = SubRms.data();
-  Out.sub_flatness = SubFlat.data(); Out.sub_flux = SubFlux.data(); Out.sub_complexity = SubCplx.data();
-  Out.sub_contrast = SubContrast.data(); Out.spectral_rms = Rms.data(); Out.spectral_centroid = Cen.data();
-  Out.spectral_spread = Spr.data(); Out.spectral_skewness = Skew.data(); Out.spectral_kurtosis = Kurt.data();
-  Out.spectral_rolloff = Roll.data(); Out.spectral_flatness = Flat.data(); Out.spectral_flux = Flux.data();
-  Out.spectral_contrast = Contrast.data(); Out.amplitude_peak = Peak.data(); Out.amplitude_rms = ARms.data();
-  Out.amplitude_silence = Silence.data(); Out.amplitude_envelope = Envelope.data(); Out.f0 = F0.data();
-  Out.f0_confidence = F0Conf.data(); Out.failsafe_f0 = F0Safe.data(); Out.auto_correlation = AutoCorr.data();
-  Out.spectral_complexity = Complexity.data(); Out.spectral_inharmonicity = Inharm.data();
-  Out.tristimulus1 = Tri1.data(); Out.tristimulus2 = Tri2.data(); Out.tristimulus3 = Tri3.data();
-  Out.frame_offset = Offset.data(); Out.buf_status = BufStatus.data();
-  const int Status = afx_extract_batch(mpPlan, Buffers.data(), n, AFX_D_ALL_PER_FRAME, &Out);
+  afx_stats_out StatsOut = {};
+  auto Bind = [&](double* afx_out::*pOut, double* afx_stats_out::*pStat, int W) {
+    Values.emplace_back(F * (size_t)W);
+    Stats.emplace_back((size_t)n * (size_t)W * AFX_NUM_STATISTICS);
+    Out.*pOut = Values.back().data();
+    StatsOut.*pStat = Stats.back().data();
+  };
+  for (const TScalarSeries& S : kScalarSeries) Bind(S.mpOut, S.mpStat, 1);
+  for (const TVectorSeries<14>& S : kSubBandSeries) Bind(S.mpOut, S.mpStat, 14);
+  for (const TVectorSeries<28>& S : kBandSeries) Bind(S.mpOut, S.mpStat, 28);
+  std::vector<int64_t> Offset((size_t)n + 1);
+  std::vector<int32_t> BufStatus((size_t)n), StatsStatus((size_t)n);
+  Out.frame_offset = Offset.data();
+  Out.buf_status = BufStatus.data();
+  StatsOut.stats_status = StatsStatus.data();
+  Status = afx_batch_fetch(Batch.mpBatch, &Out);
+  if (Status == AFX_OK) Status = afx_batch_fetch_statistics(Batch.mpBatch, &StatsOut);
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
 
   std::vector<TSampleDescriptors> Results((size_t)n);
   if (pFailed) pFailed->assign((size_t)n, std::string());
   for (int32_t i = 0; i < n; ++i) {
-    if (BufStatus[i] != AFX_OK) {
-      if (pFailed) (*pFailed)[i] = std::string("error: ") + afx_status_str(BufStatus[i]);
+    const int32_t Bad = (BufStatus[i] != AFX_OK) ? BufStatus[i] : StatsStatus[i];
+    if (Bad != AFX_OK) {
+      if (pFailed) (*pFailed)[i] = std::string("error: ") + afx_status_str(Bad);
       continue;
     }
     const int64_t f0 = Offset[i], nf = Offset[i + 1] - Offset[i];
     TSampleDescriptors& R = Results[i];
-    Fill(R.mCepstrumBands, &Mfcc[f0 * 14], nf); Fill(R.mSpectrumBands, &Bands[f0 * 28], nf);
-    Fill(R.mSpectralRmsBands, &SubRms[f0 * 14], nf); Fill(R.mSpectralFlatnessBands, &SubFlat[f0 * 14], nf);
-    Fill(R.mSpectralFluxBands, &SubFlux[f0 * 14], nf); Fill(R.mSpectralComplexityBands, &SubCplx[f0 * 14], nf);
-    Fill(R.mSpectralContrastBands, &SubContrast[f0 * 14], nf);
-    Fill(R.mSpectralRms, &Rms[f0], nf); Fill(R.mSpectralCentroid, &Cen[f0], nf); Fill(R.mSpectralSpread, &Spr[f0], nf);
-    Fill(R.mSpectralSkewness, &Skew[f0], nf); Fill(R.mSpectralKurtosis, &Kurt[f0], nf);
-    Fill(R.mSpectralRolloff, &Roll[f0], nf); Fill(R.mSpectralFlatness, &Flat[f0], nf); Fill(R.mSpectralFlux, &Flux[f0], nf);
-    Fill(R.mSpectralContrast, &Contrast[f0], nf); Fill(R.mAmplitudePeak, &Peak[f0], nf); Fill(R.mAmplitudeRms, &ARms[f0], nf);
-    Fill(R.mAmplitudeSilence, &Silence[f0], nf); Fill(R.mAmplitudeEnvelope, &Envelope[f0], nf); Fill(R.mF0, &F0[f0], nf);
-    Fill(R.mF0Confidence, &F0Conf[f0], nf); Fill(R.mFailSafeF0, &F0Safe[f0], nf); Fill(R.mAutoCorrelation, &AutoCorr[f0], nf);
-    Fill(R.mSpectralComplexity, &Complexity[f0], nf); Fill(R.mSpectralInharmonicity, &Inharm[f0], nf);
-    Fill(R.mTristimulus1, &Tri1[f0], nf); Fill(R.mTristimulus2, &Tri2[f0], nf); Fill(R.mTristimulus3, &Tri3[f0], nf);
-    R.CalcStatistics();
+    for (const TScalarSeries& S : kScalarSeries) {
+      Fill(R.*(S.mpDst), (Out.*(S.mpOut)) + f0, nf);
+      FillStatistics(R.*(S.mpDst), (StatsOut.*(S.mpStat)) + (size_t)i * AFX_NUM_STATISTICS);
+    }
+    for (const TVectorSeries<14>& S : kSubBandSeries) {
+      Fill(R.*(S.mpDst), (Out.*(S.mpOut)) + f0 * 14, nf);
+      FillStatistics(R.*(S.mpDst), (StatsOut.*(S.mpStat)) + (size_t)i * 14 * AFX_NUM_STATISTICS);
+    }
+    for (const TVectorSeries<28>& S : kBandSeries) {
+      Fill(R.*(S.mpDst), (Out.*(S.mpOut)) + f0 * 28, nf);
+      FillStatistics(R.*(S.mpDst), (StatsOut.*(S.mpStat)) + (size_t)i * 28 * AFX_NUM_STATISTICS);
+    }
   }
   return Results;
 }

@@ -3,8 +3,9 @@
 // low-level part of TSampleDescriptors (Export/SampleDescriptors.h:152-356, 395-465).  Same names,
 // same argument meaning, errors as exceptions (TReadableException there, std::runtime_error here).
 //
-// Only what the GPU path produces is present: the stateful neighbours of the loop (whitening,
-// pitch, rhythm) are not part of this library.
+// Only what the GPU path produces is present (every per-frame low-level descriptor and its statistics; the
+// rhythm tracker, SampleAnalyser.cpp:985-1048, is not).  This layer computes nothing itself: values and
+// statistics are the GPU's, fetched through the C-ABI.
 #pragma once
 
 #include <array>
@@ -28,7 +29,6 @@ struct TFramedScalarData {
   std::vector<double> mValues;  // [frame]
   double mMin = 0, mMax = 0, mMedian = 0, mMean = 0, mGeometricMean = 0, mVariance = 0, mCentroid = 0,
          mSpread = 0, mSkewness = 0, mKurtosis = 0, mFlatness = 0, mDMean = 0, mDVariance = 0;
-  void CalcStatistics();
 };
 
 // TSampleDescriptors::TFramedVectorData<W> (SampleDescriptors.h:262-356): [frame][band] values plus
@@ -38,7 +38,6 @@ struct TFramedVectorData {
   std::vector<std::array<double, W>> mValues;  // [frame][band]
   std::array<double, W> mMin{}, mMax{}, mMedian{}, mMean{}, mGeometricMean{}, mVariance{}, mCentroid{},
       mSpread{}, mSkewness{}, mKurtosis{}, mFlatness{}, mDMean{}, mDVariance{};
-  void CalcStatistics();
 };
 
 // the low-level descriptors of TSampleDescriptors that lie on the GPU path
@@ -57,17 +56,7 @@ struct TSampleDescriptors {
 
   // magnitude spectra [frame][1024] for the CPU-resident neighbours (optional)
   std::vector<double> mMagnitudeSpectrum;
-
-  // TSampleAnalyser::CalcStatistics (SampleAnalyser.cpp:2402-2412)
-  void CalcStatistics();
 };
-
-// TStatistics::Calc (Statistics.cpp:12-90) on the host, used by CalcStatistics above
-namespace TStatistics {
-void Calc(double& Min, double& Max, double& Median, double& Mean, double& GeometricMean, double& Variance,
-          double& Centroid, double& Spread, double& Skewness, double& Kurtosis, double& Flatness,
-          double& AbsDMean, double& AbsDVariance, const double* pX, int Length);
-}
 
 class TSampleAnalyser {
 public:
@@ -80,8 +69,8 @@ public:
   // frames the loop yields for a normalised buffer (SampleAnalyser.cpp:760-764, 814)
   int64_t NumberOfFrames(int64_t NumberOfSamples) const;
 
-  // AnalyzeLowLevelDescriptors for one decoded, mono, peak-normalised sample
-  // (TSampleData::mData); const and thread-safe like the reference
+  // AnalyzeLowLevelDescriptors + CalcStatistics (SampleAnalyser.cpp:723-1065) for one decoded, mono,
+  // peak-normalised sample (TSampleData::mData); const and thread-safe like the reference
   TSampleDescriptors AnalyzeLowLevelDescriptors(const std::vector<double>& SampleData, bool WithMagnitudes = false) const;
 
   // the same for many samples in one GPU batch; Failed[i] receives the message for buffers

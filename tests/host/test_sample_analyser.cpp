@@ -1,7 +1,7 @@
 // tests/host/test_sample_analyser.cpp -- C++ tests of the host layer, written like the reference's
 // own Boost tests (Source/Crawler/FeatureExtraction/Test/TestStatistics.cpp).
 //
-//   host_test stats     TStatistics::Calc known answers (no GPU)
+//   host_test nodevice  error behaviour without a usable device (no GPU needed)
 //   host_test analyse   TSampleAnalyser::AnalyzeLowLevelDescriptors vs the oracle (GPU)
 #include <cmath>
 #include <cstdio>
@@ -19,39 +19,11 @@ static int gFailures = 0;
   } while (0)
 #define CHECK_EQUAL_EPSILON(a, b, eps) CHECK(std::fabs((a) - (b)) <= (eps))
 
-static void Calc13(const std::vector<double>& x, double (&s)[13]) {
-  afec::TStatistics::Calc(s[0], s[1], s[2], s[3], s[4], s[5], s[6], s[7], s[8], s[9], s[10], s[11], s[12], x.data(),
-                          (int)x.size());
-}
-
-static int TestStatistics() {
-  // TestStatistics.cpp:36-58
-  const std::vector<std::vector<double>> Seqs = {{1, 2, 3, 4, 5, 6}, {6, 5, 4, 3, 2, 1}, {3, 2, 4, 6, 5, 1}, {4, 3, 6, 5, 2, 1}};
-  for (const auto& q : Seqs) {
-    double s[13] = {0};
-    Calc13(q, s);
-    CHECK(s[0] == 1 && s[1] == 6);
-    CHECK(s[2] == 3);                            // Median
-    CHECK_EQUAL_EPSILON(s[3], 21.0 / 6, 1e-16);  // Mean
-    CHECK_EQUAL_EPSILON(s[5], 2.9, 0.1);         // Variance
-    CHECK_EQUAL_EPSILON(s[4], 3.0, 1.0);         // GeometricMean, roughly
-  }
-  // TestStatistics.cpp:62-90 (centroid)
-  double s[13] = {0};
-  Calc13({1, 1, 1, 1, 1, 1}, s);
-  CHECK_EQUAL_EPSILON(s[6], 2.5, 0.001);
-  // against the oracle restatement on random series, incl. the Length <= 2 branches
-  std::mt19937 gen(5);
-  std::uniform_real_distribution<double> U(-3.0, 5.0);
-  for (int n : {0, 1, 2, 3, 7, 64, 85, 860}) {
-    std::vector<double> x((size_t)n);
-    for (auto& v : x) v = U(gen);
-    double a[13], b[13];
-    for (int i = 0; i < 13; ++i) a[i] = b[i] = 7.0;
-    Calc13(x, a);
-    afx_oracle_calc_statistics(x.data(), n, b);
-    for (int i = 0; i < 13; ++i) CHECK_EQUAL_EPSILON(a[i], b[i], 1e-12 * (1.0 + std::fabs(b[i])));
-  }
+// the host layer computes nothing itself; without a GPU only its error behaviour can be exercised
+static int TestNoDevice() {
+  bool Thrown = false;
+  try { afec::TSampleAnalyser Analyser(44100, 2048, 1024, /*Device*/ 9999); } catch (const afec::TReadableException&) { Thrown = true; }
+  CHECK(Thrown);     // no such device: the constructor reports it like the reference's would (exception), no fallback
   return gFailures;
 }
 
@@ -113,6 +85,17 @@ static int TestAnalyse() {
     afx_oracle_calc_statistics(series.data(), (int)nf, s);
     CHECK_EQUAL_EPSILON(R.mSpectralCentroid.mMedian, s[2], 1e-4 * s[2]);
     CHECK_EQUAL_EPSILON(R.mSpectralCentroid.mVariance, s[5], 1e-3 * s[5] + 1e-9);
+    // statistics of a vector series and of a neighbour: the GPU's reduction of its own series
+    for (int k : {0, 5, 13}) {
+      for (int64_t f = 0; f < nf; ++f) series[(size_t)f] = R.mCepstrumBands.mValues[(size_t)f][k];
+      afx_oracle_calc_statistics(series.data(), (int)nf, s);
+      CHECK_EQUAL_EPSILON(R.mCepstrumBands.mMean[k], s[3], 1e-9 * std::fabs(s[3]) + 1e-12);
+      CHECK_EQUAL_EPSILON(R.mCepstrumBands.mMedian[k], s[2], 1e-12);
+      CHECK_EQUAL_EPSILON(R.mCepstrumBands.mDVariance[k], s[12], 1e-9 * std::fabs(s[12]) + 1e-12);
+    }
+    afx_oracle_calc_statistics(R.mF0.mValues.data(), (int)nf, s);
+    CHECK_EQUAL_EPSILON(R.mF0.mMax, s[1], 0.0);
+    CHECK_EQUAL_EPSILON(R.mF0.mMean, s[3], 1e-9 * std::fabs(s[3]) + 1e-12);
   }
   afx_oracle_destroy(o);
 
@@ -126,7 +109,7 @@ static int TestAnalyse() {
 int main(int argc, char** argv) {
   int rc = 2;
   try {
-    if (argc >= 2 && !std::strcmp(argv[1], "stats")) rc = TestStatistics();
+    if (argc >= 2 && !std::strcmp(argv[1], "nodevice")) rc = TestNoDevice();
     else if (argc >= 2 && !std::strcmp(argv[1], "analyse")) rc = TestAnalyse();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());

@@ -49,26 +49,28 @@ __global__ __launch_bounds__(256) void follow_kernel(const WhitenArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wave_global = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t wave_stride = (int64_t)gridDim.x * 4;
-  constexpr int kAhead = 8;
+  constexpr int kAhead = 32;
   for (int64_t w = wave_global; w < (int64_t)a.n_bufs * 16; w += wave_stride) {
     const int b = (int)(w >> 4), k = 64 * (int)(w & 15) + lane;
     const int64_t f_begin = a.frame_offset[b], n = a.frame_offset[b + 1] - f_begin;
     const double* const col = a.mag + f_begin * kHalf + k;
     double* const save = a.follower + (int64_t)a.chunk_first[b] * kHalf + k;
     double follow = a.floor_value;                              // aubio_spectral_whitening_reset
-    for (int64_t f0 = 0; f0 < n; f0 += kAhead) {
-      double m[kAhead];
+    const int n32 = (int)n, per_chunk = a.chunk_frames;
+    for (int c0 = 0, ci = 0; c0 < n32; c0 += per_chunk, ++ci) {
+      save[(int64_t)ci * kHalf] = follow;                        // state at the chunk's first frame
+      const int c1 = (c0 + per_chunk < n32) ? c0 + per_chunk : n32;
+      for (int f0 = c0; f0 < c1; f0 += kAhead) {
+        double m[kAhead];
 #pragma unroll
-      for (int j = 0; j < kAhead; ++j) m[j] = (f0 + j < n) ? col[(f0 + j) * kHalf] : 0.0;
+        for (int j = 0; j < kAhead; ++j) m[j] = (f0 + j < c1) ? col[(int64_t)(f0 + j) * kHalf] : 0.0;
 #pragma unroll
-      for (int j = 0; j < kAhead; ++j) {
-        const int64_t f = f0 + j;
-        if (f < n) {
-          if (f % a.chunk_frames == 0) save[(f / a.chunk_frames) * kHalf] = follow;
-          double t = a.decay * follow;
-          t = (t > a.floor_value) ? t : a.floor_value;
-          follow = (m[j] > t) ? m[j] : t;
-        }
+        for (int j = 0; j < kAhead; ++j)
+          if (f0 + j < c1) {
+            double t = a.decay * follow;
+            t = (t > a.floor_value) ? t : a.floor_value;
+            follow = (m[j] > t) ? m[j] : t;
+          }
       }
     }
   }

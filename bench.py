@@ -37,9 +37,11 @@ def parse_args():
     ap.add_argument("--buffers", type=int, default=64, help="10k-frame buffers per GPU per step")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
     ap.add_argument("--mask", default="c2", choices=["c2", "stats", "all", "frame", "neighbours"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"],
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2: --buffers x 10k-frame buffers (headline); c3: 1000 synthetic 2.0 s files, full "
-                         "low-level set + per-file statistics (BASELINE.json configs[2])")
+                         "low-level set + per-file statistics (BASELINE.json configs[2]); c4: this rank's share "
+                         "of 100 000 stereo 1.0 s files (configs[3]: 12 500 per GPU on 8 GPUs, --files to change)")
+    ap.add_argument("--files", type=int, default=12500, help="files per GPU of the c4 workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-frames", type=int, default=30000, help="frames per CPU worker for the baseline")
     return ap.parse_args()
@@ -74,6 +76,17 @@ def make_c3_files(n_files, seed):
         x *= rng.uniform(0.3, 0.95) / np.max(np.abs(x))
         files.append(np.round(x * 32767.0).astype(np.int16))
     return files
+
+
+def make_c4_files(n_files, seed):
+    """stereo 16-bit 1.0 s files, right = left delayed by 7 samples x 0.8.  A pool of 64 distinct
+    files is cycled (the kernels are data-independent in time; generating 12 500 distinct files takes minutes)."""
+    pool = []
+    for x in make_c3_files(64, seed):
+        left = x[:44100].astype(np.float64)
+        right = 0.8 * np.concatenate([np.zeros(7), left[:-7]])
+        pool.append(np.stack([left, right], axis=1).round().astype(np.int16).reshape(-1))
+    return [pool[i % len(pool)] for i in range(n_files)]
 
 
 def dist_setup(n_gpus):
@@ -164,11 +177,12 @@ def main():
     # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)
     device = int(os.environ.get("AFX_BENCH_DEVICE", local))
     plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0)
-    if args.workload == "c3":
+    if args.workload in ("c3", "c4"):
         mask = (afx.D_ALL_PER_FRAME if args.mask in ("frame", "neighbours") else afx.D_ALL_LOW_LEVEL) | afx.D_STATISTICS
-        bufs = make_c3_files(1000, 1234 + rank)
+        channels = 1 if args.workload == "c3" else 2
+        bufs = make_c3_files(1000, 1234 + rank) if args.workload == "c3" else make_c4_files(args.files, 1234 + rank)
         n_bufs = len(bufs)
-        batch, _ = plan.batch_from_raw([(b, 1) for b in bufs], mask)
+        batch, _ = plan.batch_from_raw([(b, channels) for b in bufs], mask)
         pcm_kind = afx.PCM_F64
     else:
         bufs = make_buffers(args.buffers, 1234 + rank)
@@ -221,6 +235,9 @@ def main():
                 "workload": (f"C3: {'every per-frame' if args.mask in ('frame', 'neighbours') else 'spectral'} low-level "
                              f"descriptor set + per-file statistics, {n_bufs} synthetic 2.0 s mono 16-bit files per "
                              f"GPU through the LoadSample front end") if args.workload == "c3" else
+                            (f"C4 share: {'every per-frame' if args.mask in ('frame', 'neighbours') else 'spectral'} low-level "
+                             f"descriptor set + per-file statistics, {n_bufs} synthetic 1.0 s stereo 16-bit files per GPU "
+                             f"through the LoadSample front end") if args.workload == "c4" else
                             (f"C2 x{args.buffers}: 2048/1024 STFT + 14-coef MFCC, {args.buffers} mono float32 "
                              f"buffers of {FRAMES_PER_BUFFER} frames per GPU, U(-1,1) MT19937"
                              if args.mask == "c2" else f"{args.mask} descriptor set, {args.buffers} x {FRAMES_PER_BUFFER} frames"),
@@ -236,7 +253,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.precision, args.mask if args.workload == "c2" else "c3", frames),
+                "traffic": measured_traffic(args.precision, args.mask if args.workload == "c2" else args.workload, frames),
                 "kernel": "frames_kernel",
                 "algorithmic_bytes_per_frame": bytes_per_frame,
                 "launch_ms": launch_ms,

@@ -36,6 +36,7 @@ D_AUTO_CORRELATION = 1 << 18
 D_F0 = 1 << 19
 D_SPECTRAL_INHARMONICITY = 1 << 20
 D_TRISTIMULUS = 1 << 21
+D_EFFECTIVE_LENGTH = 1 << 22   # per buffer: [n_bufs][3]
 NUM_STATISTICS = 13
 STAT_NAMES = ["min", "max", "median", "mean", "gmean", "variance", "centroid", "spread", "skewness",
               "kurtosis", "flatness", "dmean", "dvariance"]
@@ -105,7 +106,7 @@ class _Buf(ctypes.Structure):
 
 class _Out(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n, _ in OUT_FIELDS] + [
-        ("frame_offset", ctypes.c_void_p), ("buf_status", ctypes.c_void_p)]
+        ("effective_length", ctypes.c_void_p), ("frame_offset", ctypes.c_void_p), ("buf_status", ctypes.c_void_p)]
 
 
 class _Raw(ctypes.Structure):
@@ -238,6 +239,10 @@ def _alloc_out(mask, total_frames, n_bufs):
             a = np.zeros((total_frames, width) if width > 1 else (total_frames,), dtype=np.float64)
             res[name] = a
             setattr(out, name, a.ctypes.data if a.size else None)
+    if mask & D_EFFECTIVE_LENGTH:
+        el = np.zeros((max(1, n_bufs), 3), dtype=np.float64)
+        out.effective_length = el.ctypes.data
+        res["effective_length"] = el[:n_bufs]
     fo = np.zeros(n_bufs + 1, dtype=np.int64)
     bs = np.zeros(max(1, n_bufs), dtype=np.int32)
     out.frame_offset = fo.ctypes.data

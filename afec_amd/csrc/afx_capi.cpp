@@ -138,9 +138,10 @@ struct Workspace {
   };
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower;
+  Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen;
   size_t bytes() const {
-    return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap;
+    return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
+           efflen.cap;
   }
 };
 
@@ -173,6 +174,8 @@ struct afx_batch {
   afx::Chunk* d_chunks = nullptr;
   afx::ChunkRemaining* d_rem = nullptr;
   int32_t* d_chunk_first = nullptr;
+  afx::BufSpan* d_spans = nullptr;
+  int32_t* d_efflen = nullptr;
   double* d_follower = nullptr;
   int chunk_frames = 0;
   double* d_rec = nullptr;
@@ -288,7 +291,8 @@ void free_tables(afx_plan* p) {
 
 void ws_free(Workspace* w) {
   if (!w) return;
-  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower}) hipFree(b->p);
+  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
+                            &w->efflen}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->stream) hipStreamDestroy(w->stream);
@@ -570,14 +574,20 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     b->frame_offset[i] = frames;
     if (b->buf_status[i] != AFX_OK) continue;
     const int64_t f = num_frames(plan, lengths[i]);
+    int64_t keep = 0;
     if (f > 0) {
-      b->used[i] = (f - 1) * plan->desc.hop_size + plan->desc.fft_size;
+      keep = (f - 1) * plan->desc.hop_size + plan->desc.fft_size;
       // the second rising-slope search of CalcAutoCorrelation (SampleAnalyser.cpp:2343-2356) may look up to
       // 33 samples past the last frame when the buffer has them
-      if (mask & AFX_D_AUTO_CORRELATION) b->used[i] = std::min<int64_t>(lengths[i], b->used[i] + 64);
-      b->arena_off[i] = arena;
-      arena += (b->used[i] + 3) & ~(int64_t)3;
+      if (mask & AFX_D_AUTO_CORRELATION) keep = std::min<int64_t>(lengths[i], keep + 64);
       frames += f;
+    }
+    // CalcEffectiveLength scans the whole buffer, also beyond the analysed 20 s (SampleAnalyser.cpp:754)
+    if (mask & AFX_D_EFFECTIVE_LENGTH) keep = lengths[i];
+    if (keep > 0) {
+      b->used[i] = keep;
+      b->arena_off[i] = arena;
+      arena += (keep + 3) & ~(int64_t)3;
     }
   }
   b->frame_offset[n_bufs] = frames;
@@ -655,6 +665,16 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     if ((e = ws_reserve(w.follower, (size_t)b->n_chunks * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(follower)"));
     b->d_follower = (double*)w.follower.p;
   }
+  if (n_bufs > 0 && (mask & AFX_D_EFFECTIVE_LENGTH)) {
+    std::vector<afx::BufSpan> spans((size_t)n_bufs);
+    for (int i = 0; i < n_bufs; ++i) spans[(size_t)i] = afx::BufSpan{b->arena_off[i], b->used[i]};
+    if ((e = ws_reserve(w.spans, spans.size() * sizeof(afx::BufSpan))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(spans)"));
+    b->d_spans = (afx::BufSpan*)w.spans.p;
+    if ((e = hipMemcpyAsync(b->d_spans, spans.data(), spans.size() * sizeof(afx::BufSpan), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(spans)"));
+    if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
+    if ((e = ws_reserve(w.efflen, (size_t)n_bufs * 6 * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(efflen)"));
+    b->d_efflen = (int32_t*)w.efflen.p;
+  }
   if (frames > 0 && b->lay.stride > 0) {
     if ((e = ws_reserve(w.rec, (size_t)frames * b->lay.stride * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rec)"));
     b->d_rec = (double*)w.rec.p;
@@ -679,7 +699,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
 
 bool mask_ok(uint32_t mask) {
   return (mask & ~(uint32_t)AFX_D_STATISTICS) != 0 &&
-         !(mask & ~(uint32_t)(AFX_D_ALL_PER_FRAME | AFX_D_MAGNITUDE | AFX_D_STATISTICS));
+         !(mask & ~(uint32_t)(AFX_D_ALL_PER_FRAME | AFX_D_MAGNITUDE | AFX_D_STATISTICS | AFX_D_EFFECTIVE_LENGTH));
 }
 
 }  // namespace
@@ -826,6 +846,12 @@ int64_t afx_batch_total_frames(const afx_batch* batch) { return batch ? batch->t
 int afx_batch_run(afx_batch* b) {
   if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
   HIP_TRY(hipSetDevice(b->plan->desc.device));
+  if (b->d_efflen) {
+    // DbToLin(-48 / -24 / -12), AudioMath.inl:108-123
+    const double k = std::log(10.0) / 20.0;
+    HIP_TRY(afx::launch_effective_length(b->d_pcm, b->pcm_dtype, b->d_spans, b->n_bufs, std::exp(-48.0 * k), std::exp(-24.0 * k),
+                                         std::exp(-12.0 * k), b->d_efflen, b->stream));
+  }
   if (b->total_frames == 0) {
     // nothing to analyse; empty series still reduce to TStatistics::Calc's Length == 0 result
     if (b->d_stats) {
@@ -911,6 +937,18 @@ int afx_batch_fetch(afx_batch* b, afx_out* out) {
   HIP_TRY(hipStreamSynchronize(b->stream));
   if (out->frame_offset) std::memcpy(out->frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t));
   if (out->buf_status) std::memcpy(out->buf_status, b->buf_status.data(), b->buf_status.size() * sizeof(int32_t));
+  if (out->effective_length) {
+    if (!b->d_efflen) return fail(AFX_ERR_INVALID_ARG, "effective_length not in the batch mask");
+    std::vector<int32_t> lt((size_t)b->n_bufs * 6);
+    if (!lt.empty()) HIP_TRY(hipMemcpy(lt.data(), b->d_efflen, lt.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+    for (int32_t i = 0; i < b->n_bufs; ++i)
+      for (int j = 0; j < 3; ++j) {
+        // TAudioMath::SamplesToMs is float arithmetic (AudioMath.inl:134-137); seconds = ms / 1000.0
+        const int samples = (int)(b->used[i] - lt[(size_t)i * 6 + 2 * j] - lt[(size_t)i * 6 + 2 * j + 1]);
+        const float ms = (float)samples / ((float)b->plan->desc.sample_rate / 1000.0f);
+        out->effective_length[(size_t)i * 3 + j] = (b->buf_status[i] == AFX_OK && b->used[i] > 0) ? (double)ms / 1000.0 : 0.0;
+      }
+  }
   const int64_t F = b->total_frames;
   if (F == 0) return AFX_OK;
   const afx::RecordLayout& l = b->lay;
@@ -1018,6 +1056,7 @@ int afx_extract_batch(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint3
     std::vector<int64_t> off((size_t)(last - first) + 1);
     part.frame_offset = off.data();
     part.buf_status = out->buf_status ? out->buf_status + first : nullptr;
+    part.effective_length = out->effective_length ? out->effective_length + (size_t)first * 3 : nullptr;
     afx_batch* b = nullptr;
     int st = afx_batch_create(plan, bufs + first, last - first, mask, &b);
     if (st != AFX_OK) return st;

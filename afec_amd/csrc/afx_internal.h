@@ -150,6 +150,15 @@ struct WhitenArgs {
 };
 hipError_t launch_whiten(const WhitenArgs& a, hipStream_t stream);
 
+// effective length (SampleAnalyser.cpp:1715-1755): silent leading / trailing samples of every buffer at
+// three floors; out[n_bufs][6] = lead, trail at -48 dB, then -24 dB, then -12 dB
+struct BufSpan {
+  int64_t off;   // first sample of the buffer in the PCM arena
+  int64_t n;     // samples (the whole buffer)
+};
+hipError_t launch_effective_length(const void* pcm, int pcm_dtype, const BufSpan* spans, int n_bufs, double floor48,
+                                   double floor24, double floor12, int32_t* out, hipStream_t stream);
+
 // per-buffer statistics of every record column (TStatistics::Calc, Statistics.cpp:12-90)
 struct StatsArgs {
   const double* rec;            // [F][stride]

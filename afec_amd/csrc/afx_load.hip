@@ -112,7 +112,49 @@ __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned
     dst[p.start_pad + n] = (double)mono_sample(src, f.format, f.channels, p.lead + n) * p.scaling;  // SA:712-718
 }
 
+// CalcEffectiveLength (SampleAnalyser.cpp:1715-1755) on the normalised buffer: for each of three floors the
+// first and the last sample above it; one workgroup per buffer
+template <typename TIn>
+__global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TIn* pcm, const BufSpan* spans, double f0,
+                                                                        double f1, double f2, int32_t* out) {
+  __shared__ long long sl[kLoadThreads / 64];
+  const BufSpan sp = spans[blockIdx.x];
+  const TIn* const x = pcm + sp.off;
+  const double floors[3] = {f0, f1, f2};
+  long long first[3] = {sp.n, sp.n, sp.n}, last[3] = {-1, -1, -1};
+  for (int64_t n = threadIdx.x; n < sp.n; n += kLoadThreads) {
+    const double v = fabs((double)x[n]);
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+      if (v > floors[j]) {
+        first[j] = n < first[j] ? n : first[j];
+        last[j] = n > last[j] ? n : last[j];
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const long long a = block_reduce(first[j], sl, [](long long p, long long q) { return p < q ? p : q; });
+    const long long b = block_reduce(last[j], sl, [](long long p, long long q) { return p > q ? p : q; });
+    if (threadIdx.x == 0) {
+      out[6 * blockIdx.x + 2 * j] = (int32_t)a;                                   // == n when nothing is above the floor
+      out[6 * blockIdx.x + 2 * j + 1] = (b < 0) ? 0 : (int32_t)(sp.n - 1 - b);    // the trailing scan stops above `lead`
+    }
+  }
+}
+
 }  // namespace
+
+hipError_t launch_effective_length(const void* pcm, int pcm_dtype, const BufSpan* spans, int n_bufs, double floor48,
+                                   double floor24, double floor12, int32_t* out, hipStream_t stream) {
+  if (n_bufs <= 0) return hipSuccess;
+  if (pcm_dtype == 0)
+    hipLaunchKernelGGL(effective_length_kernel<float>, dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+                       reinterpret_cast<const float*>(pcm), spans, floor48, floor24, floor12, out);
+  else
+    hipLaunchKernelGGL(effective_length_kernel<double>, dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+                       reinterpret_cast<const double*>(pcm), spans, floor48, floor24, floor12, out);
+  return hipGetLastError();
+}
 
 hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int n_files, double silence_floor,
                             LoadScan* scan, hipStream_t stream) {

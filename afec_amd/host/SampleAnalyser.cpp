@@ -105,7 +105,8 @@ std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
   for (int32_t i = 0; i < n; ++i) Buffers[i] = {Samples[i]->data(), AFX_PCM_F64, 0, (int64_t)Samples[i]->size()};
 
   TBatchGuard Batch;
-  int Status = afx_batch_create(mpPlan, Buffers.data(), n, AFX_D_ALL_PER_FRAME | AFX_D_STATISTICS, &Batch.mpBatch);
+  int Status = afx_batch_create(mpPlan, Buffers.data(), n, AFX_D_ALL_PER_FRAME | AFX_D_EFFECTIVE_LENGTH | AFX_D_STATISTICS,
+                                &Batch.mpBatch);
   if (Status == AFX_OK) Status = afx_batch_run(Batch.mpBatch);
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
   const size_t F = (size_t)afx_batch_total_frames(Batch.mpBatch);
@@ -125,6 +126,8 @@ std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
   for (const TVectorSeries<28>& S : kBandSeries) Bind(S.mpOut, S.mpStat, 28);
   std::vector<int64_t> Offset((size_t)n + 1);
   std::vector<int32_t> BufStatus((size_t)n), StatsStatus((size_t)n);
+  std::vector<double> EffectiveLength((size_t)n * 3);
+  Out.effective_length = EffectiveLength.data();
   Out.frame_offset = Offset.data();
   Out.buf_status = BufStatus.data();
   StatsOut.stats_status = StatsStatus.data();
@@ -142,6 +145,9 @@ std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
     }
     const int64_t f0 = Offset[i], nf = Offset[i + 1] - Offset[i];
     TSampleDescriptors& R = Results[i];
+    R.mEffectiveLength48dB = EffectiveLength[(size_t)i * 3];
+    R.mEffectiveLength24dB = EffectiveLength[(size_t)i * 3 + 1];
+    R.mEffectiveLength12dB = EffectiveLength[(size_t)i * 3 + 2];
     for (const TScalarSeries& S : kScalarSeries) {
       Fill(R.*(S.mpDst), (Out.*(S.mpOut)) + f0, nf);
       FillStatistics(R.*(S.mpDst), (StatsOut.*(S.mpStat)) + (size_t)i * AFX_NUM_STATISTICS);

@@ -44,6 +44,8 @@ struct TFramedVectorData {
 struct TSampleDescriptors {
   enum { kNumberOfSpectrumSubBands = 14, kNumberOfSpectrumBands = 28, kNumberOfCepstrumCoefficients = 14 };
 
+  // seconds between the first and last sample above -48 / -24 / -12 dB (SampleAnalyser.cpp:1715-1755)
+  double mEffectiveLength48dB = 0, mEffectiveLength24dB = 0, mEffectiveLength12dB = 0;
   TFramedScalarData mAmplitudeSilence, mAmplitudePeak, mAmplitudeRms, mAmplitudeEnvelope;
   TFramedScalarData mF0, mF0Confidence, mFailSafeF0, mAutoCorrelation;
   TFramedScalarData mSpectralComplexity, mSpectralInharmonicity, mTristimulus1, mTristimulus2, mTristimulus3;

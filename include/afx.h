@@ -79,6 +79,10 @@ enum {
   AFX_D_F0 = 1u << 19,                   /* f0, f0_confidence, failsafe_f0 [F] each  :876-917 (aubio yinfast) */
   AFX_D_SPECTRAL_INHARMONICITY = 1u << 20, /* spectral_inharmonicity [F]  :1951-1971 */
   AFX_D_TRISTIMULUS = 1u << 21,          /* tristimulus1..3     [F] each  :1975-2003 */
+  /* per file, not per frame (SampleAnalyser.cpp:754, 1715-1755) */
+  AFX_D_EFFECTIVE_LENGTH = 1u << 22,     /* effectve_length_{48,24,12}dB  [n_bufs][3] seconds between the first and the
+                                            last sample above -48 / -24 / -12 dB of the whole buffer (not only its
+                                            analysed first 20 s) */
   AFX_D_C2 = AFX_D_MFCC,
   AFX_D_SPECTRAL_STATS = 0x1FEu,     /* bits 1..8 */
   AFX_D_ALL_LOW_LEVEL = 0x1FFFu,     /* the spectral set of SURVEY 8(a), everything except the raw magnitudes */
@@ -158,6 +162,7 @@ typedef struct {
   double* tristimulus1;
   double* tristimulus2;
   double* tristimulus3;
+  double* effective_length;  /* [n_bufs][3]: -48, -24, -12 dB (per buffer; AFX_D_EFFECTIVE_LENGTH) */
   int64_t* frame_offset;     /* [n_bufs+1], optional */
   int32_t* buf_status;       /* [n_bufs], optional: AFX_OK or AFX_ERR_BAD_BUFFER (one bad buffer
                                 does not fail the batch, cf. SampleAnalyser.cpp:368-408)      */

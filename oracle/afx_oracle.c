@@ -677,6 +677,21 @@ int64_t afx_oracle_run_neighbours(const afx_oracle* o, const double* x, int64_t 
   return frames;
 }
 
+/* CalcEffectiveLength, SA.cpp:1715-1755; TAudioMath::DbToLin(double) = exp(db ln10 / 20), SamplesToMs in float
+ * (AudioMath.inl:108-123, 134-137) */
+void afx_oracle_effective_length(const afx_oracle* o, const double* x, int64_t n_samples, double* out3) {
+  static const double db[3] = { -48.0, -24.0, -12.0 };
+  const int n = (int)n_samples;
+  int s, f;
+  for (s = 0; s < 3; ++s) {
+    const double floor_v = exp(db[s] * (log(10.0) / 20.0));
+    int lead = 0, trail = 0;
+    for (f = 0; f < n; ++f, ++lead) if (fabs(x[f]) > floor_v) break;
+    for (f = n - 1; f > lead; --f, ++trail) if (fabs(x[f]) > floor_v) break;
+    out3[s] = (double)((float)(n - lead - trail) / ((float)o->sample_rate / 1000.0f)) / 1000.0;
+  }
+}
+
 /* ---- LoadSample (SA:484-718), decoded interleaved PCM in, normalised mono double out ---- */
 
 static float to_16bit_float(const void* pcm, int format, int64_t idx) {

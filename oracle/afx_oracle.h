@@ -56,6 +56,10 @@ int64_t afx_oracle_run_neighbours(const afx_oracle*, const double* x, int64_t n_
 /* TStatistics::Peaks (Statistics.cpp:140-232): bins/vals sized n; returns the number of peaks */
 int afx_oracle_peaks(const double* x, int n, double threshold, int* bins, double* vals);
 
+/* CalcEffectiveLength (SampleAnalyser.cpp:1715-1755): seconds between the first and last sample above
+ * -48 / -24 / -12 dB of the whole buffer.  PINNED against oracle/_ref/ref_driver `efflen`. */
+void afx_oracle_effective_length(const afx_oracle*, const double* x, int64_t n_samples, double* out3);
+
 /* TStatistics restatements exposed for the reference's own known-answer tests */
 double afx_oracle_sum(const double* x, int n);
 double afx_oracle_mean(const double* x, int n);

@@ -16,6 +16,7 @@
 //   ref_driver frames  <in.bin> <out.bin> [cap]  per-frame records (see kRecord)
 //   ref_driver neighbours <in.bin> <out.bin> [cap]  per-frame records of the stateful neighbours (kNeigh)
 //   ref_driver load    <in.bin> <out.bin>        LoadSample normalisation front end (SampleAnalyser.cpp:484-718)
+//   ref_driver efflen  <in.bin> <out.bin>        effective lengths at -48/-24/-12 dB per buffer (3 doubles each)
 //   ref_driver time    <n_frames> <seed>         C2 subset timing (STFT + MFCC), prints frames/s
 //
 // in.bin : int64 n_bufs ; per buffer: int64 n_samples, double[n_samples]
@@ -480,6 +481,35 @@ static int CmdLoad(const char* in, const char* outp) {
   return 0;
 }
 
+// CalcEffectiveLength (SampleAnalyser.cpp:1715-1755): private member, flow restated around the reference's
+// TAudioMath::DbToLin / SamplesToMs
+static int CmdEffectiveLength(const char* in, const char* outp) {
+  FILE* fi = fopen(in, "rb"); if (!fi) return 1;
+  int64_t nb = 0; if (fread(&nb, 8, 1, fi) != 1) return 1;
+  std::vector<double> res;
+  for (int64_t b = 0; b < nb; ++b) {
+    int64_t ns = 0; if (fread(&ns, 8, 1, fi) != 1) return 1;
+    std::vector<double> x((size_t)ns);
+    if (ns && fread(x.data(), 8, (size_t)ns, fi) != (size_t)ns) return 1;
+    const double Floors[3] = { TAudioMath::DbToLin(-48.0), TAudioMath::DbToLin(-24.0), TAudioMath::DbToLin(-12.0) };
+    const int NumberOfSamples = (int)ns;
+    for (int s = 0; s < 3; ++s) {
+      int Lead = 0;
+      for (int f = 0; f < NumberOfSamples; ++f, ++Lead)
+        if (TMathT<double>::Abs(x[(size_t)f]) > Floors[s]) break;
+      int Trail = 0;
+      for (int f = NumberOfSamples - 1; f > Lead; --f, ++Trail)
+        if (TMathT<double>::Abs(x[(size_t)f]) > Floors[s]) break;
+      res.push_back(TAudioMath::SamplesToMs(kSampleRate, NumberOfSamples - Lead - Trail) / 1000.0);
+    }
+  }
+  fclose(fi);
+  FILE* fo = fopen(outp, "wb"); if (!fo) return 1;
+  fwrite(res.data(), 8, res.size(), fo);
+  fclose(fo);
+  return 0;
+}
+
 // C2 subset timing: window -> FFT -> magnitude -> xtract_mfcc on uniform noise.
 static int CmdTime(int64_t nframes, unsigned seed) {
   TRef R;
@@ -508,7 +538,8 @@ int main(int argc, char** argv) {
   if (argc >= 4 && !strcmp(argv[1], "neighbours")) return CmdNeighbours(argv[2], argv[3], argc >= 5 && atoi(argv[4]) != 0);
   if (argc >= 2 && !strcmp(argv[1], "peakstest")) return CmdPeaksTest();
   if (argc >= 4 && !strcmp(argv[1], "load")) return CmdLoad(argv[2], argv[3]);
+  if (argc >= 4 && !strcmp(argv[1], "efflen")) return CmdEffectiveLength(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "time")) return CmdTime(atoll(argv[2]), (unsigned)atoi(argv[3]));
-  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|load|peakstest|time ...\n");
+  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|load|efflen|peakstest|time ...\n");
   return 2;
 }

@@ -65,6 +65,8 @@ def lib():
         L.afx_oracle_peaks.restype = ctypes.c_int
         L.afx_oracle_peaks.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p,
                                        ctypes.c_void_p]
+        L.afx_oracle_effective_length.restype = None
+        L.afx_oracle_effective_length.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         L.afx_oracle_run_mfcc.restype = ctypes.c_int64
         L.afx_oracle_run_mfcc.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
                                           ctypes.c_void_p]
@@ -154,6 +156,13 @@ class Oracle:
         out = np.zeros((nf, NEIGH_RECORD), dtype=np.float64)
         if nf:
             self.L.afx_oracle_run_neighbours(self.h, x.ctypes.data, x.size, int(cap), out.ctypes.data)
+        return out
+
+    def effective_length(self, x):
+        """seconds above -48 / -24 / -12 dB (CalcEffectiveLength)"""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.zeros(3)
+        self.L.afx_oracle_effective_length(self.h, x.ctypes.data, x.size, out.ctypes.data)
         return out
 
     def run_mfcc(self, x):

@@ -167,6 +167,32 @@ def main():
         out["data_" + name] = x
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "load.npz"), **out)
 
+    # effective lengths (per file): the golden signals, the long ones, and a few shaped for the three floors
+    rng = np.random.default_rng(20261006)
+    eff_in = dict(signals())
+    eff_in.update(long_signals())
+    ramp = np.concatenate([np.zeros(3000), np.linspace(0, 1, 20000), np.linspace(1, 0, 30000) ** 3, np.zeros(4000)])
+    eff_in["ramps"] = (ramp * np.sin(2 * np.pi * 300 * np.arange(ramp.size) / SR)).astype(np.float32)
+    eff_in["one_spike"] = np.zeros(5000, dtype=np.float32); eff_in["one_spike"][1234] = 0.5
+    eff_in["just_below_24dB"] = (0.06 * rng.uniform(-1, 1, 9000)).astype(np.float32)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        names = sorted(eff_in)
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<q", len(names)))
+            for k in names:
+                x = eff_in[k].astype(np.float64)
+                f.write(struct.pack("<q", x.size)); f.write(x.tobytes())
+        subprocess.check_call([REF, "efflen", fin, fout])
+        res = np.fromfile(fout, dtype=np.float64).reshape(len(names), 3)
+    stored_elsewhere = set(signals()) | set(long_signals())      # inputs already in frames.npz / neighbours.npz
+    for i, k in enumerate(names):
+        if k not in stored_elsewhere:
+            out["in_" + k] = eff_in[k]
+        out["ref_" + k] = res[i]
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "efflen.npz"), **out)
+
     # tables
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "t.bin")
@@ -183,7 +209,7 @@ def main():
         rows.append((n, cap, rec.shape[0]))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "framecount.npz"),
                         rows=np.array(rows, dtype=np.int64))
-    print("wrote tests/golden/{frames,neighbours,load,tables,framecount}.npz")
+    print("wrote tests/golden/{frames,neighbours,load,efflen,tables,framecount}.npz")
 
 
 if __name__ == "__main__":

@@ -60,6 +60,11 @@ static int TestAnalyse() {
       CHECK_EQUAL_EPSILON(R.mSpectralFlux.mValues[f], r[AFXO_FLUX], 1e-4 * std::fabs(r[AFXO_FLUX]) + 1e-7);
       CHECK(R.mAmplitudePeak.mValues[f] == r[AFXO_AMP_PEAK]);
     }
+    {
+      double eff[3];
+      afx_oracle_effective_length(o, Inputs[i]->data(), (int64_t)Inputs[i]->size(), eff);
+      CHECK(R.mEffectiveLength48dB == eff[0] && R.mEffectiveLength24dB == eff[1] && R.mEffectiveLength12dB == eff[2]);
+    }
     // the loop's neighbours
     {
       std::vector<double> nrec((size_t)nf * AFXN_RECORD);

@@ -246,3 +246,27 @@ def test_non_finite_samples_do_not_poison_other_frames_or_buffers(plan, oracle):
         _tol.check(field, res[field][off[0]:off[1]][clean], ref[clean, col], rtol, atol, what="frames without the NaN ")
         _tol.check(field, res[field][off[1]:off[2]], ref[:, col], rtol, atol, what="second buffer ")
     assert np.all(np.isfinite(res["spectral_complexity"]))
+
+
+def test_effective_length_golden_and_beyond_the_cap(oracle):
+    """per-file effective lengths (AFX_D_EFFECTIVE_LENGTH) against the reference goldens; the scan covers the
+    whole buffer, also the part beyond the analysed 20 s"""
+    z = np.load(os.path.join(GOLD, "efflen.npz"))
+    names = sorted(k[4:] for k in z.files if k.startswith("ref_"))
+    inputs = [z["in_" + n] if "in_" + n in z.files else neighbour_input(n) for n in names]
+    capped = afx.Plan(max_analysis_ms=20000)
+    res = capped.extract(inputs, afx.D_EFFECTIVE_LENGTH | afx.D_MFCC)
+    np.testing.assert_array_equal(res["effective_length"], np.stack([z["ref_" + n] for n in names]))
+    alone = capped.extract(inputs, afx.D_EFFECTIVE_LENGTH)      # no per-frame descriptor at all
+    np.testing.assert_array_equal(alone["effective_length"], res["effective_length"])
+    rng = np.random.default_rng(31)
+    long = np.zeros(882000 + 60000)
+    long[1000:882000 + 50000] = 0.2 * rng.standard_normal(882000 + 49000)     # audible well past 20 s
+    short = np.zeros(700); short[100:300] = 0.5                                # shorter than a frame
+    for dt in (np.float32, np.float64):
+        bufs = [long.astype(dt), short.astype(dt), np.zeros(3000, dt)]
+        got = capped.extract(bufs, afx.D_EFFECTIVE_LENGTH | afx.D_SPECTRAL_RMS)["effective_length"]
+        want = np.stack([oracle.effective_length(b.astype(np.float64)) for b in bufs])
+        np.testing.assert_array_equal(got, want)
+        assert want[0, 0] > 20.5 and np.all(want[2] == 0.0)
+    capped.close()

@@ -235,3 +235,34 @@ def test_oracle_load_sample_matches_reference_golden(name):
     assert np.float32(info["peak_value"]) == z["peakrms_" + name][0]
     assert np.float32(info["rms_value"]) == z["peakrms_" + name][1]
     np.testing.assert_array_equal(got, z["data_" + name])
+
+
+# ---- effective length (per file) ----------------------------------------------------------------
+
+def efflen_input(z, name):
+    """inputs of efflen.npz live there, or in frames.npz / neighbours.npz when they are the shared golden signals"""
+    if "in_" + name in z.files:
+        return z["in_" + name]
+    return _shared_golden_input(name)
+
+
+def _shared_golden_input(name):
+    for fn in ("frames.npz", "neighbours.npz"):
+        zz = np.load(os.path.join(GOLD, fn))
+        if "in_" + name in zz.files:
+            return zz["in_" + name]
+    raise KeyError(name)
+
+
+def test_oracle_effective_length_matches_reference_golden(oracle):
+    """CalcEffectiveLength (SampleAnalyser.cpp:1715-1755) against `ref_driver efflen`: exact"""
+    z = np.load(os.path.join(GOLD, "efflen.npz"))
+    names = sorted(k[4:] for k in z.files if k.startswith("ref_"))
+    assert len(names) >= 10
+    for name in names:
+        got = oracle.effective_length(efflen_input(z, name).astype(np.float64))
+        np.testing.assert_array_equal(got, z["ref_" + name], err_msg=name)
+    # the three floors are nested
+    for name in names:
+        r = z["ref_" + name]
+        assert r[0] >= r[1] >= r[2] >= 0.0

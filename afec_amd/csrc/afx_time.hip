@@ -51,6 +51,7 @@ __device__ __forceinline__ void load16(const double* p, double (&x)[16]) {
   }
 }
 
+using mask64 = unsigned long long;
 __device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -63,9 +64,23 @@ __device__ __forceinline__ int wave_max_i(int v) {
   return v;
 }
 
-// aubio_silence_detection: 10 log10(mean x^2) < threshold (mathutils.c:605-615)
-__device__ __forceinline__ bool au_silent(double sum_sq, int n, double threshold_db) {
-  return 10.0 * log10(sum_sq / (double)n) < threshold_db;
+// aubio_silence_detection: 10 log10(mean x^2) < -48 dB (mathutils.c:605-615, MSilenceThresholdDb).  log10 is
+// monotonic, so the test is mean x^2 < 10^-4.8 (they can only disagree for a level within an ulp of the
+// threshold); a NaN level is "not silent" in both forms.
+__device__ __forceinline__ bool au_silent(double sum_sq, int n) {
+  return sum_sq / (double)n < 1.5848931924611134e-05;
+}
+
+// n / d for positive normal d and moderate n: v_rcp_f64 seed, two Newton steps, then one residual correction
+// of the quotient (exact whenever n / d is representable, e.g. the all-equal difference function of a constant
+// signal, where the reference's argmin rule depends on exact ties).  The generic division with its range
+// scaling is ~25 instructions and the normalisation below needs one per lag.
+__device__ __forceinline__ double fast_div(double n, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  const double q = n * r;
+  return fma(fma(-d, q, n), r, q);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -121,7 +136,7 @@ __global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
       top = wave_max(top);
 
       if (lane == 0) {
-        if (a.lay.silence >= 0) rec[a.lay.silence] = au_silent(e, kHop, -48.0) ? 1.0 : 0.0;   // SA:865-868
+        if (a.lay.silence >= 0) rec[a.lay.silence] = au_silent(e, kHop) ? 1.0 : 0.0;   // SA:865-868
         if (a.lay.envelope >= 0) rec[a.lay.envelope] = top;
       }
     }
@@ -200,54 +215,71 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
       int remaining = remaining0 - fi * kHop;          // mData.Size() - n, >= 2048 for an emitted frame
       double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
 
+      // Everything the two searches and the correlation may touch -- samples 0 .. 2111 of the frame, as far as
+      // the buffer has them (the arena keeps up to 64 samples past the last frame) -- is loaded in one go:
+      // a[q] = x[64 q + lane], b[q] = x[64 q + lane + 1].  "x[p+1] > x[p]" is then one ballot per row and the
+      // first-index searches are scalar bit scans; no load depends on a search result.
+      constexpr int kRowsHeld = 33;
+      const int lim = min(remaining, 64 * kRowsHeld);
+      TIn ra[kRowsHeld], rb[kRowsHeld];
+#pragma unroll
+      for (int q = 0; q < kRowsHeld; ++q) {
+        const int p = 64 * q + lane;
+        ra[q] = (q < 32 || p < lim) ? x[p] : (TIn)0;
+        rb[q] = (q < 31 || p + 1 < lim) ? x[p + 1] : (TIn)0;
+      }
       // first rising step in [0, min(remaining, 1024) - 1)  (SA:2328-2341)
       int start = 0;
       {
         const int bound = min(remaining, kMaxSeek) - 1;
-        double v[16];
-        load16(x + 16 * lane, v);
-        double nxt = __shfl_down(v[0], 1);
-        if (lane == 63) nxt = (double)x[kMaxSeek];
-        int first = kBig;
+        bool found = false;
 #pragma unroll
-        for (int i = 15; i >= 0; --i) {
-          const double hi = (i == 15) ? nxt : v[i + 1];
-          if (hi > v[i] && 16 * lane + i < bound) first = 16 * lane + i;
+        for (int q = 0; q < kMaxSeek / 64; ++q) {
+          if (!found && 64 * q < bound) {
+            mask64 m = __ballot(rb[q] > ra[q]);
+            const int valid = bound - 64 * q;
+            if (valid < 64) m &= ((mask64)1 << valid) - 1;
+            if (m) { start = 64 * q + __ffsll((long long)m) - 1; found = true; }
+          }
         }
-        first = wave_min_i(first);
-        if (first != kBig) { start = first; remaining -= first; }
+        if (found) remaining -= start;
       }
-      // next rising step after the minimum period (SA:2343-2356)
+      // next rising step after the minimum period (SA:2343-2356): positions [lo, hi) of the frame
       const int seek_off = min(remaining, kMinPeriod);
       int period = seek_off;
       {
         const int bound = min(remaining - seek_off, kMaxSeek) - 1;
-        const TIn* const y = x + start + seek_off;
-        double v[17];
+        const int lo = start + seek_off, hi = lo + bound;
+        bool found = false;
 #pragma unroll
-        for (int i = 0; i < 17; ++i) {
-          const int j = 16 * lane + i;
-          v[i] = (j <= bound) ? (double)y[j] : 0.0;    // y[bound] = x[start + remaining - 1 .. ] at most
+        for (int q = 0; q < kRowsHeld; ++q) {
+          if (!found && 64 * q + 63 >= lo && 64 * q < hi) {
+            mask64 m = __ballot(rb[q] > ra[q]);
+            if (64 * q < lo) m &= ~(((mask64)1 << (lo - 64 * q)) - 1);
+            if (hi - 64 * q < 64) m &= ((mask64)1 << (hi - 64 * q)) - 1;
+            if (m) { period = seek_off + (64 * q + __ffsll((long long)m) - 1 - lo); found = true; }
+          }
         }
-        int first = kBig;
-#pragma unroll
-        for (int i = 15; i >= 0; --i)
-          if (v[i + 1] > v[i] && 16 * lane + i < bound) first = 16 * lane + i;
-        first = wave_min_i(first);
-        if (first != kBig) period = seek_off + first;
       }
       double best = 0.0;
       if (remaining != 0 && period < remaining) {
         const int width = min(remaining, kSeekWidth);
-        const TIn* const s = x + start;
+        // the segment x[start .. start + width) sits in rows start/64 .. start/64 + 9: through the plane
+        const int q0 = start >> 6, off = start & 63;
+        wave_lds_fence();
+#pragma unroll
+        for (int q = 0; q < 25; ++q)
+          if (q >= q0 && q < q0 + 10) c.plane_d[64 * (q - q0) + lane] = (double)ra[q];
+        wave_lds_fence();
         // r[i] = sum_j s[j] s[j+i] through the 2048-point transform of the zero-padded segment
         cx<double> v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int j = 2 * (64 * r + lane);
           v[r] = {0.0, 0.0};
-          if (r < 5) v[r] = {(j < width) ? (double)s[j] : 0.0, (j + 1 < width) ? (double)s[j + 1] : 0.0};
+          if (r < 5) v[r] = {(j < width) ? c.plane_d[off + j] : 0.0, (j + 1 < width) ? c.plane_d[off + j + 1] : 0.0};
         }
+        wave_lds_fence();
         fft(v, c);
         // power spectrum P[k] = |X[k]|^2, P[1024-k] = |E - w O|^2, then the packed spectrum of the inverse:
         // Zc = Ec + i Oc, Ec = (P + P')/2, Oc = (P - P')/2 conj(w^k); constant factors dropped (r is used
@@ -310,37 +342,55 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];
+    // transform of the zero-padded first half of the chunk's first frame (packed z[m] = x[2m] + i x[2m+1])
+    cx<double> zu[16];
+    {
+      const Pair* src = reinterpret_cast<const Pair*>(pcm + ch.sample_off) + lane;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        zu[r] = {0.0, 0.0};
+        if (r < 8) {
+          const Pair p = src[64 * r];
+          zu[r] = {(double)p.x, (double)p.y};
+        }
+      }
+    }
+    fft(zu, c);
     for (int fi = 0; fi < ch.nframes; ++fi) {
       const TIn* const x = pcm + ch.sample_off + (int64_t)fi * kHop;
       double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
 
-      // ---- r_t(tau) = sum_{j<W} x[j] x[j+tau], tau < W: spectra of the frame and of its first half ----
-      cx<double> zx[16], zu[16];
+      // ---- r_t(tau) = sum_{j<W} x[j] x[j+tau], tau < W, as conj(U) X: U = spectrum of the zero-padded first
+      //      half, X = spectrum of the frame = U + (-1)^k Un with Un the spectrum of the zero-padded second half.
+      //      The second half is the next frame's first half, so each frame costs one forward transform. ----
+      cx<double> zn[16];
       {
-        const Pair* src = reinterpret_cast<const Pair*>(x) + lane;
+        const Pair* src = reinterpret_cast<const Pair*>(x + W) + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const Pair p = src[64 * r];
-          zx[r] = {(double)p.x, (double)p.y};
-          zu[r] = (r < 8) ? zx[r] : cx<double>{0.0, 0.0};
+          zn[r] = {0.0, 0.0};
+          if (r < 8) {
+            const Pair p = src[64 * r];
+            zn[r] = {(double)p.x, (double)p.y};
+          }
         }
       }
-      fft(zx, c);
-      fft(zu, c);
+      fft(zn, c);
+      const double sign = (lane & 1) ? -1.0 : 1.0;      // (-1)^k, k = lane + 64 r (1024 - k has the same parity)
       cx<double> g[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const cx<double> px = partner_of(zx, r, c), pu = partner_of(zu, r, c);
+        const cx<double> pu = partner_of(zu, r, c), pn = partner_of(zn, r, c);
         const cx<double> w = c.post[64 * r];
         cx<double> e, o;
-        even_odd(zx[r], px, e, o);
-        cx<double> wo = cmul(w, o);
-        const cx<double> X{0.5 * (e.re + wo.re), 0.5 * (e.im + wo.im)};
-        const cx<double> Xp{0.5 * (e.re - wo.re), -0.5 * (e.im - wo.im)};   // X[1024-k] = conj(E - w O)
         even_odd(zu[r], pu, e, o);
-        wo = cmul(w, o);
+        cx<double> wo = cmul(w, o);
         const cx<double> U{0.5 * (e.re + wo.re), 0.5 * (e.im + wo.im)};
-        const cx<double> Up{0.5 * (e.re - wo.re), -0.5 * (e.im - wo.im)};
+        const cx<double> Up{0.5 * (e.re - wo.re), -0.5 * (e.im - wo.im)};     // U[1024-k] = conj(E - w O)
+        even_odd(zn[r], pn, e, o);
+        wo = cmul(w, o);
+        const cx<double> X{U.re + sign * (0.5 * (e.re + wo.re)), U.im + sign * (0.5 * (e.im + wo.im))};
+        const cx<double> Xp{Up.re + sign * (0.5 * (e.re - wo.re)), Up.im - sign * (0.5 * (e.im - wo.im))};
         // C = conj(U) X at k and at 1024-k
         const cx<double> C{U.re * X.re + U.im * X.im, U.re * X.im - U.im * X.re};
         const cx<double> Cp{Up.re * Xp.re + Up.im * Xp.im, Up.re * Xp.im - Up.im * Xp.re};
@@ -350,6 +400,9 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
         const cx<double> oc{d.re * w.re + d.im * w.im, d.im * w.re - d.re * w.im};
         g[r] = {ec.re - oc.im, -(ec.im + oc.re)};      // conj(Zc)
       }
+      // the second half's transform is the next frame's first-half transform
+#pragma unroll
+      for (int r = 0; r < 16; ++r) zu[r] = zn[r];
       fft(g, c);
       // c[2m] = Re F[m] / 1024, c[2m+1] = -Im F[m] / 1024, m = lane + 64 r; tau < 1024 <=> r < 8.
       // To the blocked layout through the plane.
@@ -406,7 +459,8 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       for (int i = 0; i < 16; ++i) {
         const int tau = 16 * lane + i;
         const double tmp2 = cum_before + cum[i];
-        yin[i] = (tau == 0) ? 1.0 : ((tmp2 != 0) ? yin[i] * ((double)tau / tmp2) : 1.0);
+        // yin[tau] *= tau / tmp2 (pitchyinfast.c:148-150); tmp2 >= 0 is a sum of a^2 + b^2 - ab terms
+        yin[i] = (tau == 0) ? 1.0 : ((tmp2 != 0) ? yin[i] * fast_div((double)tau, tmp2) : 1.0);
       }
 
       // ---- first dip below the tolerance, else the (last) global minimum (pitchyinfast.c:154-163) ----
@@ -448,7 +502,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       const double conf_raw = 1.0 - c.plane_d[pad_slot(at)];
       wave_lds_fence();
       double f0 = (period > 0.0) ? (double)kSampleRate / (period + 0.) : 0.0;       // pitch.c:450-462
-      if (au_silent(s0 + s1, kFft, -48.0)) f0 = 0.0;                                 // pitch.c:399-406
+      if (au_silent(s0 + s1, kFft)) f0 = 0.0;                                 // pitch.c:399-406
       // SA:886-895: confidence / MMaxPitchConfidenceValue clipped to [0, 1]
       double conf = conf_raw / 0.25;
       conf = (conf < 0.0) ? 0.0 : (conf > 1.0 ? 1.0 : conf);
@@ -457,7 +511,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
         rec[a.lay.f0] = nan_to_zero(f0);
         rec[a.lay.f0_conf] = conf;
         // hop silence (SA:865-868) parked in the fail-safe slot for afx_whiten.hip, which replaces it
-        rec[a.lay.f0_safe] = au_silent(s0, kHop, -48.0) ? 1.0 : 0.0;
+        rec[a.lay.f0_safe] = au_silent(s0, kHop) ? 1.0 : 0.0;
       }
     }
   }

@@ -377,41 +377,42 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       }
       fft(zn, c);
       const double sign = (lane & 1) ? -1.0 : 1.0;      // (-1)^k, k = lane + 64 r (1024 - k has the same parity)
+      // C = conj(U) X at k and at 1024-k, then the packed spectrum of the inverse: Zc = Ec + i Oc,
+      // Ec = (C + conj(C'))/2, Oc = (C - conj(C'))/2 conj(w^k).  The factors 1/2 are carried along instead of
+      // applied (2E, 2O, 2U, 2X, 4C, 8 Zc: exact) and undone with the 1/1024 of the inverse.
       cx<double> g[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const cx<double> pu = partner_of(zu, r, c), pn = partner_of(zn, r, c);
         const cx<double> w = c.post[64 * r];
-        cx<double> e, o;
+        cx<double> e, o, en, on;
         even_odd(zu[r], pu, e, o);
-        cx<double> wo = cmul(w, o);
-        const cx<double> U{0.5 * (e.re + wo.re), 0.5 * (e.im + wo.im)};
-        const cx<double> Up{0.5 * (e.re - wo.re), -0.5 * (e.im - wo.im)};     // U[1024-k] = conj(E - w O)
-        even_odd(zn[r], pn, e, o);
-        wo = cmul(w, o);
-        const cx<double> X{U.re + sign * (0.5 * (e.re + wo.re)), U.im + sign * (0.5 * (e.im + wo.im))};
-        const cx<double> Xp{Up.re + sign * (0.5 * (e.re - wo.re)), Up.im - sign * (0.5 * (e.im - wo.im))};
-        // C = conj(U) X at k and at 1024-k
+        even_odd(zn[r], pn, en, on);
+        const cx<double> wo = cmul(w, o), won = cmul(w, on);
+        const cx<double> U{e.re + wo.re, e.im + wo.im};
+        const cx<double> Up{e.re - wo.re, -(e.im - wo.im)};                  // U[1024-k] = conj(E - w O)
+        const cx<double> X{U.re + sign * (en.re + won.re), U.im + sign * (en.im + won.im)};
+        const cx<double> Xp{Up.re + sign * (en.re - won.re), Up.im - sign * (en.im - won.im)};
         const cx<double> C{U.re * X.re + U.im * X.im, U.re * X.im - U.im * X.re};
         const cx<double> Cp{Up.re * Xp.re + Up.im * Xp.im, Up.re * Xp.im - Up.im * Xp.re};
-        // packed spectrum of the inverse: Zc = Ec + i Oc, Ec = (C + conj(C'))/2, Oc = (C - conj(C'))/2 conj(w^k)
-        const cx<double> ec{0.5 * (C.re + Cp.re), 0.5 * (C.im - Cp.im)};
-        const cx<double> d{0.5 * (C.re - Cp.re), 0.5 * (C.im + Cp.im)};
+        const cx<double> ec{C.re + Cp.re, C.im - Cp.im};
+        const cx<double> d{C.re - Cp.re, C.im + Cp.im};
         const cx<double> oc{d.re * w.re + d.im * w.im, d.im * w.re - d.re * w.im};
-        g[r] = {ec.re - oc.im, -(ec.im + oc.re)};      // conj(Zc)
+        g[r] = {ec.re - oc.im, -(ec.im + oc.re)};      // conj(8 Zc)
       }
       // the second half's transform is the next frame's first-half transform
 #pragma unroll
       for (int r = 0; r < 16; ++r) zu[r] = zn[r];
       fft(g, c);
-      // c[2m] = Re F[m] / 1024, c[2m+1] = -Im F[m] / 1024, m = lane + 64 r; tau < 1024 <=> r < 8.
+      // c[2m] = Re F[m] / 1024, c[2m+1] = -Im F[m] / 1024 (and the carried factor 8), m = lane + 64 r;
+      // tau < 1024 <=> r < 8.
       // To the blocked layout through the plane.
       wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         const int t = 2 * (64 * r + lane);
-        c.plane_d[pad_slot(t)] = g[r].re * (1.0 / 1024.0);
-        c.plane_d[pad_slot(t) + 1] = -g[r].im * (1.0 / 1024.0);
+        c.plane_d[pad_slot(t)] = g[r].re * (1.0 / 8192.0);
+        c.plane_d[pad_slot(t) + 1] = -g[r].im * (1.0 / 8192.0);
       }
       wave_lds_fence();
       double corr[16];

@@ -697,6 +697,17 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   return AFX_OK;
 }
 
+// which of the two statistics kernels the batch needs (afx_stats.hip)
+void stats_regimes(const afx_batch* b, afx::StatsArgs* sa) {
+  sa->small_rows = 0;
+  sa->need_long = 0;
+  for (int32_t i = 0; i < b->n_bufs; ++i) {
+    const int64_t n = b->frame_offset[i + 1] - b->frame_offset[i];
+    if (n >= 2 && n <= 128) sa->small_rows = std::max<int32_t>(sa->small_rows, (int32_t)n);
+    else sa->need_long = 1;
+  }
+}
+
 bool mask_ok(uint32_t mask) {
   return (mask & ~(uint32_t)AFX_D_STATISTICS) != 0 &&
          !(mask & ~(uint32_t)(AFX_D_ALL_PER_FRAME | AFX_D_MAGNITUDE | AFX_D_STATISTICS | AFX_D_EFFECTIVE_LENGTH));
@@ -858,6 +869,7 @@ int afx_batch_run(afx_batch* b) {
       afx::StatsArgs sa{};
       sa.rec = b->d_rec; sa.frame_offset = b->d_frame_offset; sa.n_bufs = b->n_bufs; sa.stride = b->lay.stride;
       sa.stats = b->d_stats;
+      stats_regimes(b, &sa);
       HIP_TRY(afx::launch_stats(sa, b->stream));
     }
     return AFX_OK;
@@ -906,6 +918,7 @@ int afx_batch_run(afx_batch* b) {
     afx::StatsArgs sa{};
     sa.rec = b->d_rec; sa.frame_offset = b->d_frame_offset; sa.n_bufs = b->n_bufs; sa.stride = b->lay.stride;
     sa.stats = b->d_stats;
+    stats_regimes(b, &sa);
     HIP_TRY(afx::launch_stats(sa, b->stream));
   }
   return AFX_OK;

@@ -166,6 +166,8 @@ struct StatsArgs {
   int32_t n_bufs;
   int32_t stride;
   double* stats;                // [n_bufs][stride][13]
+  int32_t small_rows;           // longest series of 2..128 frames in the batch (0: none): lane-per-series kernel
+  int32_t need_long;            // some buffer has < 2 or > 128 frames: wave-per-series kernel
 };
 hipError_t launch_stats(const StatsArgs& a, hipStream_t stream);
 

@@ -168,6 +168,124 @@ __device__ void series_stats(const double* col, int64_t cstride, int n, int lane
   }
 }
 
+// ---- short series (2 <= n <= 128 frames): one LANE per series ----
+// A wave takes 64 adjacent record columns of one buffer; frame p of all of them is one coalesced 512-byte
+// row.  The moments are plain sequential sums (the reference's own order), and the median needs no sort:
+// with less_i = #{j : x_j < x_i}, the element at sorted position t is max{x_i : less_i <= t}.  x_j comes
+// from an LDS copy of the tile so that j can be a run-time loop while x_i and less_i stay in registers.
+constexpr int kSmallMax = 128;     // longest series this kernel takes (64 KiB of LDS per wave)
+constexpr int kRankChunk = 64;     // x_i held in registers at a time
+
+// one wave per workgroup; the tile is small_rows x 64 doubles (small_rows = longest short series of the batch),
+// so a CU holds as many waves as fit its 160 KiB of LDS
+__global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
+  extern __shared__ double tile_raw[];
+  const int lane = threadIdx.x;
+  double* const tile = tile_raw + lane;
+  const int groups = (a.stride + 63) / 64;
+  const int64_t total = (int64_t)a.n_bufs * groups;
+  for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
+    const int64_t buf = w / groups;
+    const int col = 64 * (int)(w - buf * groups) + lane;
+    const int64_t f0 = a.frame_offset[buf];
+    const int64_t nn = a.frame_offset[buf + 1] - f0;
+    if (nn < 2 || nn > kSmallMax) continue;               // other lengths: stats_kernel
+    const int n = (int)nn;
+    const bool active = col < a.stride;
+    const double* const base = a.rec + f0 * a.stride + (active ? col : 0);
+    // the tile in LDS: frame p of this lane's series at tile[64 p]; slots past n hold -inf (they never win
+    // the median's max and are never visited by the run-time loops below)
+    wave_lds_fence();
+    for (int p = 0; p < n; ++p) tile[64 * p] = base[(int64_t)p * a.stride];
+    for (int p = n; p < a.small_rows; ++p) tile[64 * p] = -__builtin_huge_val();
+    wave_lds_fence();
+    const double dn = (double)n;
+    double mn = tile[0], mx = mn, sum = 0.0, sj = 0.0, slog = 0.0, sd = 0.0;
+    {
+      double v = tile[0];
+#pragma unroll 4
+      for (int p = 0; p < n; ++p) {
+        const double nxt = (p + 1 < n) ? tile[64 * (p + 1)] : v;
+        mn = fmin(mn, v);
+        mx = fmax(mx, v);
+        sum += v;
+        sj += (double)p * v;
+        slog += fast_log(fabs(v) + 1e-20);                 // GeometricMean, Statistics.cpp:417-455
+        sd += fabs(nxt - v);                               // the last term is |v - v| = 0
+        v = nxt;
+      }
+    }
+    const double mean = sum / dn;
+    const double gmean = fast_exp(slog / dn);
+    const double cen = (sum == 0.0) ? 0.0 : sj / sum;      // Centroid, Statistics.cpp:459-477
+    const int nd = n - 1;
+    const double dmean = (nd >= 2) ? sd / (double)nd : sd;
+    const double spr_den = sum;
+    double var = 0.0, sv = 0.0, dvar = 0.0;
+    {
+      double v = tile[0];
+#pragma unroll 4
+      for (int p = 0; p < n; ++p) {
+        const bool has_next = p + 1 < n;
+        const double nxt = has_next ? tile[64 * (p + 1)] : v;
+        const double t = v - mean;
+        var += t * t;
+        const double u = (double)p - cen;
+        sv += u * u * v;
+        const double wd = fabs(nxt - v) - dmean;
+        dvar += has_next ? wd * wd : 0.0;
+        v = nxt;
+      }
+    }
+    var /= dn;
+    const double spr = (spr_den == 0.0) ? 0.0 : sv / spr_den;   // Spread, Statistics.cpp:486-506
+    double sk = 0.0, ku = 0.0;
+    {
+      // Statistics.cpp:510-554; (x - c) / v as (x - c) (1 / v): <= 1 ulp apart.  Lanes whose spread is below the
+      // cut run the loop on a harmless reciprocal and drop the result.
+      const bool on = fabs(spr) > (double)1e-12f;
+      const double rspr = on ? 1.0 / spr : 0.0;
+#pragma unroll 4
+      for (int p = 0; p < n; ++p) {
+        const double t = (tile[64 * p] - cen) * rspr;
+        const double tt = t * t;
+        sk += tt * t;
+        ku += tt * tt;
+      }
+      sk = on ? sk / dn : 0.0;
+      ku = on ? ku / dn - 3.0 : 0.0;
+    }
+    // median: element (n-1)/2 of the sorted series = max{x_i : #{j : x_j < x_i} <= (n-1)/2}; x_i in registers
+    // 64 at a time, x_j from the tile
+    const int target = (n - 1) / 2;
+    double med = mn;
+    for (int i0 = 0; i0 < n; i0 += kRankChunk) {
+      double x[kRankChunk];
+      int less[kRankChunk];
+#pragma unroll
+      for (int i = 0; i < kRankChunk; ++i) {
+        x[i] = (i0 + i < a.small_rows) ? tile[64 * (i0 + i)] : -__builtin_huge_val();
+        less[i] = 0;
+      }
+      for (int j = 0; j < n; ++j) {
+        const double y = tile[64 * j];
+#pragma unroll
+        for (int i = 0; i < kRankChunk; ++i) less[i] += (y < x[i]) ? 1 : 0;
+      }
+#pragma unroll
+      for (int i = 0; i < kRankChunk; ++i) med = fmax(med, (less[i] <= target) ? x[i] : mn);
+    }
+    if (active) {
+      double* const out = a.stats + (buf * a.stride + col) * 13;
+      out[0] = mn; out[1] = mx; out[2] = med; out[3] = mean; out[4] = gmean; out[5] = var;
+      out[6] = cen; out[7] = spr; out[8] = sk; out[9] = ku;
+      out[10] = (mean == 0.0) ? 0.0 : gmean / mean;        // Flatness, Statistics.cpp:565-574
+      out[11] = (n > 2) ? dmean : 0.0;
+      out[12] = (n > 2) ? ((nd >= 2) ? dvar / (double)nd : 0.0) : 0.0;
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void stats_kernel(const StatsArgs a) {
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -184,6 +302,7 @@ __global__ __launch_bounds__(256) void stats_kernel(const StatsArgs a) {
       continue;
     }
     const int n = (int)nn;
+    if (n >= 2 && n <= kSmallMax) continue;   // stats_small_kernel
     if (n <= 1) {      // Statistics.cpp:72-89: only min/max/mean (and zeros) are assigned
       if (lane < 13) out[lane] = 0.0;
       if (n == 1 && lane == 0) {
@@ -207,7 +326,25 @@ hipError_t launch_stats(const StatsArgs& a, hipStream_t stream) {
   if (total <= 0) return hipSuccess;
   const int64_t want = (total + 3) / 4;
   const int grid = (int)(want < 256 * 32 ? want : 256 * 32);
-  hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, stream, a);
+  hipError_t e = hipSuccess;
+  if (a.need_long) {
+    hipLaunchKernelGGL(stats_kernel, dim3(grid), dim3(256), 0, stream, a);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  }
+  // short series: lane-per-series kernel; 32 KiB of LDS per wave
+  static bool raised[16] = {};
+  if (a.small_rows <= 0) return hipSuccess;        // no buffer with 2..128 frames in this batch
+  const int lds = a.small_rows * 64 * 8;
+  constexpr int lds_max = kSmallMax * 64 * 8;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !raised[dev]) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(stats_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16) raised[dev] = true;
+  }
+  const int64_t waves = (int64_t)a.n_bufs * ((a.stride + 63) / 64);
+  hipLaunchKernelGGL(stats_small_kernel, dim3((unsigned)(waves < 16384 ? waves : 16384)), dim3(64), lds, stream, a);
   return hipGetLastError();
 }
 

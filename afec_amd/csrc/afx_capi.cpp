@@ -957,7 +957,11 @@ int afx_batch_fetch(afx_batch* b, afx_out* out) {
     for (int32_t i = 0; i < b->n_bufs; ++i)
       for (int j = 0; j < 3; ++j) {
         // TAudioMath::SamplesToMs is float arithmetic (AudioMath.inl:134-137); seconds = ms / 1000.0
-        const int samples = (int)(b->used[i] - lt[(size_t)i * 6 + 2 * j] - lt[(size_t)i * 6 + 2 * j + 1]);
+        // silent leading samples = index of the first sample above the floor (all of them when there is none);
+        // the trailing scan stops above that sample (SampleAnalyser.cpp:1731-1746)
+        const int64_t first = lt[(size_t)i * 6 + 2 * j], last = lt[(size_t)i * 6 + 2 * j + 1];
+        const int64_t lead = (last < 0) ? b->used[i] : first, trail = (last < 0) ? 0 : b->used[i] - 1 - last;
+        const int samples = (int)(b->used[i] - lead - trail);
         const float ms = (float)samples / ((float)b->plan->desc.sample_rate / 1000.0f);
         out->effective_length[(size_t)i * 3 + j] = (b->buf_status[i] == AFX_OK && b->used[i] > 0) ? (double)ms / 1000.0 : 0.0;
       }

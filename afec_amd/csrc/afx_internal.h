@@ -151,7 +151,7 @@ struct WhitenArgs {
 hipError_t launch_whiten(const WhitenArgs& a, hipStream_t stream);
 
 // effective length (SampleAnalyser.cpp:1715-1755): silent leading / trailing samples of every buffer at
-// three floors; out[n_bufs][6] = lead, trail at -48 dB, then -24 dB, then -12 dB
+// three floors; out[n_bufs][6] = first, last sample above the floor (INT_MAX, -1 when none) at -48, -24, -12 dB
 struct BufSpan {
   int64_t off;   // first sample of the buffer in the PCM arena
   int64_t n;     // samples (the whole buffer)

@@ -113,7 +113,13 @@ __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned
 }
 
 // CalcEffectiveLength (SampleAnalyser.cpp:1715-1755) on the normalised buffer: for each of three floors the
-// first and the last sample above it; one workgroup per buffer
+// first and the last sample above it.  out[buffer][6] = (first, last) x 3, initialised to (INT_MAX, -1);
+// a buffer is scanned by gridDim.y workgroups that merge with atomicMin / atomicMax.
+__global__ void effective_length_init_kernel(int32_t* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (i & 1) ? -1 : 0x7FFFFFFF;
+}
+
 template <typename TIn>
 __global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TIn* pcm, const BufSpan* spans, double f0,
                                                                         double f1, double f2, int32_t* out) {
@@ -121,8 +127,8 @@ __global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TI
   const BufSpan sp = spans[blockIdx.x];
   const TIn* const x = pcm + sp.off;
   const double floors[3] = {f0, f1, f2};
-  long long first[3] = {sp.n, sp.n, sp.n}, last[3] = {-1, -1, -1};
-  for (int64_t n = threadIdx.x; n < sp.n; n += kLoadThreads) {
+  long long first[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, last[3] = {-1, -1, -1};
+  for (int64_t n = (int64_t)blockIdx.y * kLoadThreads + threadIdx.x; n < sp.n; n += (int64_t)gridDim.y * kLoadThreads) {
     const double v = fabs((double)x[n]);
 #pragma unroll
     for (int j = 0; j < 3; ++j)
@@ -136,8 +142,8 @@ __global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TI
     const long long a = block_reduce(first[j], sl, [](long long p, long long q) { return p < q ? p : q; });
     const long long b = block_reduce(last[j], sl, [](long long p, long long q) { return p > q ? p : q; });
     if (threadIdx.x == 0) {
-      out[6 * blockIdx.x + 2 * j] = (int32_t)a;                                   // == n when nothing is above the floor
-      out[6 * blockIdx.x + 2 * j + 1] = (b < 0) ? 0 : (int32_t)(sp.n - 1 - b);    // the trailing scan stops above `lead`
+      if (a != 0x7FFFFFFF) atomicMin(&out[6 * blockIdx.x + 2 * j], (int32_t)a);
+      if (b >= 0) atomicMax(&out[6 * blockIdx.x + 2 * j + 1], (int32_t)b);
     }
   }
 }
@@ -147,11 +153,14 @@ __global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TI
 hipError_t launch_effective_length(const void* pcm, int pcm_dtype, const BufSpan* spans, int n_bufs, double floor48,
                                    double floor24, double floor12, int32_t* out, hipStream_t stream) {
   if (n_bufs <= 0) return hipSuccess;
+  hipLaunchKernelGGL(effective_length_init_kernel, dim3((6 * n_bufs + 255) / 256), dim3(256), 0, stream, out, 6 * n_bufs);
+  // few buffers: many workgroups per buffer; many buffers: one each
+  const int per_buffer = n_bufs >= 1024 ? 1 : (n_bufs >= 64 ? 8 : 128);
   if (pcm_dtype == 0)
-    hipLaunchKernelGGL(effective_length_kernel<float>, dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+    hipLaunchKernelGGL(effective_length_kernel<float>, dim3(n_bufs, per_buffer), dim3(kLoadThreads), 0, stream,
                        reinterpret_cast<const float*>(pcm), spans, floor48, floor24, floor12, out);
   else
-    hipLaunchKernelGGL(effective_length_kernel<double>, dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+    hipLaunchKernelGGL(effective_length_kernel<double>, dim3(n_bufs, per_buffer), dim3(kLoadThreads), 0, stream,
                        reinterpret_cast<const double*>(pcm), spans, floor48, floor24, floor12, out);
   return hipGetLastError();
 }

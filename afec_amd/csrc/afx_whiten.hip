@@ -56,22 +56,26 @@ __global__ __launch_bounds__(256) void follow_kernel(const WhitenArgs a) {
     const double* const col = a.mag + f_begin * kHalf + k;
     double* const save = a.follower + (int64_t)a.chunk_first[b] * kHalf + k;
     double follow = a.floor_value;                              // aubio_spectral_whitening_reset
+    // frames in batches of kAhead loads, whatever the chunk length (a lone 20 s file is cut into one-frame
+    // chunks to fill the chip: the loads must not wait for chunk boundaries)
     const int n32 = (int)n, per_chunk = a.chunk_frames;
-    for (int c0 = 0, ci = 0; c0 < n32; c0 += per_chunk, ++ci) {
-      save[(int64_t)ci * kHalf] = follow;                        // state at the chunk's first frame
-      const int c1 = (c0 + per_chunk < n32) ? c0 + per_chunk : n32;
-      for (int f0 = c0; f0 < c1; f0 += kAhead) {
-        double m[kAhead];
+    int next_save = 0, ci = 0;
+    for (int f0 = 0; f0 < n32; f0 += kAhead) {
+      double m[kAhead];
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j) m[j] = (f0 + j < c1) ? col[(int64_t)(f0 + j) * kHalf] : 0.0;
+      for (int j = 0; j < kAhead; ++j) m[j] = (f0 + j < n32) ? col[(int64_t)(f0 + j) * kHalf] : 0.0;
 #pragma unroll
-        for (int j = 0; j < kAhead; ++j)
-          if (f0 + j < c1) {
-            double t = a.decay * follow;
-            t = (t > a.floor_value) ? t : a.floor_value;
-            follow = (m[j] > t) ? m[j] : t;
+      for (int j = 0; j < kAhead; ++j)
+        if (f0 + j < n32) {
+          if (f0 + j == next_save) {                             // state at a chunk's first frame
+            save[(int64_t)ci * kHalf] = follow;
+            ++ci;
+            next_save += per_chunk;
           }
-      }
+          double t = a.decay * follow;
+          t = (t > a.floor_value) ? t : a.floor_value;
+          follow = (m[j] > t) ? m[j] : t;
+        }
     }
   }
 }

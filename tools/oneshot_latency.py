@@ -5,13 +5,13 @@ rng = np.random.default_rng(0)
 plan = afx.Plan()
 for secs, nrep in ((2.0, 200), (20.0, 50)):
     x = rng.uniform(-1, 1, int(44100 * secs)).astype(np.float32)
-    for mask, name in ((afx.D_C2, "mfcc"), (afx.D_ALL_LOW_LEVEL, "all")):
+    for mask, name in ((afx.D_C2, "mfcc"), (afx.D_ALL_LOW_LEVEL, "all"), (afx.D_ALL_PER_FRAME | afx.D_EFFECTIVE_LENGTH, "everything")):
         plan.extract([x], mask)
         t0 = time.perf_counter()
         for _ in range(nrep):
             plan.extract([x], mask)
         dt = (time.perf_counter() - t0) / nrep
-        print(f"one file of {secs:4.1f} s, {name:4s}: {dt*1e3:7.3f} ms per afx_extract_batch call  ({1/dt:7.0f} files/s)")
+        print(f"one file of {secs:4.1f} s, {name:10s}: {dt*1e3:7.3f} ms per afx_extract_batch call  ({1/dt:7.0f} files/s)")
 
 # PCIe-inclusive rate of a 10k-frame buffer from pageable and from page-locked host memory
 from afec_amd.capi import pinned_array

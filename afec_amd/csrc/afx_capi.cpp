@@ -138,10 +138,10 @@ struct Workspace {
   };
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen;
+  Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place;
   size_t bytes() const {
     return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
-           efflen.cap;
+           efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap;
   }
 };
 
@@ -292,7 +292,7 @@ void free_tables(afx_plan* p) {
 void ws_free(Workspace* w) {
   if (!w) return;
   for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
-                            &w->efflen}) hipFree(b->p);
+                            &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->stream) hipStreamDestroy(w->stream);
@@ -546,12 +546,16 @@ namespace {
 // size esz) using b->stream.
 template <typename Fill>
 int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const std::vector<int64_t>& lengths,
-                const std::vector<int32_t>& status, bool zero_arena, Fill fill, afx_batch** out_batch) {
+                const std::vector<int32_t>& status, bool zero_arena, Fill fill, afx_batch** out_batch,
+                Workspace* acquired = nullptr) {
   const bool want_stats = (mask & AFX_D_STATISTICS) != 0;
   mask &= ~(uint32_t)AFX_D_STATISTICS;   // the kernels see the descriptor bits only
 
   afx_batch* b = new (std::nothrow) afx_batch();
-  if (!b) return fail(AFX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  if (!b) {
+    ws_release(plan, acquired);
+    return fail(AFX_ERR_OUT_OF_MEMORY, "host allocation failed");
+  }
   b->plan = plan;
   b->mask = mask;
   b->n_bufs = n_bufs;
@@ -592,7 +596,11 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   }
   b->frame_offset[n_bufs] = frames;
   b->total_frames = frames;
-  if (frames > 0x7FFFFF00LL) { delete b; return fail(AFX_ERR_INVALID_ARG, "more than 2^31 frames in one batch"); }
+  if (frames > 0x7FFFFF00LL) {
+    delete b;
+    ws_release(plan, acquired);
+    return fail(AFX_ERR_INVALID_ARG, "more than 2^31 frames in one batch");
+  }
 
   // chunking: K consecutive frames per wave; enough chunks to fill the chip, long enough to
   // amortise the 2048-sample lead-in of each chunk
@@ -637,7 +645,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
 
   auto cleanup = [&](int st) { afx_batch_destroy(b); return st; };
   hipError_t e = hipSuccess;
-  b->ws = ws_acquire(plan, &e);
+  b->ws = acquired ? acquired : ws_acquire(plan, &e);
   if (!b->ws) return cleanup(hip_fail(e, "workspace"));
   Workspace& w = *b->ws;
   b->stream = w.stream; b->ev0 = w.ev0; b->ev1 = w.ev1;
@@ -777,19 +785,22 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     files[i] = afx::LoadFile{raw_bytes, r.n_frames, r.channels, r.format};
     raw_bytes += ((int64_t)r.n_frames * r.channels * bps + 15) & ~(int64_t)15;
   }
-  hipStream_t s = nullptr;
+  // device staging of the decoded PCM and the scan results lives in the batch's pooled workspace
+  hipError_t e = hipSuccess;
+  Workspace* ws = ws_acquire(plan, &e);
+  if (!ws) return hip_fail(e, "workspace");
+  hipStream_t s = ws->stream;
+  auto bail = [&](int st) { ws_release(plan, ws); return st; };
   unsigned char* d_raw = nullptr;
   afx::LoadFile* d_files = nullptr;
   afx::LoadScan* d_scan = nullptr;
-  auto free_tmp = [&]() { hipFree(d_raw); hipFree(d_files); hipFree(d_scan); if (s) hipStreamDestroy(s); };
-  auto bail = [&](int st) { free_tmp(); return st; };
-  hipError_t e;
   std::vector<afx::LoadScan> scan((size_t)n_bufs);
   if (n_bufs > 0) {
-    if ((e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) return bail(hip_fail(e, "hipStreamCreate"));
-    if ((e = hipMalloc((void**)&d_raw, (size_t)raw_bytes + 16)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(raw)"));
-    if ((e = hipMalloc((void**)&d_files, files.size() * sizeof(afx::LoadFile))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(files)"));
-    if ((e = hipMalloc((void**)&d_scan, scan.size() * sizeof(afx::LoadScan))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(scan)"));
+    if ((e = ws_reserve(ws->raw, (size_t)raw_bytes + 16)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(raw)"));
+    if ((e = ws_reserve(ws->files, files.size() * sizeof(afx::LoadFile))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(files)"));
+    if ((e = ws_reserve(ws->scan, scan.size() * sizeof(afx::LoadScan))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(scan)"));
+    if ((e = ws_reserve(ws->partial, (size_t)n_bufs * afx::load_scan_blocks_per_file(n_bufs) * 16)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(partial)"));
+    d_raw = (unsigned char*)ws->raw.p; d_files = (afx::LoadFile*)ws->files.p; d_scan = (afx::LoadScan*)ws->scan.p;
     for (int i = 0; i < n_bufs; ++i)
       if (status[i] == AFX_OK) {
         const int bps = raws[i].format == AFX_RAW_I16 ? 2 : (raws[i].format == AFX_RAW_I24 ? 3 : 4);
@@ -799,7 +810,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     if ((e = hipMemcpyAsync(d_files, files.data(), files.size() * sizeof(afx::LoadFile), hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(files)"));
     // -48 dB of full scale (MSilenceThresholdDb, SampleAnalyser.cpp:51, 648-649)
     const double silence_floor = 32768.0 * std::exp(-48.0 * (std::log(10.0) / 20.0));
-    if ((e = afx::launch_load_scan(d_raw, d_files, n_bufs, silence_floor, d_scan, s)) != hipSuccess) return bail(hip_fail(e, "load_scan"));
+    if ((e = afx::launch_load_scan(d_raw, d_files, n_bufs, silence_floor, ws->partial.p, d_scan, s)) != hipSuccess) return bail(hip_fail(e, "load_scan"));
     if ((e = hipMemcpyAsync(scan.data(), d_scan, scan.size() * sizeof(afx::LoadScan), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(scan)"));
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(hip_fail(e, "hipStreamSynchronize"));
   }
@@ -810,7 +821,10 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
   for (int i = 0; i < n_bufs; ++i) {
     place[i] = afx::LoadPlace{};
     if (status[i] != AFX_OK) { if (info) info[i] = afx_load_info{}; continue; }
-    const int64_t n = files[i].n_frames, lead = scan[i].lead, trail = scan[i].trail;
+    // silent leading samples = index of the first sample above the floor (all of them when there is none); the
+    // trailing scan stops above that sample (SampleAnalyser.cpp:651-669)
+    const int64_t n = files[i].n_frames;
+    const int64_t lead = (scan[i].trail < 0) ? n : scan[i].lead, trail = (scan[i].trail < 0) ? 0 : n - 1 - scan[i].trail;
     const int64_t audible = n - lead - trail;
     const int64_t end_pad = ((audible % fft) < fft / 2) ? fft / 2 : 0;
     const int64_t start_pad = (audible + end_pad < fft) ? fft - audible - end_pad : 0;
@@ -828,19 +842,17 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     }
   }
   auto fill = [&](afx_batch* b) -> int {
-    afx::LoadPlace* d_place = nullptr;
     hipError_t e2;
     for (int i = 0; i < n_bufs; ++i) place[i].out_off = b->arena_off[i], place[i].out_n = b->used[i];
-    if ((e2 = hipMalloc((void**)&d_place, place.size() * sizeof(afx::LoadPlace))) != hipSuccess) return hip_fail(e2, "hipMalloc(place)");
+    if ((e2 = ws_reserve(ws->place, place.size() * sizeof(afx::LoadPlace))) != hipSuccess) return hip_fail(e2, "hipMalloc(place)");
+    afx::LoadPlace* d_place = (afx::LoadPlace*)ws->place.p;
     e2 = hipMemcpyAsync(d_place, place.data(), place.size() * sizeof(afx::LoadPlace), hipMemcpyHostToDevice, b->stream);
     if (e2 == hipSuccess) e2 = afx::launch_load_write(d_raw, d_files, d_place, n_bufs, (double*)b->d_pcm, b->stream);
-    if (e2 == hipSuccess) e2 = hipStreamSynchronize(b->stream);
-    hipFree(d_place);
+    if (e2 == hipSuccess) e2 = hipStreamSynchronize(b->stream);   // `place` is a pageable host vector
     return e2 == hipSuccess ? AFX_OK : hip_fail(e2, "load_write");
   };
-  const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch);
-  free_tmp();
-  return st;
+  // the workspace (with the staged PCM in it) moves into the batch; build_batch releases it on failure
+  return build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch, ws);
 }
 
 int afx_batch_fetch_samples(afx_batch* b, int32_t buf, double* dst, int64_t n) {

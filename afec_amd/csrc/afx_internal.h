@@ -178,11 +178,11 @@ struct LoadFile {
   int32_t channels;
   int32_t format;    // AFX_RAW_*
 };
-struct LoadScan {    // per file, produced by the scan kernel
+struct LoadScan {    // per file, produced by the scan kernels
   double sum_sq;         // sum (x / 32768)^2 of the mono mix
   double amplification;  // 32768 / max|x|  (1 when silent)
   float max_amp;         // max |x| of the mono mix in "16-bit float" units
-  int32_t lead, trail;   // silent leading / trailing samples at -48 dB after normalisation
+  int32_t lead, trail;   // first / last sample above -48 dB after normalisation (INT_MAX / -1 when none)
   int32_t pad;
 };
 struct LoadPlace {   // per file, where the normalised samples go
@@ -193,8 +193,9 @@ struct LoadPlace {   // per file, where the normalised samples go
   int64_t start_pad; // zeros in front (StartFrameOffset)
   double scaling;    // FinalScaling
 };
+int load_scan_blocks_per_file(int n_files);      // partial_scratch holds n_files x this x 16 bytes
 hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int n_files, double silence_floor,
-                            LoadScan* scan, hipStream_t stream);
+                            void* partial_scratch, LoadScan* scan, hipStream_t stream);
 hipError_t launch_load_write(const unsigned char* raw, const LoadFile* files, const LoadPlace* place, int n_files,
                              double* arena, hipStream_t stream);
 

@@ -3,10 +3,10 @@
 // TSampleAnalyser::LoadSample (SampleAnalyser.cpp:484-718) after the container decode: conversion to
 // the "16-bit float" range, mono mix-down, rms / peak, peak normalisation factor, -48 dB silence trim
 // and zero padding.  Byte / integer work and two reductions per file: HBM-bound by construction
-// (2..4 bytes in, 8 bytes out per sample), one workgroup per file.
+// (2..4 bytes in, 8 bytes out per sample).
 //
-//   load_scan   pass 1: max |x| and sum (x/32768)^2 of the mono mix; pass 2 (same workgroup): first and
-//               last sample whose normalised magnitude exceeds the silence floor
+//   load_scan   max |x| and sum (x/32768)^2 of the mono mix, then first and last sample whose normalised
+//               magnitude exceeds the silence floor (three small kernels, several workgroups per file)
 //   load_write  writes scaling * x[lead + n] as doubles behind start_pad zeros (the arena is pre-zeroed)
 
 #include <hip/hip_runtime.h>
@@ -52,21 +52,26 @@ __device__ __forceinline__ T block_reduce(T v, T* scratch, Op op) {
   return r;
 }
 
-__global__ __launch_bounds__(kLoadThreads) void load_scan_kernel(const unsigned char* raw, const LoadFile* files,
-                                                                 double silence_floor, LoadScan* scan) {
+// A file is scanned by gridDim.y workgroups (many when the batch has few files, one when it has thousands).
+// Stage 1: per-workgroup partial sum of squares and maximum; stage 2 (one workgroup per file) adds the
+// partials in index order -- the result does not depend on timing -- and derives the amplification;
+// stage 3: first / last sample above the silence floor, merged with atomicMin / atomicMax.
+struct LoadPartial {
+  double sum_sq;
+  float max_amp;
+  float pad;
+};
+
+__global__ __launch_bounds__(kLoadThreads) void load_scan1_kernel(const unsigned char* raw, const LoadFile* files,
+                                                                  LoadPartial* partial) {
   __shared__ double sd[kLoadThreads / 64];
   __shared__ float sf[kLoadThreads / 64];
-  __shared__ long long sl[kLoadThreads / 64];
   const LoadFile f = files[blockIdx.x];
-  if (f.n_frames <= 0) {
-    if (threadIdx.x == 0) scan[blockIdx.x] = LoadScan{0.0, 1.0, 0.0f, 0, 0, 0};
-    return;
-  }
   const unsigned char* src = raw + f.raw_off;
-  // pass 1: rms and peak (SampleAnalyser.cpp:612-637)
+  // rms and peak (SampleAnalyser.cpp:612-637)
   double sum_sq = 0.0;
   float mx = 0.0f;
-  for (int64_t n = threadIdx.x; n < f.n_frames; n += kLoadThreads) {
+  for (int64_t n = (int64_t)blockIdx.y * kLoadThreads + threadIdx.x; n < f.n_frames; n += (int64_t)gridDim.y * kLoadThreads) {
     const float x = mono_sample(src, f.format, f.channels, n);
     const double t = (double)(x / 32768.0f);
     sum_sq += t * t;
@@ -74,11 +79,38 @@ __global__ __launch_bounds__(kLoadThreads) void load_scan_kernel(const unsigned 
   }
   sum_sq = block_reduce(sum_sq, sd, [](double a, double b) { return a + b; });
   mx = block_reduce(mx, sf, [](float a, float b) { return fmaxf(a, b); });
-  const double max_amp = (double)mx;
-  const double amplification = (max_amp > (double)1e-12f) ? 32768.0 / max_amp : 1.0;
-  // pass 2: silent leading / trailing samples (SampleAnalyser.cpp:651-669)
-  long long first = f.n_frames, last = -1;
-  for (int64_t n = threadIdx.x; n < f.n_frames; n += kLoadThreads) {
+  if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * gridDim.y + blockIdx.y] = LoadPartial{sum_sq, mx, 0.0f};
+}
+
+__global__ void load_scan2_kernel(const LoadFile* files, const LoadPartial* partial, int per_file, int n_files, LoadScan* scan) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_files) return;
+  double sum_sq = 0.0;
+  float mx = 0.0f;
+  if (files[i].n_frames > 0)
+    for (int y = 0; y < per_file; ++y) {
+      sum_sq += partial[(int64_t)i * per_file + y].sum_sq;
+      mx = fmaxf(mx, partial[(int64_t)i * per_file + y].max_amp);
+    }
+  LoadScan r;
+  r.sum_sq = sum_sq;
+  r.amplification = ((double)mx > (double)1e-12f) ? 32768.0 / (double)mx : 1.0;   // SampleAnalyser.cpp:639-640
+  r.max_amp = mx;
+  r.lead = 0x7FFFFFFF;      // first sample above the floor (stage 3)
+  r.trail = -1;             // last sample above the floor
+  r.pad = 0;
+  scan[i] = r;
+}
+
+__global__ __launch_bounds__(kLoadThreads) void load_scan3_kernel(const unsigned char* raw, const LoadFile* files,
+                                                                  double silence_floor, LoadScan* scan) {
+  __shared__ long long sl[kLoadThreads / 64];
+  const LoadFile f = files[blockIdx.x];
+  const unsigned char* src = raw + f.raw_off;
+  const double amplification = scan[blockIdx.x].amplification;
+  // silent leading / trailing samples (SampleAnalyser.cpp:651-669)
+  long long first = 0x7FFFFFFF, last = -1;
+  for (int64_t n = (int64_t)blockIdx.y * kLoadThreads + threadIdx.x; n < f.n_frames; n += (int64_t)gridDim.y * kLoadThreads) {
     const float x = mono_sample(src, f.format, f.channels, n);
     if (fabs(amplification * (double)x) > silence_floor) {
       first = n < first ? n : first;
@@ -87,15 +119,9 @@ __global__ __launch_bounds__(kLoadThreads) void load_scan_kernel(const unsigned 
   }
   first = block_reduce(first, sl, [](long long a, long long b) { return a < b ? a : b; });
   last = block_reduce(last, sl, [](long long a, long long b) { return a > b ? a : b; });
-  if (threadIdx.x == 0) {
-    LoadScan r;
-    r.sum_sq = sum_sq;
-    r.amplification = amplification;
-    r.max_amp = mx;
-    r.lead = (int32_t)first;                                      // == n_frames when everything is silent
-    r.trail = (last < 0) ? 0 : (int32_t)(f.n_frames - 1 - last);  // the trailing scan stops above `lead`
-    r.pad = 0;
-    scan[blockIdx.x] = r;
+  if (threadIdx.x == 0 && last >= 0) {
+    atomicMin(&scan[blockIdx.x].lead, (int32_t)first);
+    atomicMax(&scan[blockIdx.x].trail, (int32_t)last);
   }
 }
 
@@ -165,10 +191,16 @@ hipError_t launch_effective_length(const void* pcm, int pcm_dtype, const BufSpan
   return hipGetLastError();
 }
 
+int load_scan_blocks_per_file(int n_files) { return n_files >= 1024 ? 1 : (n_files >= 64 ? 8 : 64); }
+
 hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int n_files, double silence_floor,
-                            LoadScan* scan, hipStream_t stream) {
+                            void* partial_scratch, LoadScan* scan, hipStream_t stream) {
   if (n_files <= 0) return hipSuccess;
-  hipLaunchKernelGGL(load_scan_kernel, dim3(n_files), dim3(kLoadThreads), 0, stream, raw, files, silence_floor, scan);
+  const int per_file = load_scan_blocks_per_file(n_files);
+  LoadPartial* partial = reinterpret_cast<LoadPartial*>(partial_scratch);
+  hipLaunchKernelGGL(load_scan1_kernel, dim3(n_files, per_file), dim3(kLoadThreads), 0, stream, raw, files, partial);
+  hipLaunchKernelGGL(load_scan2_kernel, dim3((n_files + 255) / 256), dim3(256), 0, stream, files, partial, per_file, n_files, scan);
+  hipLaunchKernelGGL(load_scan3_kernel, dim3(n_files, per_file), dim3(kLoadThreads), 0, stream, raw, files, silence_floor, scan);
   return hipGetLastError();
 }
 

@@ -205,7 +205,6 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
   const TIn* const pcm = reinterpret_cast<const TIn*>(a.pcm);
   // TAudioMath::MsToSamples(44100, 0.8f) = 35, (44100, 12.0f) = 529 (float maths, AudioMath.inl:127-130)
   constexpr int kMinPeriod = 35, kSeekWidth = 529, kMaxSeek = kFft / 2;
-  constexpr int kBig = 1 << 30;
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];

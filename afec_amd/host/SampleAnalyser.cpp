@@ -98,17 +98,50 @@ struct TBatchGuard {
 // The whole of AnalyzeLowLevelDescriptors' loop (SampleAnalyser.cpp:814-976) and of CalcStatistics
 // (SampleAnalyser.cpp:1065, 2402-2412) runs on the GPU: every per-frame series and its 13 statistics come
 // back from one resident batch.
+namespace {
+constexpr uint32_t kEverything = AFX_D_ALL_PER_FRAME | AFX_D_EFFECTIVE_LENGTH | AFX_D_STATISTICS;
+std::vector<TSampleDescriptors> Collect(TBatchGuard& Batch, int32_t n, std::vector<std::string>* pFailed);
+}  // namespace
+
 std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
     const std::vector<const std::vector<double>*>& Samples, std::vector<std::string>* pFailed) const {
   const int32_t n = (int32_t)Samples.size();
   std::vector<afx_buf> Buffers((size_t)n);
   for (int32_t i = 0; i < n; ++i) Buffers[i] = {Samples[i]->data(), AFX_PCM_F64, 0, (int64_t)Samples[i]->size()};
-
   TBatchGuard Batch;
-  int Status = afx_batch_create(mpPlan, Buffers.data(), n, AFX_D_ALL_PER_FRAME | AFX_D_EFFECTIVE_LENGTH | AFX_D_STATISTICS,
-                                &Batch.mpBatch);
+  int Status = afx_batch_create(mpPlan, Buffers.data(), n, kEverything, &Batch.mpBatch);
   if (Status == AFX_OK) Status = afx_batch_run(Batch.mpBatch);
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
+  return Collect(Batch, n, pFailed);
+}
+
+// LoadSample (SampleAnalyser.cpp:443-719, after the container decode) + AnalyzeLowLevelDescriptors +
+// CalcStatistics for decoded files: conversion, mono mix-down, normalisation, silence trim and padding run
+// on the GPU as well (afx_batch_create_from_raw)
+std::vector<TSampleDescriptors> TSampleAnalyser::Analyze(const std::vector<TDecodedSample>& Files,
+                                                         std::vector<TSampleDataInfo>* pInfo,
+                                                         std::vector<std::string>* pFailed) const {
+  const int32_t n = (int32_t)Files.size();
+  std::vector<afx_raw> Raws((size_t)n);
+  for (int32_t i = 0; i < n; ++i)
+    Raws[i] = {Files[i].mpInterleavedSamples, Files[i].mFormat, Files[i].mNumberOfChannels, Files[i].mSampleRate, 0,
+               Files[i].mNumberOfSampleFrames};
+  std::vector<afx_load_info> Info((size_t)n);
+  TBatchGuard Batch;
+  int Status = afx_batch_create_from_raw(mpPlan, Raws.data(), n, kEverything, &Batch.mpBatch, Info.data());
+  if (Status == AFX_OK) Status = afx_batch_run(Batch.mpBatch);
+  if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
+  if (pInfo) {
+    pInfo->resize((size_t)n);
+    for (int32_t i = 0; i < n; ++i)
+      (*pInfo)[i] = {Info[i].peak_value, Info[i].rms_value, Info[i].data_offset, Info[i].n_samples};
+  }
+  return Collect(Batch, n, pFailed);
+}
+
+namespace {
+std::vector<TSampleDescriptors> Collect(TBatchGuard& Batch, int32_t n, std::vector<std::string>* pFailed) {
+  int Status = AFX_OK;
   const size_t F = (size_t)afx_batch_total_frames(Batch.mpBatch);
 
   // host arrays for every series: [F][W] values and [n][W][13] statistics
@@ -163,6 +196,7 @@ std::vector<TSampleDescriptors> TSampleAnalyser::AnalyzeLowLevelDescriptors(
   }
   return Results;
 }
+}  // namespace
 
 TSampleDescriptors TSampleAnalyser::AnalyzeLowLevelDescriptors(const std::vector<double>& SampleData,
                                                                bool WithMagnitudes) const {

@@ -60,6 +60,21 @@ struct TSampleDescriptors {
   std::vector<double> mMagnitudeSpectrum;
 };
 
+// one decoded file as the reference's decoders hand it to LoadSample: interleaved PCM (SampleAnalyser.cpp:484-530)
+struct TDecodedSample {
+  const void* mpInterleavedSamples;
+  int mFormat;              // AFX_RAW_I16 / AFX_RAW_I24 / AFX_RAW_F32 of include/afx.h
+  int mNumberOfChannels;    // 1..8
+  int mSampleRate;          // 0 = the analyser's rate; other rates must be resampled by the caller
+  int64_t mNumberOfSampleFrames;
+};
+// what LoadSample leaves in TSampleData besides the samples (Export/SampleAnalyser.h:75-100)
+struct TSampleDataInfo {
+  float mPeakValue, mRmsValue;
+  int mDataOffset;
+  int64_t mNumberOfSamples;   // size of the normalised, trimmed, padded mono buffer
+};
+
 class TSampleAnalyser {
 public:
   // Device: HIP device ordinal.  Throws TReadableException when the GPU path cannot be set up.
@@ -79,6 +94,11 @@ public:
   // that could not be analysed (one bad sample does not fail the batch, SampleAnalyser.cpp:368-408)
   std::vector<TSampleDescriptors> AnalyzeLowLevelDescriptors(
       const std::vector<const std::vector<double>*>& Samples, std::vector<std::string>* pFailed = nullptr) const;
+
+  // LoadSample + AnalyzeLowLevelDescriptors + CalcStatistics for decoded files, everything on the GPU
+  std::vector<TSampleDescriptors> Analyze(const std::vector<TDecodedSample>& Files,
+                                          std::vector<TSampleDataInfo>* pInfo = nullptr,
+                                          std::vector<std::string>* pFailed = nullptr) const;
 
 private:
   afx_plan* mpPlan;

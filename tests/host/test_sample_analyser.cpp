@@ -104,6 +104,31 @@ static int TestAnalyse() {
   }
   afx_oracle_destroy(o);
 
+  // decoded files through the GPU LoadSample front end: same descriptors as analysing the oracle's normalised buffer
+  {
+    std::vector<short> Pcm(2 * 30000);
+    for (int i = 0; i < 30000; ++i) {
+      const double v = 0.4 * std::sin(2 * M_PI * 330.0 * i / 44100.0) * std::exp(-i / 9000.0) + 0.01 * U(gen);
+      Pcm[2 * i] = (short)std::lround(v * 20000.0);
+      Pcm[2 * i + 1] = (short)std::lround(0.7 * v * 20000.0);
+    }
+    std::vector<afec::TSampleDataInfo> Info;
+    std::vector<std::string> LoadFailed;
+    const auto FromFile = Analyser.Analyze({{Pcm.data(), /*AFX_RAW_I16*/ 0, 2, 44100, 30000}}, &Info, &LoadFailed);
+    CHECK(FromFile.size() == 1 && LoadFailed[0].empty());
+    afx_oracle_load_info OracleInfo;
+    double* pMono = afx_oracle_load_sample(Pcm.data(), 0, 2, 30000, 2048, &OracleInfo);
+    CHECK(Info[0].mNumberOfSamples == OracleInfo.n_samples && Info[0].mDataOffset == OracleInfo.data_offset);
+    CHECK(Info[0].mPeakValue == OracleInfo.peak_value);
+    const std::vector<double> Mono(pMono, pMono + OracleInfo.n_samples);
+    afx_oracle_free(pMono);
+    const auto FromBuffer = Analyser.AnalyzeLowLevelDescriptors(Mono);
+    CHECK(FromFile[0].mF0.mValues == FromBuffer.mF0.mValues);
+    CHECK(FromFile[0].mSpectralCentroid.mValues == FromBuffer.mSpectralCentroid.mValues);
+    CHECK(FromFile[0].mCepstrumBands.mMedian == FromBuffer.mCepstrumBands.mMedian);
+    CHECK(FromFile[0].mEffectiveLength24dB == FromBuffer.mEffectiveLength24dB);
+  }
+
   // error behaviour: an unsupported geometry throws like the reference's constructor would assert
   bool Thrown = false;
   try { afec::TSampleAnalyser Bad(48000, 2048, 1024); } catch (const afec::TReadableException&) { Thrown = true; }

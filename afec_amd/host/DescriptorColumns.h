@@ -1,0 +1,43 @@
+// afec_amd/host/DescriptorColumns.h -- the on-disk representation of the low-level descriptors this library
+// produces (the data-format half): column names and value encodings exactly as the reference's
+// TSqliteSampleDescriptorPool writes them into its `assets` table
+// (Source/Crawler/FeatureExtraction/Source/SqliteSampleDescriptorPool.cpp:1313-1358 DDL, 1582-1651 insert):
+//
+//   <descriptor>_<R|VR|VVR>             one column per TDescriptor::Values() entry, in Descriptors() order
+//   R    REAL, the double itself
+//   VR   BLOB, msgpack array of float64          (per-frame series of a scalar; per-band statistics)
+//   VVR  BLOB, msgpack array of arrays of float64 ([frame][band] series)
+//
+// (low-level descriptors carry kAllowBinaryStorage and not kAllowFloatingPointPrecisionStorage,
+// SampleDescriptors.cpp:16-27, so every number is a float64: 0xcb + 8 bytes big-endian, msgpack-c 2.1.)
+//
+// The sqlite container itself is not written here (no sqlite headers in the image); a writer binds these
+// columns one to one.  Columns of descriptors this library does not compute (file_*, rhythm_*) are absent.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "SampleAnalyser.h"
+
+namespace afec {
+
+struct TColumn {
+  enum TType { kReal, kBlob };
+  std::string mName;   // e.g. "spectral_centroid_VR", "cepstrum_bands_median_VR", "effectve_length_48dB_R"
+  TType mType;
+  double mReal;                 // kReal
+  std::vector<uint8_t> mBlob;   // kBlob: msgpack
+};
+
+// msgpack encodings of SToMsgpack (SqliteSampleDescriptorPool.cpp:596-713)
+std::vector<uint8_t> ToMsgpack(const double* pValues, size_t Count);
+std::vector<uint8_t> ToMsgpack(const double* pValues, size_t Rows, size_t Width);   // [Rows][Width]
+
+// the columns of one analysed sample, in the reference's column order (SampleDescriptors.cpp:150-205);
+// pInfo adds analyzation_offset_R (SampleAnalyser.cpp:748-749)
+std::vector<TColumn> LowLevelColumns(const TSampleDescriptors& Descriptors, const TSampleDataInfo* pInfo = nullptr,
+                                     int SampleRate = 44100);
+
+}  // namespace afec

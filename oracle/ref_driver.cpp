@@ -17,6 +17,7 @@
 //   ref_driver neighbours <in.bin> <out.bin> [cap]  per-frame records of the stateful neighbours (kNeigh)
 //   ref_driver load    <in.bin> <out.bin>        LoadSample normalisation front end (SampleAnalyser.cpp:484-718)
 //   ref_driver efflen  <in.bin> <out.bin>        effective lengths at -48/-24/-12 dB per buffer (3 doubles each)
+//   ref_driver msgpack <in.bin> <out.bin>        BLOB encoding of a VR / VVR column (SqliteSampleDescriptorPool.cpp:596-713)
 //   ref_driver time    <n_frames> <seed>         C2 subset timing (STFT + MFCC), prints frames/s
 //
 // in.bin : int64 n_bufs ; per buffer: int64 n_samples, double[n_samples]
@@ -43,6 +44,7 @@ extern "C" {
 #include "AudioTypes/Export/AudioTypes.h"
 #include "AudioTypes/Export/Envelopes.h"
 #include "FeatureExtraction/Source/Autocorrelation.h"
+#include <msgpack.hpp>   // 3rdParty/Msgpack/Dist/include (header-only, version 2.1), as SqliteSampleDescriptorPool.cpp uses it
 extern "C" {
 #include "aubio.h"   // 3rdParty/Aubio/Dist/src, smpl_t = double (HAVE_AUBIO_DOUBLE, as Export/Aubio.h sets it)
 }
@@ -510,6 +512,33 @@ static int CmdEffectiveLength(const char* in, const char* outp) {
   return 0;
 }
 
+// SToMsgpack (SqliteSampleDescriptorPool.cpp:596-713) for the low-level descriptors (kAllowBinaryStorage, doubles):
+// the reference's own msgpack packer on a TList<double> (width 0) or a TList<TStaticArray<double, W>>.
+// in.bin: int32 width, int32 pad, int64 rows, double[rows * max(width, 1)]; out.bin: the BLOB
+static int CmdMsgpack(const char* in, const char* outp) {
+  FILE* fi = fopen(in, "rb"); if (!fi) return 1;
+  int32_t width = 0, pad = 0; int64_t rows = 0;
+  if (fread(&width, 4, 1, fi) != 1 || fread(&pad, 4, 1, fi) != 1 || fread(&rows, 8, 1, fi) != 1) return 1;
+  std::vector<double> v((size_t)rows * (size_t)std::max(width, 1));
+  if (!v.empty() && fread(v.data(), 8, v.size(), fi) != v.size()) return 1;
+  fclose(fi);
+  msgpack::sbuffer Buffer;
+  msgpack::packer<msgpack::sbuffer> Packer(&Buffer);
+  Packer.pack_array((uint32_t)rows);
+  if (width == 0) {
+    for (int64_t i = 0; i < rows; ++i) Packer.pack(v[(size_t)i]);
+  } else {
+    for (int64_t i = 0; i < rows; ++i) {
+      Packer.pack_array((uint32_t)width);
+      for (int j = 0; j < width; ++j) Packer.pack(v[(size_t)i * width + j]);
+    }
+  }
+  FILE* fo = fopen(outp, "wb"); if (!fo) return 1;
+  fwrite(Buffer.data(), 1, Buffer.size(), fo);
+  fclose(fo);
+  return 0;
+}
+
 // C2 subset timing: window -> FFT -> magnitude -> xtract_mfcc on uniform noise.
 static int CmdTime(int64_t nframes, unsigned seed) {
   TRef R;
@@ -539,7 +568,8 @@ int main(int argc, char** argv) {
   if (argc >= 2 && !strcmp(argv[1], "peakstest")) return CmdPeaksTest();
   if (argc >= 4 && !strcmp(argv[1], "load")) return CmdLoad(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "efflen")) return CmdEffectiveLength(argv[2], argv[3]);
+  if (argc >= 4 && !strcmp(argv[1], "msgpack")) return CmdMsgpack(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "time")) return CmdTime(atoll(argv[2]), (unsigned)atoi(argv[3]));
-  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|load|efflen|peakstest|time ...\n");
+  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|load|efflen|msgpack|peakstest|time ...\n");
   return 2;
 }

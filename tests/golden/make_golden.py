@@ -117,6 +117,32 @@ def run_ref_load(data, channels):
     return np.array([peak, rms], dtype=np.float32), np.array([off, lead, trail, n], dtype=np.int64), x
 
 
+def column_values(n, width=0, salt=0):
+    """Deterministic, exactly representable test values for the column encoder (the C++ host test generates the
+    same ones): v[i] = ((i * i + 7 * salt) % 97) / 8 - 3, with a zero, a negative zero and an integer mixed in."""
+    m = n * max(width, 1)
+    i = np.arange(m, dtype=np.int64)
+    v = ((i * i + 7 * salt) % 97) / 8.0 - 3.0
+    if m > 2:
+        v[1] = 0.0
+        v[2] = -0.0
+    if m > 3:
+        v[3] = 43.0 * 1000
+    return v.reshape(n, width) if width else v
+
+
+def run_ref_msgpack(values, width):
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    rows = values.shape[0]
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<iiq", width, 0, rows))
+            f.write(values.tobytes())
+        subprocess.check_call([REF, "msgpack", fin, fout])
+        return np.frombuffer(open(fout, "rb").read(), dtype=np.uint8).copy()
+
+
 def run_ref(bufs, cap=0, mode="frames", record=1147):
     with tempfile.TemporaryDirectory() as d:
         fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
@@ -193,6 +219,18 @@ def main():
         out["ref_" + k] = res[i]
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "efflen.npz"), **out)
 
+    # BLOB encoding of the low-level columns (the reference's vendored msgpack-c through SToMsgpack's calls)
+    import hashlib
+    out = {}
+    for n in (0, 1, 15, 16, 860):
+        out[f"vr_{n}"] = run_ref_msgpack(column_values(n, 0, n), 0)
+    for rows, width in ((0, 14), (3, 14), (20, 28), (860, 14)):
+        out[f"vvr_{rows}x{width}"] = run_ref_msgpack(column_values(rows, width, rows + width), width)
+    big = run_ref_msgpack(column_values(70000, 0, 5), 0)                 # array 32 header; only its digest is kept
+    out["vr_70000_sha256"] = np.frombuffer(hashlib.sha256(big.tobytes()).digest(), dtype=np.uint8).copy()
+    out["vr_70000_head"] = big[:14].copy()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "columns.npz"), **out)
+
     # tables
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "t.bin")
@@ -209,7 +247,7 @@ def main():
         rows.append((n, cap, rec.shape[0]))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "framecount.npz"),
                         rows=np.array(rows, dtype=np.int64))
-    print("wrote tests/golden/{frames,neighbours,load,efflen,tables,framecount}.npz")
+    print("wrote tests/golden/{frames,neighbours,load,efflen,columns,tables,framecount}.npz")
 
 
 if __name__ == "__main__":

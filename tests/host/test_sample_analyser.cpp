@@ -2,6 +2,8 @@
 // own Boost tests (Source/Crawler/FeatureExtraction/Test/TestStatistics.cpp).
 //
 //   host_test nodevice  error behaviour without a usable device (no GPU needed)
+//   host_test columns <out.bin>   column names + encodings of a synthetic TSampleDescriptors (no GPU); the Python
+//                                 side compares them with the reference's msgpack output and column list
 //   host_test analyse   TSampleAnalyser::AnalyzeLowLevelDescriptors vs the oracle (GPU)
 #include <cmath>
 #include <cstdio>
@@ -9,6 +11,7 @@
 #include <random>
 #include <vector>
 
+#include "../../afec_amd/host/DescriptorColumns.h"
 #include "../../afec_amd/host/SampleAnalyser.h"
 #include "../../oracle/afx_oracle.h"
 
@@ -25,6 +28,64 @@ static int TestNoDevice() {
   try { afec::TSampleAnalyser Analyser(44100, 2048, 1024, /*Device*/ 9999); } catch (const afec::TReadableException&) { Thrown = true; }
   CHECK(Thrown);     // no such device: the constructor reports it like the reference's would (exception), no fallback
   return gFailures;
+}
+
+// the same exactly representable values tests/golden/make_golden.py column_values() produces
+static std::vector<double> ColumnValues(size_t n, size_t width, long long salt) {
+  const size_t m = n * (width ? width : 1);
+  std::vector<double> v(m);
+  for (size_t i = 0; i < m; ++i) v[i] = (double)(((long long)(i * i) + 7 * salt) % 97) / 8.0 - 3.0;
+  if (m > 2) { v[1] = 0.0; v[2] = -0.0; }
+  if (m > 3) v[3] = 43.0 * 1000;
+  return v;
+}
+
+static void Put(FILE* f, const std::vector<uint8_t>& b) {
+  const uint64_t n = b.size();
+  std::fwrite(&n, 8, 1, f);
+  if (n) std::fwrite(b.data(), 1, n, f);
+}
+
+// file: blobs of the golden cases, then the columns of a synthetic sample as (name, type, payload)
+static int DumpColumns(const char* pPath) {
+  FILE* f = std::fopen(pPath, "wb");
+  if (!f) return 1;
+  for (size_t n : {0u, 1u, 15u, 16u, 860u, 70000u}) {
+    const auto v = ColumnValues(n, 0, n == 70000u ? 5 : (long long)n);
+    Put(f, afec::ToMsgpack(v.data(), n));
+  }
+  const size_t Shapes[4][2] = {{0, 14}, {3, 14}, {20, 28}, {860, 14}};
+  for (const auto& s : Shapes) {
+    const auto v = ColumnValues(s[0], s[1], (long long)(s[0] + s[1]));
+    Put(f, afec::ToMsgpack(v.data(), s[0], s[1]));
+  }
+  afec::TSampleDescriptors D;
+  const size_t Frames = 5;
+  D.mEffectiveLength48dB = 1.5; D.mEffectiveLength24dB = 1.25; D.mEffectiveLength12dB = 0.5;
+  D.mSpectralCentroid.mValues = ColumnValues(Frames, 0, 1);
+  D.mSpectralCentroid.mMedian = 2.5;
+  D.mSpectralCentroid.mDVariance = -0.125;
+  D.mF0.mValues = ColumnValues(Frames, 0, 2);
+  const auto c = ColumnValues(Frames, 14, 3);
+  D.mCepstrumBands.mValues.resize(Frames);
+  for (size_t fr = 0; fr < Frames; ++fr)
+    for (size_t b = 0; b < 14; ++b) D.mCepstrumBands.mValues[fr][b] = c[fr * 14 + b];
+  for (size_t b = 0; b < 14; ++b) D.mCepstrumBands.mMean[b] = (double)b / 4.0;
+  afec::TSampleDataInfo Info = {0.5f, 0.25f, -2205, 90000};
+  const auto Columns = afec::LowLevelColumns(D, &Info);
+  const uint64_t Count = Columns.size();
+  std::fwrite(&Count, 8, 1, f);
+  for (const auto& Col : Columns) {
+    const uint64_t Len = Col.mName.size();
+    std::fwrite(&Len, 8, 1, f);
+    std::fwrite(Col.mName.data(), 1, Len, f);
+    const uint8_t Type = (uint8_t)Col.mType;
+    std::fwrite(&Type, 1, 1, f);
+    if (Col.mType == afec::TColumn::kReal) std::fwrite(&Col.mReal, 8, 1, f);
+    else Put(f, Col.mBlob);
+  }
+  std::fclose(f);
+  return 0;
 }
 
 static int TestAnalyse() {
@@ -140,6 +201,7 @@ int main(int argc, char** argv) {
   int rc = 2;
   try {
     if (argc >= 2 && !std::strcmp(argv[1], "nodevice")) rc = TestNoDevice();
+    else if (argc >= 3 && !std::strcmp(argv[1], "columns")) rc = DumpColumns(argv[2]);
     else if (argc >= 2 && !std::strcmp(argv[1], "analyse")) rc = TestAnalyse();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());

@@ -76,6 +76,52 @@ std::vector<uint8_t> ToMsgpack(const double* pValues, size_t Rows, size_t Width)
   return Out;
 }
 
+std::vector<TColumnSpec> LowLevelSchema() {
+  static const char* const kStats[] = {"_min", "_max", "_median", "_mean", "_gmean", "_variance", "_centroid", "_spread",
+                                       "_skewness", "_kurtosis", "_flatness", "_dmean", "_dvariance"};
+  std::vector<TColumnSpec> Out;
+  auto Scalar = [&](const char* pName, const char* pPostfix, const char* pType) {
+    Out.push_back(TColumnSpec{std::string(pName) + "_" + pPostfix, pType});
+  };
+  auto FramedScalar = [&](const char* pName) {      // TFramedScalarData: VR BLOB + 13 REAL
+    Out.push_back(TColumnSpec{std::string(pName) + "_VR", "BLOB"});
+    for (const char* s : kStats) Out.push_back(TColumnSpec{std::string(pName) + s + "_R", "REAL"});
+  };
+  auto FramedVector = [&](const char* pName) {      // TFramedVectorData<W>: VVR BLOB + 13 VR BLOB
+    Out.push_back(TColumnSpec{std::string(pName) + "_VVR", "BLOB"});
+    for (const char* s : kStats) Out.push_back(TColumnSpec{std::string(pName) + s + "_VR", "BLOB"});
+  };
+  // SampleDescriptors.cpp:29-37, 150-157 (shared), Export/SampleDescriptors.h:384-390 (types)
+  Scalar("file_type", "S", "TEXT");
+  Scalar("file_size", "R", "INTEGER");
+  Scalar("file_length", "R", "REAL");
+  Scalar("file_sample_rate", "R", "INTEGER");
+  Scalar("file_channel_count", "R", "INTEGER");
+  Scalar("file_bit_depth", "R", "INTEGER");
+  // SampleDescriptors.cpp:159-205 (low level)
+  for (const char* n : {"effectve_length_48dB", "effectve_length_24dB", "effectve_length_12dB", "analyzation_offset"})
+    Scalar(n, "R", "REAL");
+  for (const char* n : {"amplitude_silence", "amplitude_peak", "amplitude_rms", "amplitude_envelope", "spectral_rms",
+                        "spectral_centroid", "spectral_rolloff", "spectral_spread", "spectral_skewness",
+                        "spectral_kurtosis", "spectral_flatness", "spectral_inharmonicity", "spectral_complexity",
+                        "spectral_contrast", "spectral_flux", "f0", "f0_confidence", "failsafe_f0", "tristimulus1",
+                        "tristimulus2", "tristimulus3", "auto_correlation"})
+    FramedScalar(n);
+  for (const char* kind : {"rhythm_complex", "rhythm_percussive"}) {
+    const std::string k(kind);
+    FramedScalar((k + "_onsets").c_str());
+    for (const char* n : {"_onset_count", "_onset_contrast", "_onset_frequency_mean", "_onset_strength", "_tempo",
+                          "_tempo_confidence"})
+      Scalar((k + n).c_str(), "R", "REAL");
+  }
+  Scalar("rhythm_final_tempo", "R", "REAL");
+  Scalar("rhythm_final_tempo_confidence", "R", "REAL");
+  for (const char* n : {"spectral_rms_bands", "spectral_flatness_bands", "spectral_flux_bands",
+                        "spectral_complexity_bands", "spectral_contrast_bands", "frequency_bands", "cepstrum_bands"})
+    FramedVector(n);
+  return Out;
+}
+
 std::vector<TColumn> LowLevelColumns(const TSampleDescriptors& D, const TSampleDataInfo* pInfo, int SampleRate) {
   std::vector<TColumn> Out;
   // order of TSampleDescriptors::Descriptors(kLowLevelDescriptors), SampleDescriptors.cpp:150-205 (the file_* and

@@ -11,8 +11,9 @@
 // (low-level descriptors carry kAllowBinaryStorage and not kAllowFloatingPointPrecisionStorage,
 // SampleDescriptors.cpp:16-27, so every number is a float64: 0xcb + 8 bytes big-endian, msgpack-c 2.1.)
 //
-// The sqlite container itself is not written here (no sqlite headers in the image); a writer binds these
-// columns one to one.  Columns of descriptors this library does not compute (file_*, rhythm_*) are absent.
+// LowLevelSchema() lists every column of the reference's low-level `assets` table with its sqlite type;
+// LowLevelColumns() holds the values of the descriptors this library computes (everything but the file_*
+// properties, which the caller knows, and rhythm_*).  SqlitePool.h writes them into a sqlite file.
 #pragma once
 
 #include <cstdint>
@@ -30,6 +31,15 @@ struct TColumn {
   double mReal;                 // kReal
   std::vector<uint8_t> mBlob;   // kBlob: msgpack
 };
+
+// name and declared sqlite type ("TEXT", "INTEGER", "REAL", "BLOB") of every descriptor column of the reference's
+// low-level `assets` table, in its order (SqliteSampleDescriptorPool.cpp:1313-1358 on
+// TSampleDescriptors::Descriptors(kLowLevelDescriptors)); filename / modtime / status precede them
+struct TColumnSpec {
+  std::string mName;
+  const char* mpSqliteType;
+};
+std::vector<TColumnSpec> LowLevelSchema();
 
 // msgpack encodings of SToMsgpack (SqliteSampleDescriptorPool.cpp:596-713)
 std::vector<uint8_t> ToMsgpack(const double* pValues, size_t Count);

@@ -1,0 +1,44 @@
+// afec_amd/host/SqlitePool.h -- the reference's low-level descriptor database:
+// TSqliteSampleDescriptorPool (Source/Crawler/FeatureExtraction/Export/SqliteSampleDescriptorPool.h,
+// Source/SqliteSampleDescriptorPool.cpp:1290-1358 tables, 1582-1690 inserts) for the descriptors this
+// library produces.  `PRAGMA user_version = 2`, one `assets` table with the reference's columns; columns of
+// descriptors that are not computed here (rhythm_*) stay NULL.
+//
+// sqlite is bound at run time (dlopen of libsqlite3.so.0: the image ships the library but not its headers);
+// the constructor throws TReadableException when it is not there.
+#pragma once
+
+#include <string>
+
+#include "DescriptorColumns.h"
+#include "SampleAnalyser.h"
+
+namespace afec {
+
+// the "Basic Data" of TSampleDescriptors the analyser cannot know (SampleAnalyser.cpp:730-746)
+struct TFileProperties {
+  std::string mFileType;   // lower-case extension
+  int mFileSize = 0;       // bytes
+  double mFileLength = 0;  // seconds
+  int mFileSampleRate = 0, mFileChannelCount = 0, mFileBitDepth = 0;
+};
+
+class TSqliteSampleDescriptorPool {
+public:
+  explicit TSqliteSampleDescriptorPool(const std::string& DatabasePath);
+  ~TSqliteSampleDescriptorPool();
+  TSqliteSampleDescriptorPool(const TSqliteSampleDescriptorPool&) = delete;
+  TSqliteSampleDescriptorPool& operator=(const TSqliteSampleDescriptorPool&) = delete;
+
+  // INSERT OR REPLACE of one analysed file in its own transaction, status "succeeded"
+  void InsertSample(const std::string& FileName, int ModificationTime, const TFileProperties& File,
+                    const TSampleDescriptors& Results, const TSampleDataInfo* pInfo = nullptr);
+  // the row of a file that could not be analysed: status "error: <Reason>", every descriptor NULL
+  void InsertFailedSample(const std::string& FileName, int ModificationTime, const std::string& Reason);
+
+private:
+  struct TImpl;
+  TImpl* mpImpl;
+};
+
+}  // namespace afec

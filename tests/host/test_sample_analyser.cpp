@@ -4,6 +4,7 @@
 //   host_test nodevice  error behaviour without a usable device (no GPU needed)
 //   host_test columns <out.bin>   column names + encodings of a synthetic TSampleDescriptors (no GPU); the Python
 //                                 side compares them with the reference's msgpack output and column list
+//   host_test sqlite <db>         writes a synthetic sample and a failed sample into a descriptor database (no GPU)
 //   host_test analyse   TSampleAnalyser::AnalyzeLowLevelDescriptors vs the oracle (GPU)
 #include <cmath>
 #include <cstdio>
@@ -13,6 +14,7 @@
 
 #include "../../afec_amd/host/DescriptorColumns.h"
 #include "../../afec_amd/host/SampleAnalyser.h"
+#include "../../afec_amd/host/SqlitePool.h"
 #include "../../oracle/afx_oracle.h"
 
 static int gFailures = 0;
@@ -40,6 +42,22 @@ static std::vector<double> ColumnValues(size_t n, size_t width, long long salt) 
   return v;
 }
 
+static afec::TSampleDescriptors SyntheticDescriptors() {
+  afec::TSampleDescriptors D;
+  const size_t Frames = 5;
+  D.mEffectiveLength48dB = 1.5; D.mEffectiveLength24dB = 1.25; D.mEffectiveLength12dB = 0.5;
+  D.mSpectralCentroid.mValues = ColumnValues(Frames, 0, 1);
+  D.mSpectralCentroid.mMedian = 2.5;
+  D.mSpectralCentroid.mDVariance = -0.125;
+  D.mF0.mValues = ColumnValues(Frames, 0, 2);
+  const auto c = ColumnValues(Frames, 14, 3);
+  D.mCepstrumBands.mValues.resize(Frames);
+  for (size_t fr = 0; fr < Frames; ++fr)
+    for (size_t b = 0; b < 14; ++b) D.mCepstrumBands.mValues[fr][b] = c[fr * 14 + b];
+  for (size_t b = 0; b < 14; ++b) D.mCepstrumBands.mMean[b] = (double)b / 4.0;
+  return D;
+}
+
 static void Put(FILE* f, const std::vector<uint8_t>& b) {
   const uint64_t n = b.size();
   std::fwrite(&n, 8, 1, f);
@@ -59,18 +77,7 @@ static int DumpColumns(const char* pPath) {
     const auto v = ColumnValues(s[0], s[1], (long long)(s[0] + s[1]));
     Put(f, afec::ToMsgpack(v.data(), s[0], s[1]));
   }
-  afec::TSampleDescriptors D;
-  const size_t Frames = 5;
-  D.mEffectiveLength48dB = 1.5; D.mEffectiveLength24dB = 1.25; D.mEffectiveLength12dB = 0.5;
-  D.mSpectralCentroid.mValues = ColumnValues(Frames, 0, 1);
-  D.mSpectralCentroid.mMedian = 2.5;
-  D.mSpectralCentroid.mDVariance = -0.125;
-  D.mF0.mValues = ColumnValues(Frames, 0, 2);
-  const auto c = ColumnValues(Frames, 14, 3);
-  D.mCepstrumBands.mValues.resize(Frames);
-  for (size_t fr = 0; fr < Frames; ++fr)
-    for (size_t b = 0; b < 14; ++b) D.mCepstrumBands.mValues[fr][b] = c[fr * 14 + b];
-  for (size_t b = 0; b < 14; ++b) D.mCepstrumBands.mMean[b] = (double)b / 4.0;
+  const afec::TSampleDescriptors D = SyntheticDescriptors();
   afec::TSampleDataInfo Info = {0.5f, 0.25f, -2205, 90000};
   const auto Columns = afec::LowLevelColumns(D, &Info);
   const uint64_t Count = Columns.size();
@@ -85,6 +92,19 @@ static int DumpColumns(const char* pPath) {
     else Put(f, Col.mBlob);
   }
   std::fclose(f);
+  return 0;
+}
+
+static int WriteDatabase(const char* pPath) {
+  afec::TSqliteSampleDescriptorPool Pool(pPath);
+  const afec::TSampleDescriptors D = SyntheticDescriptors();
+  const afec::TSampleDataInfo Info = {0.5f, 0.25f, -2205, 90000};
+  afec::TFileProperties File;
+  File.mFileType = "wav"; File.mFileSize = 176444; File.mFileLength = 2.0; File.mFileSampleRate = 44100;
+  File.mFileChannelCount = 1; File.mFileBitDepth = 16;
+  Pool.InsertSample("Kicks/one.wav", 1700000000, File, D, &Info);
+  Pool.InsertSample("Kicks/one.wav", 1700000001, File, D, &Info);      // INSERT OR REPLACE: still one row
+  Pool.InsertFailedSample("Kicks/broken.wav", 1700000002, "could not decode");
   return 0;
 }
 
@@ -202,6 +222,7 @@ int main(int argc, char** argv) {
   try {
     if (argc >= 2 && !std::strcmp(argv[1], "nodevice")) rc = TestNoDevice();
     else if (argc >= 3 && !std::strcmp(argv[1], "columns")) rc = DumpColumns(argv[2]);
+    else if (argc >= 3 && !std::strcmp(argv[1], "sqlite")) rc = WriteDatabase(argv[2]);
     else if (argc >= 2 && !std::strcmp(argv[1], "analyse")) rc = TestAnalyse();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());

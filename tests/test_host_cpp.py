@@ -122,6 +122,63 @@ def test_column_names_and_msgpack_blobs_match_the_reference(tmp_path):
     assert cols["amplitude_peak_VR"] == [] and cols["frequency_bands_VVR"] == []
 
 
+def full_schema():
+    """every column of the reference's low-level `assets` table with its declared type (README.md "Low-Level
+    Features"; SampleDescriptors.cpp:150-205; SqliteSampleDescriptorPool.cpp:1313-1358)"""
+    cols = [("filename", "TEXT"), ("modtime", "INTEGER"), ("status", "TEXT"), ("file_type_S", "TEXT"),
+            ("file_size_R", "INTEGER"), ("file_length_R", "REAL"), ("file_sample_rate_R", "INTEGER"),
+            ("file_channel_count_R", "INTEGER"), ("file_bit_depth_R", "INTEGER"), ("effectve_length_48dB_R", "REAL"),
+            ("effectve_length_24dB_R", "REAL"), ("effectve_length_12dB_R", "REAL"), ("analyzation_offset_R", "REAL")]
+
+    def framed_scalar(n):
+        return [(n + "_VR", "BLOB")] + [(f"{n}_{s}_R", "REAL") for s in STATS]
+
+    for n in SCALAR_SERIES:
+        cols += framed_scalar(n)
+    for kind in ("rhythm_complex", "rhythm_percussive"):
+        cols += framed_scalar(kind + "_onsets")
+        cols += [(kind + s + "_R", "REAL") for s in ("_onset_count", "_onset_contrast", "_onset_frequency_mean",
+                                                      "_onset_strength", "_tempo", "_tempo_confidence")]
+    cols += [("rhythm_final_tempo_R", "REAL"), ("rhythm_final_tempo_confidence_R", "REAL")]
+    for n in VECTOR_SERIES:
+        cols += [(n + "_VVR", "BLOB")] + [(f"{n}_{s}_VR", "BLOB") for s in STATS]
+    return cols
+
+
+def test_descriptor_database_is_the_references_schema(tmp_path):
+    """the sqlite file the host layer writes, read back with Python's sqlite3 + msgpack: user_version,
+    the `assets` columns (names, order, declared types), a succeeded row, a failed row"""
+    import sqlite3
+
+    import msgpack
+    from tests.golden.make_golden import column_values
+
+    build()
+    db = str(tmp_path / "afec-ll.db")
+    out = subprocess.run([BIN, "sqlite", db], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    con = sqlite3.connect(db)
+    assert con.execute("PRAGMA user_version").fetchone()[0] == 2
+    info = con.execute("PRAGMA table_info(assets)").fetchall()
+    assert [(r[1], r[2]) for r in info] == full_schema()
+    assert len(info) == 3 + 6 + 4 + 22 * 14 + 2 * (14 + 6) + 2 + 7 * 14          # 461 columns
+    assert [r[1] for r in info if r[5]] == ["filename"]                           # PRIMARY KEY
+    rows = con.execute("SELECT filename, modtime, status FROM assets ORDER BY filename").fetchall()
+    assert rows == [("Kicks/broken.wav", 1700000002, "error: could not decode"), ("Kicks/one.wav", 1700000001, "succeeded")]
+    con.row_factory = sqlite3.Row
+    ok = con.execute("SELECT * FROM assets WHERE filename = 'Kicks/one.wav'").fetchone()
+    assert (ok["file_type_S"], ok["file_size_R"], ok["file_length_R"], ok["file_sample_rate_R"],
+            ok["file_channel_count_R"], ok["file_bit_depth_R"]) == ("wav", 176444, 2.0, 44100, 1, 16)
+    assert ok["effectve_length_24dB_R"] == 1.25 and ok["spectral_centroid_median_R"] == 2.5
+    assert msgpack.unpackb(ok["spectral_centroid_VR"]) == column_values(5, 0, 1).tolist()
+    assert msgpack.unpackb(ok["cepstrum_bands_VVR"]) == column_values(5, 14, 3).tolist()
+    assert msgpack.unpackb(ok["cepstrum_bands_mean_VR"]) == [b / 4.0 for b in range(14)]
+    assert ok["rhythm_final_tempo_R"] is None and ok["rhythm_complex_onsets_VR"] is None     # not computed here
+    bad = con.execute("SELECT * FROM assets WHERE filename = 'Kicks/broken.wav'").fetchone()
+    assert all(bad[k] is None for k in bad.keys() if k not in ("filename", "modtime", "status"))
+    con.close()
+
+
 @pytest.mark.gpu
 def test_host_sample_analyser_matches_oracle():
     run("analyse")

@@ -270,3 +270,43 @@ def test_effective_length_golden_and_beyond_the_cap(oracle):
         np.testing.assert_array_equal(got, want)
         assert want[0, 0] > 20.5 and np.all(want[2] == 0.0)
     capped.close()
+
+
+def test_chunking_invariance_bitwise(plan):
+    """the same buffer alone (short chunks, one round) and inside a large batch (long chunks): carried state --
+    the whitening follower, the pitch kernel's first-half transform -- must not depend on where chunks start"""
+    rng = np.random.default_rng(41)
+    x = (0.4 * rng.standard_normal(2048 + 1024 * 2999)).astype(np.float32)
+    x[200000:260000] *= 0.001                       # a quiet stretch: the follower decays through it
+    alone = plan.extract([x], afx.D_NEIGHBOURS)
+    others = [rng.uniform(-1, 1, 2048 + 1024 * 1499).astype(np.float32) for _ in range(40)]
+    batch = plan.extract(others[:20] + [x] + others[20:], afx.D_NEIGHBOURS)
+    lo, hi = batch["frame_offset"][20], batch["frame_offset"][21]
+    assert hi - lo == 3000
+    for k in NEIGH_FIELDS:
+        np.testing.assert_array_equal(batch[k][lo:hi], alone[k], err_msg=k)
+
+
+def test_full_size_buffer_against_oracle_samples(plan, oracle):
+    """BASELINE configs[1] size (one 10 000-frame buffer): the head of the buffer against the oracle for every
+    neighbour, and frames deep inside it for the descriptors that only see their own frame"""
+    rng = np.random.default_rng(42)
+    n = 2048 + 1024 * 9999
+    t = np.arange(n) / 44100.0
+    x = (0.3 * np.sin(2 * np.pi * (180.0 + 40.0 * np.sin(2 * np.pi * 0.7 * t)) * t) + 0.05 * rng.standard_normal(n)).astype(np.float32)
+    res = plan.extract([x], afx.D_NEIGHBOURS)
+    assert res["frame_offset"][-1] == 10000
+    head = oracle.run_neighbours(x[:2048 + 1024 * 63].astype(np.float64))
+    for field, col in NEIGH_FIELDS.items():
+        if field == "auto_correlation":
+            continue        # `remaining` differs between the slice and the whole buffer only in the last frame; checked below
+        rtol, atol = _tol.NEIGH_TOL[field]
+        _tol.check(field, res[field][:64], head[:, col], rtol, atol, what="head ")
+    local = ["amplitude_silence", "amplitude_envelope", "f0", "f0_confidence", "auto_correlation"]
+    for f in rng.integers(100, 9990, 24):
+        seg = x[1024 * f: 1024 * f + 2048 + 64].astype(np.float64)
+        ref = oracle.run_neighbours(seg)[0]
+        for field in local:
+            rtol, atol = _tol.NEIGH_TOL[field]
+            _tol.check(field, res[field][f:f + 1], ref[NEIGH_FIELDS[field]:NEIGH_FIELDS[field] + 1], rtol, atol,
+                       what=f"frame {f} ")

@@ -133,10 +133,12 @@ __device__ __forceinline__ double nan_to_zero(double v) { return (v != v) ? 0.0 
 
 // sqrt for magnitudes: x >= 0 and far from overflow, so the range scaling of the generic
 // expansion is dropped: one v_rsq_f64 seed, one Goldschmidt step, one residual correction
-// (<= 1 ulp).  Inputs below 1e-290 (|X| < 1e-145) are flushed to 0, like the reference's FTZ/DAZ
-// FFT (AudioMath.cpp:27-36) would long before.
+// (<= 1 ulp).  Sums of squares below the smallest normal double are flushed to 0: the reference's
+// TAudioMath::Magnitude runs with the SSE DAZ + FZ bits set (AudioMath.cpp:25-35, 478-480), so its
+// bins below ~1.5e-154 are exactly 0 as well.
 __device__ __forceinline__ double mag_sqrt(double x) {
-  const double xs = x > 1e-290 ? x : 1e-290;
+  constexpr double kMinNormal = 2.2250738585072014e-308;
+  const double xs = x >= kMinNormal ? x : kMinNormal;
   const double r = __builtin_amdgcn_rsq(xs);
   double g = xs * r;
   double h = 0.5 * r;
@@ -145,7 +147,7 @@ __device__ __forceinline__ double mag_sqrt(double x) {
   h = fma(h, e, h);
   const double d = fma(-g, g, xs);
   g = fma(d, h, g);
-  return x > 1e-290 ? g : 0.0;
+  return x >= kMinNormal ? g : 0.0;
 }
 __device__ __forceinline__ float mag_sqrt(float x) { return sqrtf(x); }
 

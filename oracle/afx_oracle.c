@@ -9,6 +9,7 @@
  * Xt/ = R/3rdParty/LibXtract/Dist/.
  */
 #include "afx_oracle.h"
+#include <float.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -168,7 +169,15 @@ static void stft_frame(const afx_oracle* o, const double* x, double* re, double*
   int i;
   for (i = 0; i < n; ++i) { re[i] = x[i] * o->window[i]; im[i] = 0.0; }
   fft_forward(o, re, im);
-  for (i = 0; i < n / 2; ++i) mag[i] = sqrt(re[i] * re[i] + im[i] * im[i]);
+  /* TAudioMath::Magnitude runs with the SSE DAZ + FZ bits set (AudioMath.cpp:25-35, 478-480): a product that
+   * would be denormal is flushed to zero, so bins below ~1.5e-154 come out as exactly 0 */
+  for (i = 0; i < n / 2; ++i) {
+    double a = re[i] * re[i], b = im[i] * im[i], p;
+    if (a < DBL_MIN) a = 0.0;
+    if (b < DBL_MIN) b = 0.0;
+    p = a + b;
+    mag[i] = sqrt(p < DBL_MIN ? 0.0 : p);
+  }
   for (i = n / 2; i < n; ++i) mag[i] = 0.0;
 }
 

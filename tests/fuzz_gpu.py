@@ -1,0 +1,124 @@
+"""Randomised parity soak (not collected by pytest: run by hand on the GPU box):
+    python tests/fuzz_gpu.py [seconds] [seed]
+Random ragged batches of varied material and random descriptor masks through the C-ABI against the oracle,
+with the tolerances of tests/_tol.py; prints every mismatch and exits non-zero if there was one."""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import afec_amd as afx                                   # noqa: E402
+from tests import _tol                                   # noqa: E402
+from tests._oracle import FIELDS, NEIGH_FIELDS, Oracle  # noqa: E402
+
+
+def material(rng, n):
+    t = np.arange(n) / 44100.0
+    kind = rng.integers(0, 9)
+    if kind == 0:
+        x = rng.uniform(-1, 1, n)
+    elif kind == 1:
+        x = rng.uniform(0.05, 1.0) * np.sin(2 * np.pi * rng.uniform(30, 8000) * t + rng.uniform(0, 6.28))
+    elif kind == 2:
+        x = sum(rng.uniform(0.05, 0.4) * np.sin(2 * np.pi * rng.uniform(50, 5000) * t) for _ in range(rng.integers(2, 6)))
+    elif kind == 3:
+        x = rng.standard_normal(n) * np.maximum(np.exp(-t / rng.uniform(0.01, 0.5)), 1e-9)   # -180 dB floor
+    elif kind == 4:
+        x = np.zeros(n)
+        for _ in range(rng.integers(1, 6)):
+            a = int(rng.integers(0, n))
+            m = int(min(n - a, rng.integers(100, 20000)))
+            x[a:a + m] += rng.uniform(0.1, 0.8) * np.sin(2 * np.pi * rng.uniform(80, 2000) * np.arange(m) / 44100.0) * np.exp(-np.arange(m) / rng.uniform(500, 8000))
+    elif kind == 5:
+        x = np.clip(3.0 * np.sin(2 * np.pi * rng.uniform(60, 900) * t), -1, 1)      # clipped: plateaus in time
+    elif kind == 6:
+        x = 0.3 * rng.standard_normal(n) + rng.uniform(-0.5, 0.5)                   # DC offset
+    elif kind == 7:
+        x = 1e-4 * rng.standard_normal(n)                                            # near the silence threshold
+        x *= 10 ** rng.uniform(-1, 1.5)
+    else:
+        x = np.sign(np.sin(2 * np.pi * rng.uniform(40, 1500) * t)) * rng.uniform(0.1, 1.0)
+    if rng.random() < 0.3:
+        a = int(rng.integers(0, n))
+        x[a:a + int(rng.integers(0, 30000))] = 0.0                                  # a silent gap
+    return x
+
+
+def dump(round_index, bufs, mask):
+    """failing inputs go to gpurun_out/fuzz/ for analysis against the oracle and the reference driver"""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fuzz")
+    os.makedirs(d, exist_ok=True)
+    np.savez_compressed(os.path.join(d, f"round{round_index}.npz"), mask=np.array(mask),
+                        **{f"buf{i}": b for i, b in enumerate(bufs)})
+
+
+def main():
+    seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    plan, oracle = afx.Plan(max_analysis_ms=0), Oracle()
+    t0 = time.time()
+    rounds = frames = bad = skipped = 0
+    while time.time() - t0 < seconds:
+        bufs = []
+        for _ in range(int(rng.integers(1, 7))):
+            n = int(rng.choice([rng.integers(0, 3000), rng.integers(2048, 40000), rng.integers(2048, 200000)]))
+            x = material(rng, n) if n else np.zeros(0)
+            bufs.append(x.astype(np.float32 if rng.random() < 0.5 else np.float64))
+        dt = bufs[0].dtype
+        bufs = [b.astype(dt) for b in bufs]
+        mask = int(rng.integers(1, 1 << 22)) & afx.D_ALL_PER_FRAME
+        if mask == 0:
+            mask = afx.D_ALL_PER_FRAME
+        res = plan.extract(bufs, mask)
+        ref = np.concatenate([oracle.run(b.astype(np.float64)) for b in bufs]) if bufs else None
+        nref = np.concatenate([oracle.run_neighbours(b.astype(np.float64)) for b in bufs])
+        frames += ref.shape[0]
+        if ref.shape[0] == 0:
+            rounds += 1
+            continue
+        # Frames whose discrete outputs are decided by rounding noise in ANY implementation (the reference's own
+        # objects disagree with the oracle there): an exactly flat magnitude spectrum (an impulse at the frame
+        # start: "strict local maximum" is a coin toss per bin) and a flat difference function (a frame that is
+        # almost entirely digital silence: yinfast's confidence is ~1e-14 and its arg-min picks noise).
+        mags = ref[:, 1:752]
+        flat_spectrum = (mags.max(axis=1) - mags.min(axis=1)) <= 1e-9 * mags.max(axis=1)
+        zero_counts = []
+        for b in bufs:
+            nf = oracle.num_frames(b.size, False)
+            cz = np.concatenate([[0], np.cumsum(b == 0)])
+            zero_counts += [cz[1024 * f + 2048] - cz[1024 * f] for f in range(nf)]
+        flat_yin = np.array(zero_counts, dtype=np.int64) >= 1024      # at least half of the frame is digital silence
+        skipped += int(flat_spectrum.sum() + flat_yin.sum())
+        discrete_spectral = {"sub_complexity", "sub_flux", "spectral_flux", "spectral_complexity"}
+        pitch_fields = {"f0", "failsafe_f0"}
+        for field, (a, b) in FIELDS.items():
+            if field == "mag" or field not in res:
+                continue
+            keep = ~flat_spectrum if field in discrete_spectral else np.ones(ref.shape[0], bool)
+            try:
+                _tol.check(field, res[field].reshape(ref.shape[0], -1)[keep], ref[keep, a:b], *_tol.GPU_TOL[field])
+            except AssertionError as e:
+                bad += 1
+                dump(rounds, bufs, mask)
+                print(f"round {rounds} mask {mask:#x}: {e}")
+        for field, col in NEIGH_FIELDS.items():
+            if field not in res:
+                continue
+            keep = ~flat_spectrum if field in discrete_spectral else (~flat_yin if field in pitch_fields else np.ones(ref.shape[0], bool))
+            try:
+                _tol.check(field, res[field][keep], nref[keep, col], *_tol.NEIGH_TOL[field])
+            except AssertionError as e:
+                bad += 1
+                dump(rounds, bufs, mask)
+                print(f"round {rounds} mask {mask:#x}: {e}")
+        rounds += 1
+    print(f"{rounds} rounds, {frames} frames, {bad} mismatching (round, descriptor) pairs, "
+          f"{skipped} ill-conditioned frames left out of the discrete comparisons, seed {seed}")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

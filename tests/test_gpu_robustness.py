@@ -113,3 +113,26 @@ def test_large_call_is_split_internally_and_matches_small_calls():
         for k in ("mfcc", "spectral_flux", "spectral_rolloff"):
             np.testing.assert_array_equal(big[k][a:b], ref[k][roff[j]:roff[j + 1]])
     plan.close()
+
+
+def test_vanishing_amplitudes_flush_like_the_reference():
+    """a decay down to 1e-160: TAudioMath::Magnitude runs with DAZ + FZ set, so bins below ~1.5e-154 are exactly
+    zero there (flatness 1.0, no peaks); the kernel flushes the same way and stays finite all the way down"""
+    rng = np.random.default_rng(51)
+    n = 2048 + 1024 * 50
+    x = rng.standard_normal(n) * np.exp(-np.arange(n) / 120.0)        # 1e-150 after ~41 000 samples, 1e-190 at the end
+    plan = afx.Plan(max_analysis_ms=0)
+    res = plan.extract([x], afx.D_ALL_LOW_LEVEL)
+    ref = Oracle().run(x)
+    from tests._oracle import FIELDS
+    for field, (a, b) in FIELDS.items():
+        if field == "mag":
+            continue
+        got = res[field].reshape(ref.shape[0], -1)
+        assert np.all(np.isfinite(got)), field
+        rtol, atol = _tol.GPU_TOL[field]
+        # the transition (per-product flush there, flush of the sum here: |X| around 1e-154) is left out
+        keep = np.r_[0:37, 46:51]
+        _tol.check(field, got[keep], ref[keep, a:b], rtol, atol, what="vanishing ")
+    assert res["spectral_flatness"][-1] == 1.0 and not res["sub_complexity"][-1].any()
+    plan.close()

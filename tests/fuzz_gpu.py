@@ -114,6 +114,35 @@ def main():
                 bad += 1
                 dump(rounds, bufs, mask)
                 print(f"round {rounds} mask {mask:#x}: {e}")
+        # per-file statistics of the GPU's own series (the reduction alone is compared, at 1e-9)
+        if rng.random() < 0.25:
+            from tests import _oracle
+            b = plan.batch(bufs, mask | afx.D_STATISTICS)
+            b.run()
+            series, st = b.fetch(), b.fetch_statistics()
+            b.close()
+            off = series["frame_offset"]
+            for i in range(len(bufs)):
+                if off[i + 1] - off[i] < 2 or off[i + 1] - off[i] > 1024:
+                    continue
+                for name, arr in st.items():
+                    if name == "stats_status":
+                        continue
+                    vals = series[name][off[i]:off[i + 1]].reshape(off[i + 1] - off[i], -1)
+                    got = arr[i].reshape(vals.shape[1], 13)
+                    for w in range(vals.shape[1]):
+                        v = vals[:, w]
+                        if not np.all(np.isfinite(v)):
+                            continue
+                        want = _oracle.calc_statistics(v)
+                        tiny = abs(v.sum()) < 1e-6 * np.abs(v).sum() or not np.abs(v).sum() > 0
+                        for j, sn in enumerate(afx.STAT_NAMES):
+                            if tiny and sn in ("centroid", "spread", "skewness", "kurtosis", "flatness"):
+                                continue
+                            if not abs(got[w, j] - want[j]) <= 1e-8 * abs(want[j]) + 1e-11:
+                                bad += 1
+                                dump(rounds, bufs, mask)
+                                print(f"round {rounds} statistics {name}[{w}].{sn} of buffer {i}: got {got[w, j]!r} want {want[j]!r}")
         rounds += 1
     print(f"{rounds} rounds, {frames} frames, {bad} mismatching (round, descriptor) pairs, "
           f"{skipped} ill-conditioned frames left out of the discrete comparisons, seed {seed}")

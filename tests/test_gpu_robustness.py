@@ -32,8 +32,9 @@ def test_concurrent_calls_on_one_plan_match_serial():
     inputs = [[rng.uniform(-1, 1, 2048 + 1024 * int(rng.integers(1, 60))).astype(np.float32) for _ in range(5)]
               for _ in range(8)]
     plan = afx.Plan()
-    mask = afx.D_ALL_LOW_LEVEL
+    mask = afx.D_ALL_PER_FRAME | afx.D_EFFECTIVE_LENGTH       # every kernel of the library
     serial = [plan.extract(bufs, mask) for bufs in inputs]
+    raws = [[(np.round(b * 20000).astype(np.int16), 1) for b in bufs] for bufs in inputs]
     out = [None] * len(inputs)
     errs = []
 
@@ -41,6 +42,11 @@ def test_concurrent_calls_on_one_plan_match_serial():
         try:
             for _ in range(3):
                 out[i] = plan.extract(inputs[i], mask)
+                # and the LoadSample front end with its per-call staging, from the same threads
+                b, _ = plan.batch_from_raw(raws[i], afx.D_MFCC | afx.D_STATISTICS)
+                b.run()
+                b.fetch_statistics()
+                b.close()
         except Exception as e:  # noqa: BLE001
             errs.append(e)
 

@@ -151,11 +151,15 @@ __device__ __forceinline__ double mag_sqrt(double x) {
 }
 __device__ __forceinline__ float mag_sqrt(float x) { return sqrtf(x); }
 
-// TAudioMath::LinToDb(double), AudioMath.inl:55-70 (MEpsilon is the float literal 1e-12f)
-__device__ __forceinline__ double lin_to_db(double v) {
-  if (v == 1.0) return 0.0;
-  if (v > (double)1e-12f) return log(v) * 8.685889638065035;  // 20 / ln 10
-  return -200.0;
+// n / d for normal d of either sign and moderate n: v_rcp_f64 seed, two Newton steps, then one residual
+// correction of the quotient (exact whenever n / d is representable, <= 1 ulp otherwise).  The generic division
+// with its range scaling is ~25 instructions.
+__device__ __forceinline__ double fast_div(double n, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(r, fma(-d, r, 1.0), r);
+  r = fma(r, fma(-d, r, 1.0), r);
+  const double q = n * r;
+  return fma(fma(-d, q, n), r, q);
 }
 
 
@@ -209,6 +213,13 @@ __device__ __forceinline__ double fast_log(double x) {
   p = fma(p, z, 1.0 / 3.0);
   p = fma(p, z, 1.0);
   return fma((double)e, 0.693147180559945309417, 2.0 * s * p);
+}
+
+// TAudioMath::LinToDb(double), AudioMath.inl:55-70 (MEpsilon is the float literal 1e-12f)
+__device__ __forceinline__ double lin_to_db(double v) {
+  if (v == 1.0) return 0.0;
+  if (v > (double)1e-12f) return fast_log(v) * 8.685889638065035;  // 20 / ln 10
+  return -200.0;
 }
 
 // e^x for |x| < 700: x = k ln2 + r, |r| <= ln2/2, degree-13 Taylor on r (|error| < 2e-16 relative), ldexp

@@ -71,18 +71,6 @@ __device__ __forceinline__ bool au_silent(double sum_sq, int n) {
   return sum_sq / (double)n < 1.5848931924611134e-05;
 }
 
-// n / d for positive normal d and moderate n: v_rcp_f64 seed, two Newton steps, then one residual correction
-// of the quotient (exact whenever n / d is representable, e.g. the all-equal difference function of a constant
-// signal, where the reference's argmin rule depends on exact ties).  The generic division with its range
-// scaling is ~25 instructions and the normalisation below needs one per lag.
-__device__ __forceinline__ double fast_div(double n, double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = fma(r, fma(-d, r, 1.0), r);
-  r = fma(r, fma(-d, r, 1.0), r);
-  const double q = n * r;
-  return fma(fma(-d, q, n), r, q);
-}
-
 // ---------------------------------------------------------------------------------------------
 // hop kernel: silence flag + envelope maximum of the hop (first 1024 samples of the frame)
 // ---------------------------------------------------------------------------------------------

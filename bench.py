@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--buffers", type=int, default=64, help="10k-frame buffers per GPU per step")
     ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
-    ap.add_argument("--mask", default="c2", choices=["c2", "stats", "all", "frame", "neighbours"])
+    ap.add_argument("--mask", default="c2", choices=["c2", "star", "stats", "all", "frame", "neighbours"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2: --buffers x 10k-frame buffers (headline); c3: 1000 synthetic 2.0 s files, full "
                          "low-level set + per-file statistics (BASELINE.json configs[2]); c4: this rank's share "
@@ -171,7 +171,11 @@ def main():
     if world != max(1, args.gpus) and rank == 0:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
 
-    mask = {"c2": afx.D_C2, "stats": afx.D_MFCC | afx.D_SPECTRAL_STATS,
+    # "star": the descriptors BASELINE.json's north_star names -- MFCC + spectral rms / centroid (+ spread, same
+    # function) / rolloff / flatness
+    star = (afx.D_MFCC | afx.D_SPECTRAL_RMS | afx.D_SPECTRAL_CENTROID | afx.D_SPECTRAL_SPREAD | afx.D_SPECTRAL_ROLLOFF |
+            afx.D_SPECTRAL_FLATNESS)
+    mask = {"c2": afx.D_C2, "star": star, "stats": afx.D_MFCC | afx.D_SPECTRAL_STATS,
             "all": afx.D_ALL_LOW_LEVEL, "frame": afx.D_ALL_PER_FRAME, "neighbours": afx.D_NEIGHBOURS}[args.mask]
     precision = afx.PRECISION_F64 if args.precision == "f64" else afx.PRECISION_F32
     # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)

@@ -16,7 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=2)
     ap.add_argument("--precision", default="f64")
-    ap.add_argument("--mask", default="c2", choices=["c2", "stats", "all", "frame", "neighbours"])
+    ap.add_argument("--mask", default="c2", choices=["c2", "star", "stats", "all", "frame", "neighbours"])
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("libs", nargs="+")
     args = ap.parse_args()

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -26,6 +27,9 @@
 namespace {
 
 thread_local std::string g_last_error;
+#if defined(AFX_STAMPS) && AFX_STAMPS
+unsigned long long* g_stamp_buf = nullptr;
+#endif
 
 int fail(int status, const std::string& msg) {
   g_last_error = msg;
@@ -124,6 +128,11 @@ struct DeviceTables {
   void* t1_f64 = nullptr;
   void* t2_f64 = nullptr;
   void* post_f64 = nullptr;
+  // half-wave kernels (afx_frames32.hip), always double
+  void* win32 = nullptr;
+  void* tw32 = nullptr;
+  void* post32 = nullptr;
+  void* melw32 = nullptr;
 };
 
 }  // namespace
@@ -138,10 +147,11 @@ struct Workspace {
   };
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place;
+  unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
+  Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   size_t bytes() const {
     return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
-           efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap;
+           efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap + queue.cap;
   }
 };
 
@@ -154,6 +164,7 @@ struct afx_plan {
   std::vector<double> mel;     // [14][fft/2]
   DeviceTables dev;
   int cu_count = 256;
+  bool halfwave = true;   // AFX_HALFWAVE=0 in the environment keeps the 64-lane frame kernels (A/B timing)
 };
 
 struct afx_batch {
@@ -182,8 +193,10 @@ struct afx_batch {
   double* d_mag = nullptr;
   int64_t* d_frame_offset = nullptr;
   double* d_stats = nullptr;
+  unsigned* d_queue = nullptr;   // work-queue counter of the half-wave frame kernel (lives in the workspace)
   std::vector<int64_t> arena_off, used;  // per buffer: start and length (samples) of its analysed prefix in d_pcm
   bool mag_wanted = false;
+  bool halfwave = false;   // frames by the half-wave kernel: a wave walks two chunks at a time
 };
 
 namespace {
@@ -250,11 +263,45 @@ int upload_double_twiddles(afx_plan* p) {
   return AFX_OK;
 }
 
+// tables of the half-wave kernels (afx_frames32.hip): bin / sample index = q + 32 row, always double
+int upload_halfwave_tables(afx_plan* p) {
+  using C = cpx<double>;
+  const int fft = p->desc.fft_size;
+  std::vector<C> win(1024), tw(1024), post(1024);
+  for (int r = 0; r < 32; ++r)
+    for (int q = 0; q < 32; ++q) {
+      const int n = q + 32 * r;
+      // 1/fft: kDivFwdByN (Fourier.cpp:265-270); 1/2: even/odd untangle of the half-size FFT
+      win[32 * r + q] = {p->window[2 * n] / (2.0 * fft), p->window[2 * n + 1] / (2.0 * fft)};
+      tw[32 * r + q] = twiddle<double>((long long)r * q, 1024);   // [n2 = r][k1 = q]
+      post[32 * r + q] = twiddle<double>(n, 2048);
+    }
+  std::vector<double> melw((size_t)afx::kMel32Pairs * 32, 0.0);
+  int idx = 0;
+  for (int r = 0; r < afx::kMel32Rows; ++r)
+    for (int f = 0; f < afx::kNumCep; ++f)
+      if (afx::mel32_touches(f, r)) {
+        for (int q = 0; q < 32; ++q) melw[(size_t)idx * 32 + q] = p->mel[(size_t)f * afx::kHalf + 32 * r + q];
+        ++idx;
+      }
+  auto up = [](void** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc(dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  HIP_TRY(up(&p->dev.win32, win.data(), win.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.tw32, tw.data(), tw.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.post32, post.data(), post.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.melw32, melw.data(), melw.size() * sizeof(double)));
+  return AFX_OK;
+}
+
 int upload_tables(afx_plan* p) {
   int st = (p->desc.precision == AFX_PRECISION_F64) ? upload_tables_typed<double>(p)
                                                     : upload_tables_typed<float>(p);
   if (st != AFX_OK) return st;
   if (p->desc.precision != AFX_PRECISION_F64 && (st = upload_double_twiddles(p)) != AFX_OK) return st;
+  if ((st = upload_halfwave_tables(p)) != AFX_OK) return st;
   // packed mel rows: one 64-lane row per (r, f) pair the static cover lists, in the kernel's precision
   std::vector<double> melw((size_t)afx::kMelPairs * 64, 0.0);
   int idx = 0;
@@ -286,13 +333,14 @@ void free_tables(afx_plan* p) {
   if (p->dev.t1_f64 != p->dev.t1) { hipFree(p->dev.t1_f64); hipFree(p->dev.t2_f64); hipFree(p->dev.post_f64); }
   hipFree(p->dev.win); hipFree(p->dev.t1); hipFree(p->dev.t2); hipFree(p->dev.post);
   hipFree(p->dev.melw); hipFree(p->dev.dct);
+  hipFree(p->dev.win32); hipFree(p->dev.tw32); hipFree(p->dev.post32); hipFree(p->dev.melw32);
   p->dev = DeviceTables{};
 }
 
 void ws_free(Workspace* w) {
   if (!w) return;
   for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
-                            &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place}) hipFree(b->p);
+                            &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place, &w->queue}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->stream) hipStreamDestroy(w->stream);
@@ -492,6 +540,7 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   if (e != hipSuccess) { delete p; return hip_fail(e, "hipSetDevice"); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess) p->cu_count = prop.multiProcessorCount;
+  if (const char* hw = std::getenv("AFX_HALFWAVE")) p->halfwave = (hw[0] != '0');
   const int st = upload_tables(p);
   if (st != AFX_OK) { free_tables(p); delete p; return st; }
   *out_plan = p;
@@ -606,7 +655,9 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   // amortise the 2048-sample lead-in of each chunk
   // K is picked to minimise (rounds of the wave slots) x (frames per chunk + lead-in): long chunks for
   // big batches, one round of short chunks when the batch barely fills the chip
-  const int64_t slots = (int64_t)plan->cu_count * afx::frames_waves_per_block(fmask);
+  b->halfwave = plan->halfwave && afx::frames_use_halfwave(fmask, plan->desc.precision, dtype);
+  const int waves_per_block = b->halfwave ? afx::frames32_waves_per_block() : afx::frames_waves_per_block(fmask);
+  const int64_t slots = (int64_t)plan->cu_count * waves_per_block * (b->halfwave ? 2 : 1);
   int K = 32;
   {
     double best = 1e300;
@@ -621,25 +672,35 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   std::vector<afx::ChunkRemaining> remaining;
   std::vector<int32_t> chunk_first((size_t)n_bufs, 0);
   b->chunk_frames = K;
+  // When the half-wave frame kernel is the only consumer of the chunk table (it draws chunks from a work queue),
+  // the last part of every buffer is cut into short chunks and the table is ordered long chunks first: the waves
+  // run dry within a quarter of a long chunk's time of each other instead of a whole one.
+  const bool guided = b->halfwave && K >= 8 && !(mask & (kTimeBits | kWhitenBits | AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX));
+  const int Ks = guided ? K / 4 : K;
   for (int i = 0; i < n_bufs; ++i) {
     const int64_t f = b->frame_offset[i + 1] - b->frame_offset[i];
     chunk_first[(size_t)i] = (int32_t)chunks.size();
-    for (int64_t f0 = 0; f0 < f; f0 += K) {
+    const int64_t f_long = guided ? (f * 7 / 8) / K * K : f;   // frames covered by chunks of K
+    for (int64_t f0 = 0; f0 < f;) {
+      const int k = (f0 < f_long) ? K : Ks;
       remaining.push_back((afx::ChunkRemaining)std::min<int64_t>(lengths[i] - f0 * plan->desc.hop_size, 1 << 30));
       afx::Chunk c;
       const bool first = (f0 == 0);
       c.sample_off = b->arena_off[i] + f0 * plan->desc.hop_size;
       c.frame0 = (int32_t)(b->frame_offset[i] + f0);
-      c.nframes = (int16_t)std::min<int64_t>(K, f - f0);
+      c.nframes = (int16_t)std::min<int64_t>(k, f - f0);
       c.flags = (int16_t)(first ? afx::kChunkFirstOfBuffer : 0);
       chunks.push_back(c);
+      f0 += k;
     }
   }
+  if (guided)
+    std::stable_sort(chunks.begin(), chunks.end(), [](const afx::Chunk& x, const afx::Chunk& y) { return x.nframes > y.nframes; });
   b->n_chunks = (int)chunks.size();
   // one workgroup per CU (its LDS holds the shared tables plus one exchange plane per wave);
   // waves walk the chunk list with a grid stride
-  const int waves_per_block = afx::frames_waves_per_block(fmask);
-  b->grid_blocks = (int)std::min<int64_t>((b->n_chunks + waves_per_block - 1) / waves_per_block,
+  const int64_t wave_items = b->halfwave ? (b->n_chunks + 1) / 2 : b->n_chunks;
+  b->grid_blocks = (int)std::min<int64_t>((wave_items + waves_per_block - 1) / waves_per_block,
                                           (int64_t)plan->cu_count);
   if (b->grid_blocks < 1) b->grid_blocks = 1;
 
@@ -660,6 +721,15 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     if ((e = ws_reserve(w.chunks, chunks.size() * sizeof(afx::Chunk))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(chunks)"));
     b->d_chunks = (afx::Chunk*)w.chunks.p;
     if ((e = hipMemcpyAsync(b->d_chunks, chunks.data(), chunks.size() * sizeof(afx::Chunk), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(chunks)"));
+  }
+  if (b->n_chunks > 0 && b->halfwave) {
+    if (!w.queue.p) {
+      // zeroed once: every launch advances the counter by its number of chunk pairs (afx_frames32.hip)
+      if ((e = ws_reserve(w.queue, 64)) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(queue)"));
+      if ((e = hipMemsetAsync(w.queue.p, 0, 64, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemset(queue)"));
+      w.queue_count = 0;
+    }
+    b->d_queue = (unsigned*)w.queue.p;
   }
   if (b->n_chunks > 0 && (mask & kTimeBits)) {
     if ((e = ws_reserve(w.rem, remaining.size() * sizeof(afx::ChunkRemaining))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(remaining)"));
@@ -897,7 +967,20 @@ int afx_batch_run(afx_batch* b) {
     a.lay = b->lay;
     a.mag_out = b->d_mag;
     a.win = t.win; a.t1 = t.t1; a.t2 = t.t2; a.post = t.post; a.melw = t.melw; a.dct = t.dct;
-    HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
+    a.win32 = t.win32; a.tw32 = t.tw32; a.post32 = t.post32; a.melw32 = t.melw32;
+#if defined(AFX_STAMPS) && AFX_STAMPS
+    // diagnostic build: per-stage cycle counters of the half-wave kernel, printed when the batch is destroyed
+    static unsigned long long* stamp_buf = nullptr;
+    if (!stamp_buf) { HIP_TRY(hipMalloc((void**)&stamp_buf, (16 + 8192) * 8)); HIP_TRY(hipMemset(stamp_buf, 0, (16 + 8192) * 8)); }
+    a.stamps = stamp_buf;
+    g_stamp_buf = stamp_buf;
+#endif
+    if (b->halfwave) {
+      a.queue = b->d_queue;
+      a.queue_base = b->ws->queue_count;
+      b->ws->queue_count += (unsigned)((b->n_chunks + 1) / 2);
+      HIP_TRY(afx::launch_frames32(a, b->grid_blocks, b->stream));
+    } else HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
   }
   if (b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) {
     afx::BandArgs ba{};
@@ -1032,6 +1115,44 @@ void afx_batch_destroy(afx_batch* b) {
   if (!b) return;
   hipSetDevice(b->plan->desc.device);
   if (b->stream) hipStreamSynchronize(b->stream);
+#if defined(AFX_STAMPS) && AFX_STAMPS
+  if (g_stamp_buf) {
+    unsigned long long h[16];
+    if (hipMemcpy(h, g_stamp_buf, sizeof h, hipMemcpyDeviceToHost) == hipSuccess && h[15]) {
+      static const char* names[10] = {"wait DMA+window", "hop+convert", "P1", "exchange", "DMA issue+twiddle", "P2",
+                                      "untangle", "mel rows", "win issue+reduce", "log+DCT"};
+      unsigned long long tot = 0;
+      for (int i = 0; i < 10; ++i) tot += h[i];
+      std::fprintf(stderr, "[afx stamps] %llu stamped iterations (2 frames each), %.0f cycles per iteration\n", h[15], (double)tot / h[15]);
+      for (int i = 0; i < 10; ++i) std::fprintf(stderr, "[afx stamps] %-18s %8.0f cycles  %5.1f %%\n", names[i], (double)h[i] / h[15], 100.0 * h[i] / tot);
+      // lifetimes of every wave of the LAST launch, by wave index inside the workgroup
+      static unsigned long long life[8192];
+      if (hipMemcpy(life, g_stamp_buf + 16, sizeof life, hipMemcpyDeviceToHost) == hipSuccess) {
+        unsigned long long r0 = ~0ull, r1 = 0;
+        double sum_core = 0, sum_real = 0;
+        double wsum[8] = {}, wmin[8], wmax[8] = {}, wend[8] = {};
+        int wn[8] = {};
+        for (int w = 0; w < 8; ++w) wmin[w] = 1e30;
+        for (int i = 0; i < 2048; ++i) {
+          if (!life[4 * i + 1]) continue;
+          r0 = std::min(r0, life[4 * i + 2]); r1 = std::max(r1, life[4 * i + 3]);
+        }
+        for (int i = 0; i < 2048; ++i) {
+          if (!life[4 * i + 1]) continue;
+          const int w = i & 7;
+          const double dr = (double)(life[4 * i + 3] - life[4 * i + 2]) / 100.0;
+          sum_core += (double)(life[4 * i + 1] - life[4 * i]); sum_real += dr * 100.0;
+          wsum[w] += dr; wmin[w] = std::min(wmin[w], dr); wmax[w] = std::max(wmax[w], dr); ++wn[w];
+          wend[w] += (double)(life[4 * i + 3] - r0) / 100.0;
+        }
+        std::fprintf(stderr, "[afx stamps] last launch: span first-entry..last-exit %.1f us, core clock %.3f GHz\n", (double)(r1 - r0) / 100.0, sum_core / sum_real * 0.1);
+        for (int w = 0; w < 8; ++w)
+          if (wn[w]) std::fprintf(stderr, "[afx stamps]   wave %d: life mean %.1f us (min %.1f, max %.1f), mean exit at %.1f us\n", w, wsum[w] / wn[w], wmin[w], wmax[w], wend[w] / wn[w]);
+      }
+      hipMemset(g_stamp_buf, 0, (16 + 8192) * 8);
+    }
+  }
+#endif
   ws_release(b->plan, b->ws);
   delete b;
 }

@@ -1,0 +1,448 @@
+// afec_amd/csrc/afx_frames32.hip -- gfx950 STFT + MFCC kernel, one frame per HALF-wave.
+//
+// A wavefront is two independent 32-lane halves; each half owns a run of consecutive frames of one buffer
+// ("chunk") and computes the 2048-point FFT of the windowed real frame as a 1024-point complex FFT of
+// z[n] = x[2n] + i x[2n+1] held as 32 complex doubles per lane (lane = 32 h + q):
+//
+//   load   v[n1] = z[q + 32 n1]                      (hop reuse: rows 0..15 are last frame's 16..31, kept in
+//          registers; the new hop arrives by LDS-DMA in the wave's exchange plane, issued one frame ahead)
+//   P1     32-point DFT over n1, in registers        -> register k1
+//   E      exchange through the wave's LDS plane, slot = 1056 h + 33 k1 + n2 (conflict-free for
+//          ds_write_b64 and ds_read_b64)             -> lane q = k1, register n2
+//   T      * w1024^(n2 k1)                           (LDS table [n2][k1])
+//   P2     32-point DFT over n2, in registers        -> v[k2] = Z[q + 32 k2]
+//   U      partner Z[1024-k] by a cross-lane read inside the half, even/odd untangle, |X[k]|, k = q + 32 r
+//
+// then the descriptors straight from the magnitudes in registers; sums over a frame's bins are reductions over
+// the 32 lanes of a half (v_permlane16_swap + DPP), so one instruction stream serves two frames.  Compared with
+// the 64-lane layout of afx_kernels.hip (16 x 4 x 16, two exchanges) this drops the register-transpose exchange
+// (64 v_permlane*_swap per frame), one of the two twiddle stages and half of the reduction work.  Index algebra,
+// LDS bank rules and the reduction's lane map are modelled in tools/fft32_dataflow_model.py.
+//
+// What each stage replaces in the reference (SampleAnalyser.cpp = SA):
+//   window+FFT+magnitude  SA:826-845 (xtract_windowed, TFftTransformComplex, TAudioMath::Magnitude)
+//   mel+log+DCT           SA:2052-2063 -> LibXtract vector.c:350-391
+
+#include <hip/hip_runtime.h>
+
+#include "afx_internal.h"
+#include "afx_device.h"
+#include "afx_fft32.h"
+
+namespace afx {
+namespace {
+
+using f32x32::cx;
+
+constexpr int kHalfSlots = 1056;                      // 8-byte slots per half: 33 * 31 + 31 + 1, rounded to 32
+constexpr int kPlane32Bytes = 2 * kHalfSlots * 8;     // 16 896 per wave
+constexpr int kWaves32 = 8;
+
+template <int POST_ROWS>
+struct Lds32 {
+  static constexpr int tw = 0;                              // [32][32] cx<double>: w1024^(n2 k1)
+  static constexpr int post = tw + 32 * 32 * 16;            // [POST_ROWS][32] cx<double>: w2048^(q + 32 r)
+  static constexpr int dct = post + POST_ROWS * 32 * 16;    // [14][16] double
+  static constexpr int logc = dct + 14 * 16 * 8;            // 16 doubles: constants of the logarithm (kLogConst)
+  static constexpr int xchg = logc + 16 * 8;                // kWaves32 planes
+  static constexpr int total = xchg + kWaves32 * kPlane32Bytes;
+};
+
+// ---- constant tables in global memory through buffer descriptors ----
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t table_rsrc(const void* p, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double2 table_load2(__amdgpu_buffer_rsrc_t rs, int lane_off, int row_off) {
+  return __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off, row_off, 0));
+}
+// row offset as the scalar offset: for a lane offset the compiler cannot see through
+__device__ __forceinline__ double table_load1(__amdgpu_buffer_rsrc_t rs, int lane_off, int row_off) {
+  return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, row_off, 0));
+}
+
+// ---- reductions over the 32 lanes of each half ----
+// 16 per-lane values summed over the half at once: lane L ends with the total of a[(L & 31) >> 1]
+__device__ __forceinline__ double half_sum16(double (&a)[16], int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    swap16(a[i], a[i + 8]);
+    a[i] += a[i + 8];
+  }
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0, b1 = (lane & 2) != 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const double keep = b3 ? a[i + 4] : a[i];
+    const double send = b3 ? a[i] : a[i + 4];
+    a[i] = keep + dpp_mov<kDppRor8>(send);
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double keep = b2 ? a[i + 2] : a[i];
+    const double send = b2 ? a[i] : a[i + 2];
+    a[i] = keep + dpp_mov<kDppHalfMirror>(send);
+  }
+  const double keep = b1 ? a[1] : a[0];
+  const double send = b1 ? a[0] : a[1];
+  double z = keep + dpp_mov<kDppXor2>(send);
+  z += dpp_mov<kDppXor1>(z);
+  return z;
+}
+
+// Constants of finish_mfcc32's logarithm.  They live in LDS and are read where they are used: as literals the
+// compiler keeps every one of them in a vector register pair for the whole kernel (no 64-bit literals on
+// gfx950's VOP3), which this kernel cannot afford.
+__device__ const double kLogConst[16] = {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0,
+                                         1.0 / 11.0, 1.0 / 9.0,  1.0 / 7.0,  1.0 / 5.0,  1.0 / 3.0,  0.693147180559945309417,
+                                         0.70710678118654752440, 2e-42, 0.0, 0.0};
+
+// natural log of a positive normal double: frexp + atanh series (|s| <= 0.1716), ~1e-16 absolute on log(m)
+__device__ __forceinline__ double log_lds(double x, const double* c) {
+  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lowhalf = m < c[12];
+  m = lowhalf ? m + m : m;
+  e = lowhalf ? e - 1 : e;
+  const double s = fast_div(m - 1.0, m + 1.0);
+  const double z = s * s;
+  double p = c[0];
+#pragma unroll
+  for (int i = 1; i < 11; ++i) p = fma(p, z, c[i]);
+  p = fma(p, z, 1.0);
+  return fma((double)e, c[11], 2.0 * s * p);
+}
+
+// log + 14-point DCT-II + store (vector.c:364-391) for the frames whose mel sums sit in lanes 2 f + slot of each
+// half.  recp: this lane's output element of slot s = lane & 1 (coefficient n = (lane >> 1) & 15); left: frames
+// of this half still to be stored, counted from slot s.
+__device__ __forceinline__ void finish_mfcc32(double acc, double*& recp, int& left, int stride2, const double* dct,
+                                              const double* logc, int lane) {
+  const double lg = log_lds(fmax(acc, logc[13]), logc);  // XTRACT_LOG_LIMIT 2e-42, vector.c:364
+  // lane-derived addresses are recomputed here (laundered lane id): hoisted out of the frame loop they would each
+  // hold a register for the whole kernel
+  int ln = lane;
+  asm volatile("" : "+v"(ln));
+  const int n = (ln >> 1) & 15;
+  const double2* drow = reinterpret_cast<const double2*>(dct + 16 * (n < kNumCep ? n : 0));
+  const int idx = ((ln & 32) + (ln & 1)) << 2;   // byte index of lane 32 h + s for ds_bpermute
+  const int lo32 = __double2loint(lg), hi32 = __double2hiint(lg);
+  double c = 0.0;
+#pragma unroll
+  for (int m = 0; m < kNumCep; m += 2) {
+    const double2 d = drow[m >> 1];
+    const double l0 = __hiloint2double(__builtin_amdgcn_ds_bpermute(idx + 8 * m, hi32), __builtin_amdgcn_ds_bpermute(idx + 8 * m, lo32));
+    const double l1 = __hiloint2double(__builtin_amdgcn_ds_bpermute(idx + 8 * m + 8, hi32), __builtin_amdgcn_ds_bpermute(idx + 8 * m + 8, lo32));
+    c = fma(l0, d.x, c);
+    c = fma(l1, d.y, c);
+  }
+  if (n < kNumCep && left > 0) *recp = c;
+  recp += stride2;
+  left -= 2;
+}
+
+// Diagnostic build only (make stamps -> libafx_hip_stamps.so, never the shipped library): wave 0 of every
+// workgroup stamps s_memtime at the stage boundaries and adds the differences to per-stage counters.
+#ifndef AFX_STAMPS
+#define AFX_STAMPS 0
+#endif
+#if AFX_STAMPS
+// scalar-only: s_memtime into an SGPR pair, the per-stage sums stay in SGPRs (no vector registers, no memory traffic)
+#define AFX_STAMP(i)                                                                           \
+  do {                                                                                         \
+    unsigned long long t_;                                                                     \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_));                           \
+    stamp_acc[i] += (unsigned)(t_ - stamp_prev);                                               \
+    stamp_prev = t_;                                                                           \
+  } while (0)
+#else
+#define AFX_STAMP(i)
+#endif
+
+template <int FEAT>
+__global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs a) {
+  constexpr int MR = kMel32Rows;   // rows of 32 bins whose magnitudes are needed: bins 0..383
+  using Map = Lds32<MR>;
+  extern __shared__ __align__(16) unsigned char lds_raw[];
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: SGPR arithmetic
+  const int h = lane >> 5, q = lane & 31;
+
+  // ---- shared tables ----
+  copy_lds_table(lds_raw + Map::tw, a.tw32, 32 * 32 * 16, threadIdx.x, kWaves32 * 64);
+  copy_lds_table(lds_raw + Map::post, a.post32, MR * 32 * 16, threadIdx.x, kWaves32 * 64);
+  copy_lds_table(lds_raw + Map::dct, a.dct, 14 * 16 * 8, threadIdx.x, kWaves32 * 64);
+  copy_lds_table(lds_raw + Map::logc, kLogConst, 16 * 8, threadIdx.x, kWaves32 * 64);
+#if AFX_STAMPS
+  unsigned stamp_acc[16] = {};
+  unsigned long long life_core0, life_real0;
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(life_core0), "=s"(life_real0));
+  const bool stamping = (wave == 0) && a.stamps != nullptr;
+  unsigned long long stamp_prev = 0;
+#endif
+  __syncthreads();
+
+  // window and mel tables: buffer loads (one descriptor in SGPRs, lane offset in one VGPR, the row as an
+  // immediate / scalar offset) instead of one 64-bit address pair per row
+  const __amdgpu_buffer_rsrc_t win_rs = table_rsrc(a.win32, 32 * 32 * 16);                  // [32 n1 + q] double2
+  const __amdgpu_buffer_rsrc_t mel_rs = table_rsrc(a.melw32, kMel32Pairs * 32 * 8);         // [32 pair + q] double
+  const int q16 = 16 * q, q8 = 8 * q;
+  const double2* const tw = reinterpret_cast<const double2*>(lds_raw + Map::tw) + q;        // + 32 n2
+  const double2* const post = reinterpret_cast<const double2*>(lds_raw + Map::post) + q;    // + 32 r
+  const double* const dct = reinterpret_cast<const double*>(lds_raw + Map::dct);
+  const double* const logc = reinterpret_cast<const double*>(lds_raw + Map::logc);
+  const int stride2 = 2 * a.lay.stride;
+  double* const plane = reinterpret_cast<double*>(lds_raw + Map::xchg + wave * kPlane32Bytes) + kHalfSlots * h;
+  double* const pw = plane + q;                      // + 33 k1: this lane is n2 = q when writing
+  // + n2: this lane is k1 = q when reading (volatile: one ds_read_b64 per value, never ds_read2_b64 at half
+  // the rate; the explicit LDS address space keeps the volatile accesses DS instructions)
+  using lds_vdouble = volatile __attribute__((address_space(3))) double;
+  lds_vdouble* const pr = (lds_vdouble*)(plane + 33 * q);
+  const int partner = (lane & 32) + ((32 - q) & 31);
+  // the new hop of the next frame (rows 16..31 of both halves, 8 KiB per wave) is moved global -> LDS by eight
+  // global_load_lds_dwordx4 (1 KiB each: lane L's 16 bytes land at 16 L) into the exchange plane, which is idle
+  // between two exchanges: image [row][half][q] float2.  Lane L moves complex samples 2 (L & 15), +1 of row
+  // 16 + 2 j + (L >> 5) of half (L >> 4) & 1.
+  const int dh = (lane >> 4) & 1, drow = lane >> 5, dq = 2 * (lane & 15);
+  typedef __attribute__((address_space(1))) const void gvoid;
+  typedef __attribute__((address_space(3))) void lvoid;
+  unsigned char* const plane_bytes = lds_raw + Map::xchg + wave * kPlane32Bytes;
+  lds_vdouble* const hop = (lds_vdouble*)(plane_bytes + 256 * h + 8 * q);   // + 64 r (8-byte units: 512 bytes a row)
+
+  const float* const pcm = reinterpret_cast<const float*>(a.pcm);
+
+  // Work queue.  A static split is badly unbalanced here: of the two waves that share a SIMD the older one wins
+  // the issue arbitration and finishes its share ~35 % earlier (measured), and CUs differ by up to 30 %.  Every
+  // wave starts with the pair of chunks of its own index (no atomic on the way in) and then draws further pairs
+  // from one device counter.  A draw follows every processed pair, so a launch advances the counter by exactly
+  // the number of pairs: the host passes the counter's value at launch (queue_base) instead of resetting it.
+  const int n_items = (a.n_chunks + 1) >> 1;
+  const int n_static = min((int)(gridDim.x * kWaves32), n_items);
+  for (int slot = blockIdx.x * kWaves32 + wave; slot < n_items;) {
+    const int ci = 2 * slot + h;
+    const bool have = ci < a.n_chunks;
+    const Chunk ch = a.chunks[have ? ci : 2 * slot];
+    const int nfr = have ? ch.nframes : 0;
+    const int total = max(__builtin_amdgcn_readlane(nfr, 0), __builtin_amdgcn_readlane(nfr, 32));
+    const float2* src = reinterpret_cast<const float2*>(pcm + ch.sample_off) + q;
+    // this lane's part in the LDS-DMA: the chunk of half dh
+    const int cid = 2 * slot + dh;
+    const bool have_d = cid < a.n_chunks;
+    const Chunk chd = a.chunks[have_d ? cid : 2 * slot];
+    const int last_d = max((have_d ? (int)chd.nframes : 0) - 1, 0);
+    const float* const dsrc = pcm + chd.sample_off + 64 * (16 + drow) + 2 * dq;   // row 16 + drow, sample 2 dq
+
+    float2 lo[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) lo[r] = src[32 * r];
+    // frame 0's new hop (every DS operation of the previous chunk has been waited for)
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      __builtin_amdgcn_global_load_lds((gvoid*)(dsrc + 128 * j), (lvoid*)(plane_bytes + 1024 * j), 16, 0, 0);
+
+    double mel_acc = 0.0;  // mel sums of up to two finished frames per half: lane 2 f + slot
+    // this lane's output element: coefficient (q >> 1) of the frame in slot q & 1
+    double* recp = a.rec + ((int64_t)ch.frame0 + (q & 1)) * a.lay.stride + a.lay.mfcc + ((q >> 1) & 15);
+    int left = nfr - (q & 1);
+
+    // The loop body is software-pipelined by hand (two waves per SIMD leave little for the hardware to hide):
+    // every table / LDS / cross-lane read is issued one step before the arithmetic that consumes it, and
+    // sched_barriers keep the compiler from folding the steps back together.
+    double2 w[32];   // window pairs of the NEXT frame: loaded at the bottom of the loop, when the FFT registers are dead
+#pragma unroll
+    for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
+
+#if AFX_STAMPS
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(stamp_prev));
+#endif
+    for (int fi = 0; fi < total; ++fi) {
+      // ---- window (table carries the 1/2048 of kDivFwdByN and the 1/2 of the untangle) ----
+      cx<double> v[32];
+      {
+        float2 nx[16];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the hop's LDS-DMA has landed (and the window pairs)
+        AFX_STAMP(0);   // wait for DMA + window
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nx[r] = __builtin_bit_cast(float2, (double)hop[64 * r]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          v[r] = {(double)lo[r].x * w[r].x, (double)lo[r].y * w[r].y};
+          v[r + 16] = {(double)nx[r].x * w[r + 16].x, (double)nx[r].y * w[r + 16].y};
+          lo[r] = nx[r];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      AFX_STAMP(1);   // hop reads + conversion + window
+
+      // ---- P1 ----
+      f32x32::dft32(v);
+      __builtin_amdgcn_sched_barrier(0);
+      AFX_STAMP(2);   // P1
+
+      // ---- E: real parts, then imaginary parts through the same plane (a wave's DS operations execute in
+      // order, so the second round of writes needs no wait for the first round of reads); the first two groups
+      // of twiddles queue up behind them ----
+      double2 t[32];
+      {
+        double re[32], im[32];
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) pw[33 * k1] = v[k1].re;
+#pragma unroll
+        for (int n2 = 0; n2 < 32; ++n2) re[n2] = pr[n2];
+#pragma unroll
+        for (int k1 = 0; k1 < 32; ++k1) pw[33 * k1] = v[k1].im;
+#pragma unroll
+        for (int n2 = 0; n2 < 32; ++n2) im[n2] = pr[n2];
+#pragma unroll
+        for (int n2 = 1; n2 < 16; ++n2) t[n2] = tw[32 * n2];
+#pragma unroll
+        for (int n2 = 0; n2 < 32; ++n2) v[n2] = {re[n2], im[n2]};
+      }
+      // ---- the next frame's new hop: LDS-DMA into the plane once the exchange reads have returned (the DMA is a
+      // vector-memory operation: nothing else orders it behind this wave's DS reads).  The last frame of a chunk
+      // re-reads its own hop (no branch: the loop body stays one basic block).
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      AFX_STAMP(3);   // exchange
+      {
+        const float* const nd = dsrc + (size_t)min(fi + 1, last_d) * kHop;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          __builtin_amdgcn_global_load_lds((gvoid*)(nd + 128 * j), (lvoid*)(plane_bytes + 1024 * j), 16, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- T: * w1024^(n2 k1), groups of eight, the group after next in flight ----
+#pragma unroll
+      for (int n2 = 1; n2 < 8; ++n2) v[n2] = f32x32::cmul(v[n2], cx<double>{t[n2].x, t[n2].y});
+#pragma unroll
+      for (int n2 = 16; n2 < 24; ++n2) t[n2] = tw[32 * n2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n2 = 8; n2 < 16; ++n2) v[n2] = f32x32::cmul(v[n2], cx<double>{t[n2].x, t[n2].y});
+#pragma unroll
+      for (int n2 = 24; n2 < 32; ++n2) t[n2] = tw[32 * n2];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int n2 = 16; n2 < 32; ++n2) v[n2] = f32x32::cmul(v[n2], cx<double>{t[n2].x, t[n2].y});
+      __builtin_amdgcn_sched_barrier(0);
+      AFX_STAMP(4);   // DMA issue + twiddles
+
+      // ---- P2: v[k2] = Z[q + 32 k2] ----
+      f32x32::dft32(v);
+      __builtin_amdgcn_sched_barrier(0);
+      AFX_STAMP(5);   // P2
+
+      // ---- U: untangle + magnitude: mag[r] = |X[q + 32 r]|, four rows at a time, the next four rows' partner
+      // values (cross-lane) and post-twiddles (LDS) in flight ----
+      double mag[MR];
+      cx<double> pp[MR];
+      double2 pw2[MR];
+      double mwt[kMel32Pairs];
+      auto fetch = [&](int r) {
+        pp[r] = {__shfl(v[31 - r].re, partner), __shfl(v[31 - r].im, partner)};
+        pw2[r] = post[32 * r];
+      };
+      auto untangle = [&](int r) {
+        cx<double> p = pp[r];
+        if (q == 0) p = v[(32 - r) & 31];
+        const cx<double> z = v[r];
+        const double2 wq = pw2[r];
+        const double er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
+        const double orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
+        const double xr = er + (wq.x * orr - wq.y * oi);
+        const double xi = ei + (wq.x * oi + wq.y * orr);
+        mag[r] = mag_sqrt(xr * xr + xi * xi);
+      };
+#pragma unroll
+      for (int r = 0; r < 4; ++r) fetch(r);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 4; r < 8; ++r) fetch(r);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) untangle(r);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 8; r < 12; ++r) fetch(r);
+#pragma unroll
+      for (int r = 4; r < 8; ++r) untangle(r);
+      __builtin_amdgcn_sched_barrier(0);
+      // the packed mel rows come from global memory (L1/L2-resident): issued here, when two thirds of the FFT
+      // registers are dead
+#pragma unroll
+      for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
+#pragma unroll
+      for (int r = 8; r < 12; ++r) untangle(r);
+      __builtin_amdgcn_sched_barrier(0);
+      AFX_STAMP(6);   // untangle
+
+      // ---- MFCC: sparse mel rows now; log + DCT once per two iterations (vector.c:350-391) ----
+      {
+        double e[16];
+#pragma unroll
+        for (int f = 0; f < 16; ++f) e[f] = 0.0;
+#pragma unroll
+        for (int r = 0; r < kMel32Rows; ++r)
+#pragma unroll
+          for (int f = 0; f < kNumCep; ++f)
+            if (mel32_touches(f, r)) e[f] += mag[r] * mwt[mel32_pair_index(r, f)];
+        __builtin_amdgcn_sched_barrier(0);
+        AFX_STAMP(7);   // mel rows (waits for the table loads)
+        // the next frame's window pairs, under the reduction and the log / DCT
+#pragma unroll
+        for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
+        const double tot = half_sum16(e, lane);  // lane L: filter (L & 31) >> 1 of this half's frame
+        if ((lane & 1) == (fi & 1)) mel_acc = tot;
+        AFX_STAMP(8);   // window issue + reduction
+        if (fi & 1) finish_mfcc32(mel_acc, recp, left, stride2, dct, logc, lane);
+        AFX_STAMP(9);   // log + DCT + store (every second iteration)
+#if AFX_STAMPS
+        stamp_acc[15] += 1;
+#endif
+      }
+    }
+    if (total & 1) finish_mfcc32(mel_acc, recp, left, stride2, dct, logc, lane);
+    unsigned drawn = 0;
+    if (lane == 0) drawn = atomicAdd(a.queue, 1u);
+    slot = n_static + (int)((unsigned)__builtin_amdgcn_readfirstlane(drawn) - a.queue_base);
+  }
+#if AFX_STAMPS
+  if (stamping && lane == 0)
+    for (int i = 0; i < 16; ++i) atomicAdd(&a.stamps[i], (unsigned long long)stamp_acc[i]);
+  if (a.stamps != nullptr && lane == 0) {
+    // life of this wave: core-clock and 100 MHz real-time stamps at entry and exit, per workgroup
+    unsigned long long life_core1, life_real1;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(life_core1), "=s"(life_real1));
+    unsigned long long* const l = a.stamps + 16 + 4 * ((blockIdx.x & 255) * 8 + wave);
+    l[0] = life_core0; l[1] = life_core1; l[2] = life_real0; l[3] = life_real1;
+  }
+#endif
+}
+
+}  // namespace
+
+int frames32_waves_per_block() { return kWaves32; }
+
+// which (descriptor mask, arithmetic, PCM type) combinations the half-wave kernels serve
+bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype) {
+  return mask == 1u && precision == 0 && pcm_dtype == 0;
+}
+
+// MFCC-only class, f64 arithmetic, f32 PCM
+hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream) {
+  if (a.n_chunks <= 0) return hipSuccess;
+  constexpr int lds = Lds32<kMel32Rows>::total;
+  auto k = frames32_kernel<0>;
+  static bool attribute_set[16] = {};   // per device: raising the dynamic LDS limit once is enough
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attribute_set[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e != hipSuccess) return e;
+    if (dev >= 0 && dev < 16) attribute_set[dev] = true;
+  }
+  hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(kWaves32 * 64), lds, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace afx

@@ -46,6 +46,26 @@ constexpr int mel_pair_index(int r, int f) {
   return -1;
 }
 
+// the same cover on rows of 32 bins (half-wave layout of afx_frames32.hip: bin = q + 32 r)
+constexpr int kMel32Rows = 12;    // bins 0..383
+constexpr bool mel32_touches(int f, int r) { return kMelLo[f] <= 32 * r + 31 && kMelHi[f] >= 32 * r; }
+constexpr int mel32_pair_count() {
+  int n = 0;
+  for (int r = 0; r < kMel32Rows; ++r)
+    for (int f = 0; f < kNumCep; ++f) n += mel32_touches(f, r) ? 1 : 0;
+  return n;
+}
+constexpr int kMel32Pairs = mel32_pair_count();  // 31
+constexpr int mel32_pair_index(int r, int f) {
+  int n = 0;
+  for (int rr = 0; rr < kMel32Rows; ++rr)
+    for (int ff = 0; ff < kNumCep; ++ff) {
+      if (rr == r && ff == f) return n;
+      n += mel32_touches(ff, rr) ? 1 : 0;
+    }
+  return -1;
+}
+
 // 28 "frequency_bands" edges in bins: round(f/21) of SampleAnalyser.cpp:2015-2019, first start =
 // bin 1, last end clamped to 1024 (SampleAnalyser.cpp:2029-2040)
 constexpr int kBandEdge[kNumBands + 1] = {1, 2, 5, 7, 10, 14, 19, 24, 30, 37, 44, 51, 60, 70, 82,
@@ -94,12 +114,24 @@ struct FrameArgs {
   const void* post;  // [16][64] complex w2048^(lane+64r)                             (T)
   const void* melw;    // [kMelPairs][64] packed mel rows                                  (T)
   const double* dct;   // [14][16]: cos(pi * (n/14) * (m + 0.5)), m < 14
+  // tables of the half-wave kernels (afx_frames32.hip), always double
+  const void* win32;   // [32][32] pairs (w[2n], w[2n+1]) / 4096, n = q + 32 n1
+  const void* tw32;    // [32][32] complex w1024^(n2 k1), index 32 n2 + k1
+  const void* post32;  // [32][32] complex w2048^(q + 32 r)
+  const void* melw32;  // [kMel32Pairs][32] packed mel rows
+  unsigned* queue;     // work-queue counter of the half-wave kernels: advances by ceil(n_chunks / 2) per launch
+  unsigned queue_base; // its value when this launch starts
+  unsigned long long* stamps;   // diagnostic builds (AFX_STAMPS): 16 per-stage cycle counters, else nullptr
 };
 
 // launchers (afx_kernels.hip).  precision: 0 = f64, 1 = f32; pcm_dtype: AFX_PCM_*
 hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int grid_blocks,
                          hipStream_t stream);
 int frames_waves_per_block(uint32_t mask);    // waves (of 64 lanes) per workgroup
+// half-wave kernels (afx_frames32.hip): a wave walks two chunks at a time, one per 32-lane half
+bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype);
+hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream);
+int frames32_waves_per_block();
 int frames_feature_class(uint32_t mask);     // 0 = MFCC only, 1 = + statistics, 2 = everything
 
 // band-feature kernel (SampleAnalyser.cpp:2067-2308) working from stored magnitudes

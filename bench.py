@@ -43,6 +43,7 @@ def parse_args():
                          "of 100 000 stereo 1.0 s files (configs[3]: 12 500 per GPU on 8 GPUs, --files to change)")
     ap.add_argument("--files", type=int, default=12500, help="files per GPU of the c4 workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-single", action="store_true", help="skip the single-10k-frame-buffer figure (profiling runs)")
     ap.add_argument("--cpu-frames", type=int, default=30000, help="frames per CPU worker for the baseline")
     return ap.parse_args()
 
@@ -211,7 +212,7 @@ def main():
 
     # the literal BASELINE configs[1] shape as a secondary number: ONE resident buffer of 10 000 frames
     single = None
-    if rank == 0 and args.workload == "c2" and args.mask == "c2":
+    if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
         one = plan.batch(make_buffers(1, 4321), mask)
         for _ in range(5):
             one.run()

@@ -62,6 +62,17 @@ __device__ __forceinline__ double table_load1(__amdgpu_buffer_rsrc_t rs, int lan
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, row_off, 0));
 }
 
+// Magnitude for the mel sums: v_rsq_f64 seed (~2^-23) + one Goldschmidt step (~2e-14 relative).  Sums of squares
+// below the smallest normal double come out as sqrt(DBL_MIN) ~ 1.5e-154 instead of the reference's flushed 0
+// (TAudioMath::Magnitude runs with DAZ + FZ, AudioMath.cpp:25-35): every mel sum of such bins stays below the
+// 2e-42 floor of the logarithm, so the MFCCs are the same and the select is saved.
+__device__ __forceinline__ double mag_sqrt_mel(double x) {
+  const double xs = fmax(x, 2.2250738585072014e-308);
+  const double r = __builtin_amdgcn_rsq(xs);
+  const double g = xs * r, h = 0.5 * r;
+  return fma(g, fma(-h, g, 0.5), g);
+}
+
 // ---- reductions over the 32 lanes of each half ----
 // 16 per-lane values summed over the half at once: lane L ends with the total of a[(L & 31) >> 1]
 __device__ __forceinline__ double half_sum16(double (&a)[16], int lane) {
@@ -283,7 +294,23 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       // ---- E: real parts, then imaginary parts through the same plane (a wave's DS operations execute in
       // order, so the second round of writes needs no wait for the first round of reads); the first two groups
       // of twiddles queue up behind them ----
+      // twiddles by first-stage butterfly: group g = butterflies j = 2 g, 2 g + 1 on rows j, j + 8, j + 16, j + 24
       double2 t[32];
+      auto load_tw = [&](int g) {
+#pragma unroll
+        for (int j = 2 * g; j < 2 * g + 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            if (j + 8 * i != 0) t[j + 8 * i] = tw[32 * (j + 8 * i)];
+      };
+      auto bfly_tw = [&](int g) {
+#pragma unroll
+        for (int j = 2 * g; j < 2 * g + 2; ++j) {
+          const cx<double> w1{t[j + 8].x, t[j + 8].y}, w2{t[j + 16].x, t[j + 16].y}, w3{t[j + 24].x, t[j + 24].y};
+          if (j == 0) f32x32::radix4_tw3(v[0], v[8], v[16], v[24], w1, w2, w3);
+          else f32x32::radix4_tw4(v[j], v[j + 8], v[j + 16], v[j + 24], cx<double>{t[j].x, t[j].y}, w1, w2, w3);
+        }
+      };
       {
         double re[32], im[32];
 #pragma unroll
@@ -294,8 +321,8 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         for (int k1 = 0; k1 < 32; ++k1) pw[33 * k1] = v[k1].im;
 #pragma unroll
         for (int n2 = 0; n2 < 32; ++n2) im[n2] = pr[n2];
-#pragma unroll
-        for (int n2 = 1; n2 < 16; ++n2) t[n2] = tw[32 * n2];
+        load_tw(0);
+        load_tw(1);
 #pragma unroll
         for (int n2 = 0; n2 < 32; ++n2) v[n2] = {re[n2], im[n2]};
       }
@@ -312,24 +339,19 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       }
       __builtin_amdgcn_sched_barrier(0);
 
-      // ---- T: * w1024^(n2 k1), groups of eight, the group after next in flight ----
-#pragma unroll
-      for (int n2 = 1; n2 < 8; ++n2) v[n2] = f32x32::cmul(v[n2], cx<double>{t[n2].x, t[n2].y});
-#pragma unroll
-      for (int n2 = 16; n2 < 24; ++n2) t[n2] = tw[32 * n2];
+      // ---- T + P2: v[k2] = Z[q + 32 k2]; the factors w1024^(n2 k1) are fused into the first radix-4 stage of
+      // the 32-point DFT, two butterflies at a time, the twiddles of the butterflies after next in flight ----
+      bfly_tw(0);
+      load_tw(2);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int n2 = 8; n2 < 16; ++n2) v[n2] = f32x32::cmul(v[n2], cx<double>{t[n2].x, t[n2].y});
-#pragma unroll
-      for (int n2 = 24; n2 < 32; ++n2) t[n2] = tw[32 * n2];
+      bfly_tw(1);
+      load_tw(3);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int n2 = 16; n2 < 32; ++n2) v[n2] = f32x32::cmul(v[n2], cx<double>{t[n2].x, t[n2].y});
+      bfly_tw(2);
+      bfly_tw(3);
       __builtin_amdgcn_sched_barrier(0);
-      AFX_STAMP(4);   // DMA issue + twiddles
-
-      // ---- P2: v[k2] = Z[q + 32 k2] ----
-      f32x32::dft32(v);
+      AFX_STAMP(4);   // DMA issue + twiddled first stage
+      f32x32::dft32_rest(v);
       __builtin_amdgcn_sched_barrier(0);
       AFX_STAMP(5);   // P2
 
@@ -352,7 +374,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         const double orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
         const double xr = er + (wq.x * orr - wq.y * oi);
         const double xi = ei + (wq.x * oi + wq.y * orr);
-        mag[r] = mag_sqrt(xr * xr + xi * xi);
+        mag[r] = mag_sqrt_mel(xr * xr + xi * xi);
       };
 #pragma unroll
       for (int r = 0; r < 4; ++r) fetch(r);

@@ -655,7 +655,10 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   // amortise the 2048-sample lead-in of each chunk
   // K is picked to minimise (rounds of the wave slots) x (frames per chunk + lead-in): long chunks for
   // big batches, one round of short chunks when the batch barely fills the chip
-  b->halfwave = plan->halfwave && afx::frames_use_halfwave(fmask, plan->desc.precision, dtype);
+  // the half-wave kernel pays a longer prologue per chunk: it serves batches that give every half-wave slot
+  // several frames; smaller ones (one short file per call) stay with the 64-lane kernel
+  b->halfwave = plan->halfwave && afx::frames_use_halfwave(fmask, plan->desc.precision, dtype) &&
+                frames >= 8 * (int64_t)plan->cu_count * afx::frames32_waves_per_block() * 2;
   const int waves_per_block = b->halfwave ? afx::frames32_waves_per_block() : afx::frames_waves_per_block(fmask);
   const int64_t slots = (int64_t)plan->cu_count * waves_per_block * (b->halfwave ? 2 : 1);
   int K = 32;

@@ -73,8 +73,8 @@ __device__ __forceinline__ double mag_sqrt_mel(double x) {
   return fma(g, fma(-h, g, 0.5), g);
 }
 
-// ---- reductions over the 32 lanes of each half ----
-// 16 per-lane values summed over the half at once: lane L ends with the total of a[(L & 31) >> 1]
+// ---- reduction of 16 per-lane values over the 32 lanes of each half, in registers: lane L ends with the total of
+// a[(L & 31) >> 1] ----
 __device__ __forceinline__ double half_sum16(double (&a)[16], int lane) {
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -276,18 +276,30 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 #pragma unroll
         for (int r = 0; r < 16; ++r) nx[r] = __builtin_bit_cast(float2, (double)hop[64 * r]);
         __builtin_amdgcn_sched_barrier(0);
+        // window products fused into the first radix-4 stage of P1 (rows j, j + 8 from the overlap half, rows
+        // j + 16, j + 24 from the new hop): a w_a +- c w_c as one product and two fused multiply-adds
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          v[r] = {(double)lo[r].x * w[r].x, (double)lo[r].y * w[r].y};
-          v[r + 16] = {(double)nx[r].x * w[r + 16].x, (double)nx[r].y * w[r + 16].y};
-          lo[r] = nx[r];
+        for (int j = 0; j < 8; ++j) {
+          const double ar = (double)lo[j].x, ai = (double)lo[j].y, br = (double)lo[j + 8].x, bi = (double)lo[j + 8].y;
+          const double cr = (double)nx[j].x, ci = (double)nx[j].y, dr = (double)nx[j + 8].x, di = (double)nx[j + 8].y;
+          const double par = ar * w[j].x, pai = ai * w[j].y, pbr = br * w[j + 8].x, pbi = bi * w[j + 8].y;
+          const double t0r = fma(cr, w[j + 16].x, par), t0i = fma(ci, w[j + 16].y, pai);
+          const double t1r = fma(-cr, w[j + 16].x, par), t1i = fma(-ci, w[j + 16].y, pai);
+          const double t2r = fma(dr, w[j + 24].x, pbr), t2i = fma(di, w[j + 24].y, pbi);
+          const double t3r = fma(-dr, w[j + 24].x, pbr), t3i = fma(-di, w[j + 24].y, pbi);
+          v[j] = {t0r + t2r, t0i + t2i};
+          v[j + 16] = {t0r - t2r, t0i - t2i};
+          v[j + 8] = {t1r + t3i, t1i - t3r};
+          v[j + 24] = {t1r - t3i, t1i + t3r};
         }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lo[r] = nx[r];
       }
       __builtin_amdgcn_sched_barrier(0);
-      AFX_STAMP(1);   // hop reads + conversion + window
+      AFX_STAMP(1);   // hop reads + conversion + window + first radix-4 stage
 
-      // ---- P1 ----
-      f32x32::dft32(v);
+      // ---- P1 (rest) ----
+      f32x32::dft32_rest(v);
       __builtin_amdgcn_sched_barrier(0);
       AFX_STAMP(2);   // P1
 
@@ -372,8 +384,8 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         const double2 wq = pw2[r];
         const double er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
         const double orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
-        const double xr = er + (wq.x * orr - wq.y * oi);
-        const double xi = ei + (wq.x * oi + wq.y * orr);
+        const double xr = fma(wq.x, orr, fma(-wq.y, oi, er));
+        const double xi = fma(wq.x, oi, fma(wq.y, orr, ei));
         mag[r] = mag_sqrt_mel(xr * xr + xi * xi);
       };
 #pragma unroll

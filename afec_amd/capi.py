@@ -50,7 +50,7 @@ PCM_F32, PCM_F64 = 0, 1
 
 # every symbol include/afx.h declares (tests check the library exports exactly these)
 EXPORTS = [
-    "afx_status_str", "afx_last_error", "afx_plan_create", "afx_plan_destroy",
+    "afx_status_str", "afx_last_error", "afx_build_info", "afx_plan_create", "afx_plan_destroy",
     "afx_plan_get_window", "afx_plan_get_mel_table", "afx_plan_get_bin_range", "afx_num_frames",
     "afx_extract_batch", "afx_batch_create", "afx_batch_total_frames", "afx_batch_run",
     "afx_batch_sync", "afx_batch_run_timed", "afx_batch_fetch", "afx_batch_fetch_statistics", "afx_batch_destroy",
@@ -158,6 +158,7 @@ def load_library():
     L.afx_status_str.restype = ctypes.c_char_p
     L.afx_status_str.argtypes = [ctypes.c_int]
     L.afx_last_error.restype = ctypes.c_char_p
+    L.afx_build_info.restype = ctypes.c_char_p
     L.afx_plan_create.argtypes = [ctypes.POINTER(_PlanDesc), ctypes.POINTER(vp)]
     L.afx_plan_destroy.argtypes = [vp]
     L.afx_plan_destroy.restype = None

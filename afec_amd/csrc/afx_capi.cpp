@@ -164,7 +164,9 @@ struct afx_plan {
   std::vector<double> mel;     // [14][fft/2]
   DeviceTables dev;
   int cu_count = 256;
-  bool halfwave = true;   // AFX_HALFWAVE=0 in the environment keeps the 64-lane frame kernels (A/B timing)
+  // AFX_HALFWAVE in the environment when the plan is created: 0 = 64-lane frame kernels only (A/B timing),
+  // 1 = by batch size (default), 2 = half-wave kernel for every batch it supports (tests)
+  int halfwave = 1;
 };
 
 struct afx_batch {
@@ -489,6 +491,22 @@ const char* afx_status_str(int status) {
 
 const char* afx_last_error(void) { return g_last_error.c_str(); }
 
+// What this library was built with: the shipped library has no diagnostic or ablation switch set
+// (tests/test_capi_cpu.py asserts it).
+const char* afx_build_info(void) {
+#if defined(AFX_STAMPS) && AFX_STAMPS
+#define AFX_INFO_STAMPS "1"
+#else
+#define AFX_INFO_STAMPS "0"
+#endif
+#if defined(AFX_ABL) && AFX_ABL
+#define AFX_INFO_ABL "1"
+#else
+#define AFX_INFO_ABL "0"
+#endif
+  return "afx abi=" "3" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL;
+}
+
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   if (!desc || !out_plan) return fail(AFX_ERR_INVALID_ARG, "null argument");
   *out_plan = nullptr;
@@ -540,7 +558,7 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   if (e != hipSuccess) { delete p; return hip_fail(e, "hipSetDevice"); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess) p->cu_count = prop.multiProcessorCount;
-  if (const char* hw = std::getenv("AFX_HALFWAVE")) p->halfwave = (hw[0] != '0');
+  if (const char* hw = std::getenv("AFX_HALFWAVE")) p->halfwave = (hw[0] == '0') ? 0 : (hw[0] == '2' ? 2 : 1);
   const int st = upload_tables(p);
   if (st != AFX_OK) { free_tables(p); delete p; return st; }
   *out_plan = p;
@@ -658,7 +676,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   // the half-wave kernel pays a longer prologue per chunk: it serves batches that give every half-wave slot
   // several frames; smaller ones (one short file per call) stay with the 64-lane kernel
   b->halfwave = plan->halfwave && afx::frames_use_halfwave(fmask, plan->desc.precision, dtype) &&
-                frames >= 8 * (int64_t)plan->cu_count * afx::frames32_waves_per_block() * 2;
+                (plan->halfwave == 2 || frames >= 8 * (int64_t)plan->cu_count * afx::frames32_waves_per_block() * 2);
   const int waves_per_block = b->halfwave ? afx::frames32_waves_per_block() : afx::frames_waves_per_block(fmask);
   const int64_t slots = (int64_t)plan->cu_count * waves_per_block * (b->halfwave ? 2 : 1);
   int K = 32;

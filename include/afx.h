@@ -33,6 +33,8 @@ enum {
 };
 const char* afx_status_str(int status);
 const char* afx_last_error(void); /* thread-local detail text of the last failing call */
+/* "afx abi=N arch=gfx950 stamps=0 ablation=0": the shipped library carries no diagnostic / ablation switch */
+const char* afx_build_info(void);
 
 /* ---- PCM sample types of afx_buf.dtype ---- */
 enum {
@@ -108,6 +110,8 @@ typedef struct {
                               0 disables the cap (synthetic benchmarks)                       */
 } afx_plan_desc;
 
+/* Environment read by afx_plan_create: AFX_HALFWAVE = 0 | 1 | 2 selects the frame kernel of the MFCC-only class
+ * (0: 64-lane kernel, 1: by batch size (default), 2: half-wave kernel for every batch; results agree to rounding). */
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan);
 void afx_plan_destroy(afx_plan* plan);
 

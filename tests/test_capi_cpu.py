@@ -50,6 +50,15 @@ def test_status_strings(lib):
     assert b"device" in lib.afx_status_str(-3)
 
 
+def test_shipped_library_has_no_diagnostic_or_ablation_switches(lib):
+    info = lib.afx_build_info().decode()
+    assert "arch=gfx950" in info and "stamps=0" in info and "ablation=0" in info, info
+    # the switches themselves must not be set by the product Makefile
+    mk = open(os.path.join(ROOT, "afec_amd", "csrc", "Makefile")).read()
+    product_flags = [l for l in mk.splitlines() if l.startswith("CXXFLAGS")]
+    assert product_flags and all("AFX_STAMPS" not in l and "AFX_ABL" not in l for l in product_flags)
+
+
 def test_plan_create_fails_loudly_without_gpu(lib):
     import ctypes
     n = ctypes.c_int(0)

@@ -1,0 +1,123 @@
+"""GPU parity of the half-wave STFT + MFCC kernel (afec_amd/csrc/afx_frames32.hip): the MFCC-only class with
+f32 PCM, forced on for every batch size with AFX_HALFWAVE=2, against the reference goldens, the oracle and the
+64-lane kernel (AFX_HALFWAVE=0).  Covers what the work queue and the two-chunks-per-wave walk can get wrong:
+odd chunk counts, chunks of different lengths in the two halves of a wave, one-frame buffers, repeated launches
+on one batch (the queue counter is never reset) and workspace reuse between batches."""
+import os
+
+import numpy as np
+import pytest
+
+import afec_amd as afx
+from tests import _tol
+from tests._oracle import FIELDS, Oracle
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def make_plan(mode):
+    old = os.environ.get("AFX_HALFWAVE")
+    os.environ["AFX_HALFWAVE"] = str(mode)
+    try:
+        return afx.Plan(max_analysis_ms=0)
+    finally:
+        if old is None:
+            del os.environ["AFX_HALFWAVE"]
+        else:
+            os.environ["AFX_HALFWAVE"] = old
+
+
+@pytest.fixture(scope="module")
+def forced():
+    p = make_plan(2)
+    yield p
+    p.close()
+
+
+@pytest.fixture(scope="module")
+def lanes64():
+    p = make_plan(0)
+    yield p
+    p.close()
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return Oracle()
+
+
+def golden_names():
+    z = np.load(os.path.join(GOLD, "frames.npz"))
+    return sorted(k[3:] for k in z.files if k.startswith("in_"))
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_mfcc(forced, name):
+    z = np.load(os.path.join(GOLD, "frames.npz"))
+    x, ref = z["in_" + name], z["ref_" + name]
+    res = forced.extract([x.astype(np.float32)], afx.D_MFCC)
+    a, b = FIELDS["mfcc"]
+    # goldens were generated from double input; the signals are exactly representable in float32 or the
+    # float32 rounding is part of both sides only when the test converts: compare against the oracle on the
+    # float32 signal instead when the cast changes the input
+    if np.array_equal(x.astype(np.float32).astype(np.float64), x):
+        _tol.check("mfcc", res["mfcc"], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=name + " ")
+    else:
+        o = Oracle().run(x.astype(np.float32).astype(np.float64))
+        _tol.check("mfcc", res["mfcc"], o[:, a:b], *_tol.GPU_TOL["mfcc"], what=name + " (oracle) ")
+
+
+def test_ragged_batch_matches_oracle_and_the_64_lane_kernel(forced, lanes64, oracle):
+    rng = np.random.default_rng(5)
+    # 0 and sub-frame buffers, one-frame buffers, lengths that leave chunks of different sizes in the two halves
+    lens = [0, 100, 2048, 2048, 3072, 2048 + 1024 * 2, 2048 + 1024 * 33, 2048 + 1024 * 64, 2048 + 1024 * 97, 2047,
+            2048 + 1024 * 31, 2048]
+    bufs = [rng.uniform(-1, 1, n).astype(np.float32) for n in lens]
+    bufs[6] = (0.5 * np.sin(2 * np.pi * 440.0 * np.arange(lens[6]) / 44100)).astype(np.float32)   # tonal
+    bufs[7][:] = 0.0                                                                             # silence: log floor
+    got = forced.extract(bufs, afx.D_MFCC)
+    ref64 = lanes64.extract(bufs, afx.D_MFCC)
+    assert got["frame_offset"].tolist() == ref64["frame_offset"].tolist()
+    assert got["buf_status"].tolist() == ref64["buf_status"].tolist()
+    # two FFT factorisations of the same double arithmetic
+    _tol.check("mfcc", got["mfcc"], ref64["mfcc"], 1e-9, 1e-9, what="half-wave vs 64-lane ")
+    a, b = FIELDS["mfcc"]
+    off = got["frame_offset"]
+    for i, x in enumerate(bufs):
+        if off[i + 1] == off[i]:
+            continue
+        o = oracle.run(x.astype(np.float64))
+        _tol.check("mfcc", got["mfcc"][off[i]:off[i + 1]], o[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"buffer {i} ")
+
+
+def test_repeated_launches_and_workspace_reuse(forced):
+    rng = np.random.default_rng(9)
+    a = [rng.uniform(-1, 1, 2048 + 1024 * 150).astype(np.float32) for _ in range(5)]
+    b = [rng.uniform(-1, 1, 2048 + 1024 * 17).astype(np.float32) for _ in range(3)]
+    first = forced.extract(a, afx.D_MFCC)["mfcc"].copy()
+    batch = forced.batch(a, afx.D_MFCC)
+    for _ in range(4):            # the work-queue counter advances from launch to launch
+        batch.run()
+    batch.sync()
+    np.testing.assert_array_equal(batch.fetch()["mfcc"], first)
+    batch.close()
+    other = forced.extract(b, afx.D_MFCC)["mfcc"].copy()    # the pooled workspace (and its counter) changes hands
+    np.testing.assert_array_equal(forced.extract(a, afx.D_MFCC)["mfcc"], first)
+    np.testing.assert_array_equal(forced.extract(b, afx.D_MFCC)["mfcc"], other)
+
+
+def test_default_plan_picks_the_half_wave_kernel_for_large_batches(forced, oracle):
+    """Above the size threshold a default plan takes the same path (bitwise the same results)."""
+    rng = np.random.default_rng(21)
+    bufs = [rng.uniform(-1, 1, 2048 + 1024 * 2999).astype(np.float32) for _ in range(24)]   # 72 000 frames
+    auto = make_plan(1)
+    try:
+        got = auto.extract(bufs, afx.D_MFCC)["mfcc"]
+    finally:
+        auto.close()
+    np.testing.assert_array_equal(got, forced.extract(bufs, afx.D_MFCC)["mfcc"])
+    a, b = FIELDS["mfcc"]
+    o = oracle.run(bufs[3][:2048 + 1024 * 40].astype(np.float64))
+    _tol.check("mfcc", got[3 * 3000:3 * 3000 + 41], o[:, a:b], *_tol.GPU_TOL["mfcc"], what="large batch ")

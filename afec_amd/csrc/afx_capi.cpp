@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -156,6 +157,9 @@ struct Workspace {
 };
 
 struct afx_plan {
+  // the plan handle and every live batch hold one reference; the last one to go frees the plan (a batch destroyed
+  // after afx_plan_destroy still finds its plan, its device and its workspace pool)
+  std::atomic<int> refs{1};
   std::mutex pool_mutex;
   std::vector<Workspace*> pool;
   afx_plan_desc desc;
@@ -198,6 +202,7 @@ struct afx_batch {
   unsigned* d_queue = nullptr;   // work-queue counter of the half-wave frame kernel (lives in the workspace)
   std::vector<int64_t> arena_off, used;  // per buffer: start and length (samples) of its analysed prefix in d_pcm
   bool mag_wanted = false;
+  bool ran = false;        // afx_batch_run has been enqueued at least once: the fetches have something to fetch
   bool halfwave = false;   // frames by the half-wave kernel: a wave walks two chunks at a time
 };
 
@@ -499,11 +504,7 @@ const char* afx_build_info(void) {
 #else
 #define AFX_INFO_STAMPS "0"
 #endif
-#if defined(AFX_ABL) && AFX_ABL
-#define AFX_INFO_ABL "1"
-#else
-#define AFX_INFO_ABL "0"
-#endif
+#define AFX_INFO_ABL "0"   /* the ablation switches of round 1 are gone from the sources */
   return "afx abi=" "3" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL;
 }
 
@@ -565,13 +566,18 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   return AFX_OK;
 }
 
-void afx_plan_destroy(afx_plan* plan) {
-  if (!plan) return;
+static void plan_release(afx_plan* plan) {
+  if (plan->refs.fetch_sub(1) != 1) return;
   hipSetDevice(plan->desc.device);
   for (Workspace* w : plan->pool) ws_free(w);
   plan->pool.clear();
   free_tables(plan);
   delete plan;
+}
+
+void afx_plan_destroy(afx_plan* plan) {
+  if (!plan) return;
+  plan_release(plan);   // deferred until the last batch of this plan is destroyed
 }
 
 int afx_plan_get_window(const afx_plan* plan, double* out) {
@@ -624,6 +630,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     return fail(AFX_ERR_OUT_OF_MEMORY, "host allocation failed");
   }
   b->plan = plan;
+  plan->refs.fetch_add(1);
   b->mask = mask;
   b->n_bufs = n_bufs;
   b->lay = make_layout(mask);
@@ -665,6 +672,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   b->total_frames = frames;
   if (frames > 0x7FFFFF00LL) {
     delete b;
+    plan->refs.fetch_sub(1);
     ws_release(plan, acquired);
     return fail(AFX_ERR_INVALID_ARG, "more than 2^31 frames in one batch");
   }
@@ -812,29 +820,34 @@ bool mask_ok(uint32_t mask) {
          !(mask & ~(uint32_t)(AFX_D_ALL_PER_FRAME | AFX_D_MAGNITUDE | AFX_D_STATISTICS | AFX_D_EFFECTIVE_LENGTH));
 }
 
-}  // namespace
+// first valid buffer's PCM type (the arena of a call is homogeneous); -1 when there is none
+int first_valid_dtype(const afx_buf* bufs, int32_t n_bufs) {
+  for (int i = 0; i < n_bufs; ++i) {
+    const afx_buf& s = bufs[i];
+    if (s.n_samples >= 0 && (s.n_samples == 0 || s.pcm) && (s.dtype == AFX_PCM_F32 || s.dtype == AFX_PCM_F64)) return s.dtype;
+  }
+  return -1;
+}
 
-extern "C" {
-
-int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask,
-                     afx_batch** out_batch) {
+// afx_batch_create with the PCM type of the whole call given (afx_extract_batch cuts large calls into groups: the
+// type is decided once, over all buffers, not per group)
+int batch_create_typed(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask, int dtype, afx_batch** out_batch) {
   if (!plan || !out_batch || n_bufs < 0 || (n_bufs > 0 && !bufs))
     return fail(AFX_ERR_INVALID_ARG, "null argument");
   *out_batch = nullptr;
   if (!mask_ok(mask)) return fail(AFX_ERR_INVALID_ARG, "bad descriptor mask");
   HIP_TRY(hipSetDevice(plan->desc.device));
 
-  // one PCM dtype per batch (the arena is homogeneous); first valid buffer decides
+  // one PCM dtype per batch (the arena is homogeneous); first valid buffer of the call decides
   std::vector<int32_t> status((size_t)n_bufs, AFX_OK);
   std::vector<int64_t> lengths((size_t)n_bufs, 0);
-  int dtype = -1;
   for (int i = 0; i < n_bufs; ++i) {
     const afx_buf& s = bufs[i];
     const bool good = s.n_samples >= 0 && (s.n_samples == 0 || s.pcm) &&
                       (s.dtype == AFX_PCM_F32 || s.dtype == AFX_PCM_F64);
     if (!good) { status[i] = AFX_ERR_BAD_BUFFER; continue; }
     if (dtype < 0) dtype = s.dtype;
-    if (s.dtype != dtype) status[i] = AFX_ERR_BAD_BUFFER;
+    if (s.dtype != dtype) { status[i] = AFX_ERR_BAD_BUFFER; continue; }
     lengths[i] = s.n_samples;
   }
   if (dtype < 0) dtype = AFX_PCM_F32;
@@ -849,6 +862,17 @@ int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32
     return AFX_OK;
   };
   return build_batch(plan, n_bufs, mask, dtype, lengths, status, /*zero_arena=*/false, fill, out_batch);
+}
+
+}  // namespace
+
+extern "C" {
+
+int afx_batch_create(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint32_t mask,
+                     afx_batch** out_batch) {
+  if (!plan || !out_batch || n_bufs < 0 || (n_bufs > 0 && !bufs))
+    return fail(AFX_ERR_INVALID_ARG, "null argument");
+  return batch_create_typed(plan, bufs, n_bufs, mask, first_valid_dtype(bufs, n_bufs), out_batch);
 }
 
 // LoadSample front end (SampleAnalyser.cpp:484-718) on the GPU: decoded interleaved PCM in,
@@ -960,6 +984,7 @@ int64_t afx_batch_total_frames(const afx_batch* batch) { return batch ? batch->t
 int afx_batch_run(afx_batch* b) {
   if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
   HIP_TRY(hipSetDevice(b->plan->desc.device));
+  b->ran = true;
   if (b->d_efflen) {
     // DbToLin(-48 / -24 / -12), AudioMath.inl:108-123
     const double k = std::log(10.0) / 20.0;
@@ -1062,6 +1087,15 @@ int afx_batch_run_timed(afx_batch* b, int32_t steps, float* elapsed_ms) {
 
 int afx_batch_fetch(afx_batch* b, afx_out* out) {
   if (!b || !out) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  if (!b->ran) return fail(AFX_ERR_INVALID_ARG, "afx_batch_fetch before afx_batch_run (the pooled workspace would hand back another batch's results)");
+  {
+    // every requested output must be in the batch mask, whatever the number of frames
+    const afx::RecordLayout& lay = b->lay;
+    for (const FieldDesc& d : kFields)
+      if (out->*(d.out) && lay.*(d.off) < 0) return fail(AFX_ERR_INVALID_ARG, "output requested that is not in the batch mask");
+    if (out->magnitude && !(b->mask & AFX_D_MAGNITUDE)) return fail(AFX_ERR_INVALID_ARG, "magnitude not in the batch mask");
+    if (out->effective_length && !b->d_efflen && b->n_bufs > 0) return fail(AFX_ERR_INVALID_ARG, "effective_length not in the batch mask");
+  }
   HIP_TRY(hipSetDevice(b->plan->desc.device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   if (out->frame_offset) std::memcpy(out->frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t));
@@ -1109,6 +1143,7 @@ int afx_batch_fetch_statistics(afx_batch* b, afx_stats_out* out) {
   if (!b || !out) return fail(AFX_ERR_INVALID_ARG, "null argument");
   if (b->n_bufs == 0) return AFX_OK;
   if (!b->d_stats) return fail(AFX_ERR_INVALID_ARG, "AFX_D_STATISTICS was not in the batch mask");
+  if (!b->ran) return fail(AFX_ERR_INVALID_ARG, "afx_batch_fetch_statistics before afx_batch_run");
   HIP_TRY(hipSetDevice(b->plan->desc.device));
   HIP_TRY(hipStreamSynchronize(b->stream));
   const afx::RecordLayout& l = b->lay;
@@ -1126,14 +1161,15 @@ int afx_batch_fetch_statistics(afx_batch* b, afx_stats_out* out) {
   }
   if (out->stats_status)
     for (int32_t i = 0; i < b->n_bufs; ++i) {
-      const int64_t n = b->frame_offset[i + 1] - b->frame_offset[i];
-      out->stats_status[i] = (b->buf_status[i] != AFX_OK) ? b->buf_status[i] : (n > 1024 ? AFX_ERR_UNSUPPORTED : AFX_OK);
+      out->stats_status[i] = b->buf_status[i];
     }
   return AFX_OK;
 }
 
 void afx_batch_destroy(afx_batch* b) {
   if (!b) return;
+  afx_plan* const plan = b->plan;
+  struct Release { afx_plan* p; ~Release() { plan_release(p); } } release_plan_last{plan};
   hipSetDevice(b->plan->desc.device);
   if (b->stream) hipStreamSynchronize(b->stream);
 #if defined(AFX_STAMPS) && AFX_STAMPS
@@ -1205,6 +1241,7 @@ int afx_extract_batch(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint3
     afx_batch_destroy(b);
     return st;
   }
+  const int call_dtype = first_valid_dtype(bufs, n_bufs);
   struct Col { double* afx_out::*field; int width; };
   std::vector<Col> cols;
   for (const FieldDesc& d : kFields) cols.push_back(Col{d.out, d.width});
@@ -1229,7 +1266,7 @@ int afx_extract_batch(afx_plan* plan, const afx_buf* bufs, int32_t n_bufs, uint3
     part.buf_status = out->buf_status ? out->buf_status + first : nullptr;
     part.effective_length = out->effective_length ? out->effective_length + (size_t)first * 3 : nullptr;
     afx_batch* b = nullptr;
-    int st = afx_batch_create(plan, bufs + first, last - first, mask, &b);
+    int st = batch_create_typed(plan, bufs + first, last - first, mask, call_dtype, &b);
     if (st != AFX_OK) return st;
     st = afx_batch_run(b);
     if (st == AFX_OK) st = afx_batch_fetch(b, &part);

@@ -14,10 +14,6 @@
 
 #include "afx_device.h"
 
-#ifndef AFX_ABL
-#define AFX_ABL 0   // timing experiments only (outputs wrong): bit0 no LDS exchange, bit1 no table reads,
-#endif              // bit2 no descriptor epilogue, bit3 no butterflies
-
 namespace afx {
 namespace {
 
@@ -109,7 +105,6 @@ struct Xchg;
 template <>
 struct Xchg<float> {
   static __device__ __forceinline__ void run(unsigned char* plane, unsigned rd_addr, int wlane, cx<float> (&v)[16]) {
-    if (AFX_ABL & 1) return;
     float2* p = reinterpret_cast<float2*>(plane) + wlane;
     wave_lds_fence();
 #pragma unroll
@@ -126,7 +121,6 @@ struct Xchg<float> {
 template <>
 struct Xchg<double> {
   static __device__ __forceinline__ void run(unsigned char* plane, unsigned rd_addr, int wlane, cx<double> (&v)[16]) {
-    if (AFX_ABL & 1) return;
     double* p = reinterpret_cast<double*>(plane) + wlane;
     double re[16], im[16];
     wave_lds_fence();

@@ -184,8 +184,8 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
       cx<T> v[16];
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        const cx<T> w0 = (AFX_ABL & 2) ? cx<T>{(T)0.5, (T)0.25} : win[64 * r];
-        const cx<T> w1 = (AFX_ABL & 2) ? cx<T>{(T)0.125, (T)0.75} : win[64 * (r + 8)];
+        const cx<T> w0 = win[64 * r];
+        const cx<T> w1 = win[64 * (r + 8)];
         v[r] = {(T)lo[r].x * w0.re, (T)lo[r].y * w0.im};
         v[r + 8] = {(T)nxt[r].x * w1.re, (T)nxt[r].y * w1.im};
         lo[r] = nxt[r];
@@ -201,17 +201,17 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
       }
 
       // ---- P1, E1 (register transpose), T1 ----
-      if (!(AFX_ABL & 8)) dft16(v);
+      dft16(v);
       transpose_m2_into_registers(v);   // lane = 16 jh + n2, v[4 m2 + jl]
 #pragma unroll
-      for (int g = 4; g < 16; ++g) v[g] = cmul(v[g], (AFX_ABL & 2) ? cx<T>{(T)0.6, (T)0.8} : t1[g]);
+      for (int g = 4; g < 16; ++g) v[g] = cmul(v[g], t1[g]);
 
       // ---- P2 + T2 + E2 ----
 #pragma unroll
       for (int jl = 0; jl < 4; ++jl) radix4(v[jl], v[4 + jl], v[8 + jl], v[12 + jl]);
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
-        v[g] = cmul(v[g], (AFX_ABL & 2) ? cx<T>{(T)0.6, (T)0.8} : t2[64 * g]);
+        v[g] = cmul(v[g], t2[64 * g]);
 #if AFX_TABLE_BATCH
         if ((g + 1) % AFX_TABLE_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
 #endif
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
       Xchg<T>::run(plane, e2r_addr, e2w, v);
 
       // ---- P3: v[k2] = Z[lane + 64 k2] ----
-      if (!(AFX_ABL & 8)) dft16(v);
+      dft16(v);
 
       // ---- E3 + untangle + magnitude: mag[r] = |X[lane + 64 r]| ----
       T mag[MR];
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         cx<T> p{__shfl(v[15 - r].re, partner), __shfl(v[15 - r].im, partner)};
         if (lane == 0) p = v[(16 - r) & 15];
         const cx<T> z = v[r];
-        const cx<T> w = (AFX_ABL & 2) ? cx<T>{(T)0.8, (T)-0.6} : post[64 * r];
+        const cx<T> w = post[64 * r];
         const T er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
         const T orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
         const T xr = er + (w.re * orr - w.im * oi);
@@ -247,12 +247,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         }
 
         // ---- MFCC: sparse mel rows now; log + DCT once per four frames (vector.c:350-391) ----
-        if (AFX_ABL & 4) {
-          double sacc = 0.0;
-#pragma unroll
-          for (int r = 0; r < MR; ++r) sacc += (double)mag[r];
-          if (sacc == 1.2345e-300) rec[a.lay.mfcc + (lane & 7)] = sacc;
-        } else if (FEAT == kFeatC2 || (a.mask & 1u)) {
+        if (FEAT == kFeatC2 || (a.mask & 1u)) {
           // mel partial sums in the kernel's own precision (the float kernels' magnitudes carry 1e-7
           // already); the log and the DCT below are always double
           T e[16];

@@ -2,7 +2,7 @@
 // TStatistics::Calc (Statistics.cpp:12-90) as TFramedScalarData / TFramedVectorData::OnCalcStatistics
 // apply it to each series after the frame loop (SampleAnalyser.cpp:1065, 2402-2412).
 //
-// One wave per (buffer, record column).  A series of n <= 1024 frames sits in registers as
+// One wave per (buffer, record column) for series of more than 128 frames.  A series of n <= 1024 frames sits in registers as
 // x[16 lane' + i] ... (position p = R lane + reg, R = 1, 2, 4, 8 or 16 registers per lane picked
 // from n), the moments are wave reductions, the median comes from a bitonic sort of
 // order-preserving 64-bit keys (Statistics.cpp:316-413 selects element (n-1)/2 of the sorted
@@ -168,6 +168,112 @@ __device__ void series_stats(const double* col, int64_t cstride, int n, int lane
   }
 }
 
+// ---- long series (n > 1024 frames: only with the 20 s cap disabled): one wave streams the column ----
+// Three passes over the column for the moments (the same formulas as series_stats) and an exact median by a
+// most-significant-digit radix select on the order-preserving keys: eight passes of eight bits, each a 256-bin
+// histogram (in this wave's LDS slice) of the keys that match the digits chosen so far.
+__device__ void series_stats_long(const double* col, int64_t cstride, int n, int lane, unsigned* hist, double* out) {
+  const double dn = (double)n;
+  double mn = 1.0e308, mx = -1.0e308, s = 0.0, sj = 0.0, slog = 0.0, sd = 0.0;
+  for (int p = lane; p < n; p += 64) {
+    const double x = col[(int64_t)p * cstride];
+    mn = fmin(mn, x);
+    mx = fmax(mx, x);
+    s += x;
+    sj += (double)p * x;
+    slog += fast_log(fabs(x) + 1e-20);
+    if (p + 1 < n) sd += fabs(col[(int64_t)(p + 1) * cstride] - x);
+  }
+  mn = wave_min(mn);
+  mx = wave_max(mx);
+  s = wave_sum(s);
+  sj = wave_sum(sj);
+  slog = wave_sum(slog);
+  sd = wave_sum(sd);
+  const double mean = s / dn;
+  const double gmean = fast_exp(slog / dn);
+  const double cen = (s == 0.0) ? 0.0 : sj / s;
+  const int nd = n - 1;
+  const double dmean = sd / (double)nd;   // nd >= 2 here
+  double var = 0.0, sv = 0.0, dvar = 0.0;
+  for (int p = lane; p < n; p += 64) {
+    const double x = col[(int64_t)p * cstride];
+    const double t = x - mean;
+    var += t * t;
+    const double u = (double)p - cen;
+    sv += u * u * x;
+    if (p + 1 < n) {
+      const double w = fabs(col[(int64_t)(p + 1) * cstride] - x) - dmean;
+      dvar += w * w;
+    }
+  }
+  var = wave_sum(var) / dn;
+  sv = wave_sum(sv);
+  dvar = wave_sum(dvar);
+  const double spr = (s == 0.0) ? 0.0 : sv / s;
+  double sk = 0.0, ku = 0.0;
+  if (fabs(spr) > (double)1e-12f) {
+    for (int p = lane; p < n; p += 64) {
+      const double t = (col[(int64_t)p * cstride] - cen) / spr;
+      const double tt = t * t;
+      sk += tt * t;
+      ku += tt * tt;
+    }
+    sk = wave_sum(sk) / dn;
+    ku = wave_sum(ku) / dn - 3.0;
+  }
+  // median: the key of rank (n-1)/2
+  u64 prefix = 0;
+  int rank = (n - 1) / 2;
+  for (int shift = 56; shift >= 0; shift -= 8) {
+    wave_lds_fence();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) hist[4 * lane + i] = 0;
+    wave_lds_fence();
+    for (int p = lane; p < n; p += 64) {
+      const u64 k = order_key(col[(int64_t)p * cstride]);
+      const bool match = (shift == 56) || ((k >> (shift + 8)) == (prefix >> (shift + 8)));
+      if (match) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+    }
+    wave_lds_fence();
+    unsigned c[4], local = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      c[i] = hist[4 * lane + i];
+      local += c[i];
+    }
+    unsigned incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned t = __shfl_up(incl, o);
+      if (lane >= o) incl += t;
+    }
+    const unsigned base = incl - local;
+    const bool mine = (unsigned)rank >= base && (unsigned)rank < incl;
+    int digit = 0, below = 0;
+    if (mine) {
+      unsigned cum = base;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if ((unsigned)rank >= cum + c[i]) cum += c[i];
+        else { digit = 4 * lane + i; below = (int)cum; break; }
+      }
+    }
+    const int src = __ffsll((unsigned long long)__ballot(mine)) - 1;
+    digit = __shfl(digit, src);
+    below = __shfl(below, src);
+    prefix |= (u64)(unsigned)digit << shift;
+    rank -= below;
+  }
+  if (lane == 0) {
+    out[0] = mn; out[1] = mx; out[2] = key_value(prefix); out[3] = mean; out[4] = gmean; out[5] = var;
+    out[6] = cen; out[7] = spr; out[8] = sk; out[9] = ku;
+    out[10] = (mean == 0.0) ? 0.0 : gmean / mean;
+    out[11] = dmean;
+    out[12] = dvar / (double)nd;
+  }
+}
+
 // ---- short series (2 <= n <= 128 frames): one LANE per series ----
 // A wave takes 64 adjacent record columns of one buffer; frame p of all of them is one coalesced 512-byte
 // row.  The moments are plain sequential sums (the reference's own order), and the median needs no sort:
@@ -287,6 +393,8 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
 }
 
 __global__ __launch_bounds__(256) void stats_kernel(const StatsArgs a) {
+  __shared__ unsigned hist_all[4 * 256];   // radix-select histograms of the long-series path, one slice per wave
+  unsigned* const hist = hist_all + 256 * (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int64_t wave0 = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int64_t total = (int64_t)a.n_bufs * a.stride;
@@ -297,8 +405,8 @@ __global__ __launch_bounds__(256) void stats_kernel(const StatsArgs a) {
     const int64_t nn = a.frame_offset[buf + 1] - f0;
     double* const out = a.stats + w * 13;
     const double* const col = a.rec + f0 * a.stride + colidx;
-    if (nn > 1024) {   // not representable in one wave's registers: flagged, host reports AFX_ERR_UNSUPPORTED
-      if (lane < 13) out[lane] = __longlong_as_double(0x7FF8000000000000ll);
+    if (nn > 1024) {   // does not fit one wave's registers: streamed
+      series_stats_long(col, a.stride, (int)nn, lane, hist, out);
       continue;
     }
     const int n = (int)nn;

@@ -2,7 +2,9 @@
 #include "SqlitePool.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 
+#include <cstdlib>
 #include <map>
 
 namespace afec {
@@ -46,6 +48,16 @@ struct TSqliteSampleDescriptorPool::TImpl {
       throw TReadableException(std::string(pWhat) + ": " + (mpDatabase ? mApi.errmsg(mpDatabase) : "sqlite error"));
   }
   void Execute(const std::string& Sql) { Check(mApi.exec(mpDatabase, Sql.c_str(), nullptr, nullptr, nullptr), Sql.c_str()); }
+  // first column of the first row as an int (TDatabase::ExecuteScalarInt)
+  int ExecuteScalarInt(const std::string& Sql) {
+    int Value = 0;
+    auto Callback = [](void* pUser, int Count, char** ppValues, char**) -> int {
+      if (Count > 0 && ppValues[0]) *static_cast<int*>(pUser) = std::atoi(ppValues[0]);
+      return 0;
+    };
+    Check(mApi.exec(mpDatabase, Sql.c_str(), Callback, &Value, nullptr), Sql.c_str());
+    return Value;
+  }
 };
 
 TSqliteSampleDescriptorPool::TSqliteSampleDescriptorPool(const std::string& DatabasePath) : mpImpl(new TImpl) {
@@ -70,14 +82,40 @@ TSqliteSampleDescriptorPool::TSqliteSampleDescriptorPool(const std::string& Data
     Resolve(A.mpLibrary, "sqlite3_errmsg", A.errmsg);
     mpImpl->Check(A.open(DatabasePath.c_str(), &mpImpl->mpDatabase), "sqlite3_open");
     mpImpl->mSchema = LowLevelSchema();
-    // SqliteSampleDescriptorPool.cpp:1304-1352: version + assets table, in one transaction
-    std::string Ddl = "CREATE TABLE IF NOT EXISTS assets(filename TEXT PRIMARY KEY,modtime INTEGER,status TEXT";
-    for (const TColumnSpec& c : mpImpl->mSchema) Ddl += "," + c.mName + " " + c.mpSqliteType;
-    Ddl += ")";
-    mpImpl->Execute("BEGIN");
-    mpImpl->Execute("PRAGMA user_version = '2'");        // kCurrentVersion, Export/SqliteSampleDescriptorPool.h:58
-    mpImpl->Execute(Ddl);
-    mpImpl->Execute("COMMIT");
+    // TSqliteSampleDescriptorPool::InitializeDatabase (SqliteSampleDescriptorPool.cpp:1224-1358): an existing assets
+    // table is kept only at the current version; a newer database is refused, an older one is thrown away
+    constexpr int kCurrentVersion = 2;                   // Export/SqliteSampleDescriptorPool.h:58
+    bool CreateNewTables = false;
+    if (mpImpl->ExecuteScalarInt("SELECT count(name) FROM sqlite_master WHERE type='table' AND name='assets'") != 1) {
+      CreateNewTables = true;
+    } else {
+      const int DatabaseVersion = mpImpl->ExecuteScalarInt("PRAGMA user_version");
+      if (DatabaseVersion > kCurrentVersion)
+        throw TReadableException("Unknown database version: " + std::to_string(DatabaseVersion) +
+                                 ". The database maybe got created by a newer version of the crawler.");
+      if (DatabaseVersion < kCurrentVersion) {
+        CreateNewTables = true;
+        // try trashing the entire file first, drop the table as the fallback
+        A.close(mpImpl->mpDatabase);
+        mpImpl->mpDatabase = nullptr;
+        const bool DeleteSucceeded = (::unlink(DatabasePath.c_str()) == 0);
+        mpImpl->Check(A.open(DatabasePath.c_str(), &mpImpl->mpDatabase), "sqlite3_open (upgrade)");
+        if (!DeleteSucceeded) {
+          mpImpl->Execute("DROP table 'assets'");
+          mpImpl->Execute("VACUUM");
+        }
+      }
+    }
+    if (CreateNewTables) {
+      // SqliteSampleDescriptorPool.cpp:1304-1352: version + assets table, in one transaction
+      std::string Ddl = "CREATE TABLE IF NOT EXISTS assets(filename TEXT PRIMARY KEY,modtime INTEGER,status TEXT";
+      for (const TColumnSpec& c : mpImpl->mSchema) Ddl += "," + c.mName + " " + c.mpSqliteType;
+      Ddl += ")";
+      mpImpl->Execute("BEGIN");
+      mpImpl->Execute("PRAGMA user_version = '" + std::to_string(kCurrentVersion) + "'");
+      mpImpl->Execute(Ddl);
+      mpImpl->Execute("COMMIT");
+    }
   } catch (...) {
     if (mpImpl->mpDatabase) A.close(mpImpl->mpDatabase);
     dlclose(A.mpLibrary);
@@ -127,7 +165,16 @@ void TSqliteSampleDescriptorPool::InsertSample(const std::string& FileName, int 
       else if (c.mName == "file_sample_rate_R") r = I.mApi.bind_int(pStatement, Index, File.mFileSampleRate);
       else if (c.mName == "file_channel_count_R") r = I.mApi.bind_int(pStatement, Index, File.mFileChannelCount);
       else if (c.mName == "file_bit_depth_R") r = I.mApi.bind_int(pStatement, Index, File.mFileBitDepth);
-      else r = I.mApi.bind_null(pStatement, Index);      // rhythm_*: not computed by this library
+      else {
+        // a descriptor this library does not compute: a well-formed placeholder, because the reference's reader
+        // unpacks every BLOB column of a "succeeded" row (SqliteSampleDescriptorPool.cpp:1004-1014): an empty
+        // msgpack array for the vectors, 0 for the scalars
+        static const unsigned char kEmptyMsgpackArray[1] = {0x90};
+        const std::string Type = c.mpSqliteType;
+        if (Type == "BLOB") r = I.mApi.bind_blob(pStatement, Index, kEmptyMsgpackArray, 1, kSqliteTransient);
+        else if (Type == "REAL") r = I.mApi.bind_double(pStatement, Index, 0.0);
+        else r = I.mApi.bind_text(pStatement, Index, "", -1, kSqliteTransient);
+      }
       I.Check(r, c.mName.c_str());
       ++Index;
     }

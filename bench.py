@@ -115,15 +115,34 @@ def reduce_max_sum(dist, seconds, frames):
     return float(t.item()), float(f.item())
 
 
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(frames_per_worker):
     """The reference CPU path timed on this host: oracle/_ref/ref_driver (the reference's own
     objects, kind "reference") when present, else the oracle restatement (kind "port").  One
     worker process per host core, the analogue of the crawler's one-file-per-task thread pool
-    (Crawler.cpp:706-728)."""
-    cores = max(1, min(os.cpu_count() or 1, 64))   # bounded sample: <= 64 worker processes
+    (Crawler.cpp:706-728); before that one process alone, for the un-contended single-thread rate."""
+    host_cpus = os.cpu_count() or 1
+    try:
+        host_cpus_usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        host_cpus_usable = host_cpus
+    cores = max(1, min(host_cpus_usable, 256))   # bounded sample: <= 256 worker processes
+    host = {"cpu_model": cpu_model(), "os_cpu_count": host_cpus, "cpus_usable": host_cpus_usable}
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
-    t0 = time.perf_counter()
     if os.path.exists(ref) and os.access(ref, os.X_OK):
+        alone = subprocess.run([ref, "time", str(max(2000, frames_per_worker // 4)), "999"], stdout=subprocess.PIPE,
+                               stderr=subprocess.DEVNULL)
+        alone_rate = json.loads(alone.stdout.decode())["frames_per_s"] if alone.returncode == 0 else None
+        t0 = time.perf_counter()
         procs = [subprocess.Popen([ref, "time", str(frames_per_worker), str(1234 + i)],
                                   stdout=subprocess.PIPE, stderr=subprocess.DEVNULL) for i in range(cores)]
         outs = [p.communicate()[0] for p in procs]
@@ -131,18 +150,20 @@ def cpu_baseline(frames_per_worker):
         dt = time.perf_counter() - t0
         if ok:
             per = [json.loads(o.decode())["frames_per_s"] for o in outs]
-            return {"value": cores * frames_per_worker / dt, "unit": "frames/s", "cores": cores, "kind": "reference",
-                    "sample": f"{cores} processes x {frames_per_worker} frames of U(-1,1), window+FFT+magnitude+xtract_mfcc "
-                              f"via the reference's own objects (oracle/_ref/ref_driver time)",
-                    "single_thread_frames_per_s": float(np.median(per))}
+            return dict(host, **{
+                "value": cores * frames_per_worker / dt, "unit": "frames/s", "cores": cores, "kind": "reference",
+                "sample": f"{cores} processes x {frames_per_worker} frames of U(-1,1), window+FFT+magnitude+xtract_mfcc "
+                          f"via the reference's own objects (oracle/_ref/ref_driver time)",
+                "single_thread_frames_per_s": alone_rate,
+                "per_process_frames_per_s_while_all_run": float(np.median(per))})
     # port: the oracle restatement through ctypes in worker processes
     import multiprocessing as mp
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(cores) as pool:
         pool.map(_oracle_worker, [(frames_per_worker, 1234 + i) for i in range(cores)])
     dt = time.perf_counter() - t0
-    return {"value": cores * frames_per_worker / dt, "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} processes x {frames_per_worker} frames of U(-1,1), STFT+MFCC via oracle/afx_oracle.c"}
+    return dict(host, **{"value": cores * frames_per_worker / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+                         "sample": f"{cores} processes x {frames_per_worker} frames of U(-1,1), STFT+MFCC via oracle/afx_oracle.c"})
 
 
 def _oracle_worker(arg):
@@ -153,17 +174,30 @@ def _oracle_worker(arg):
     return float(Oracle().run_mfcc(x)[0, 0])
 
 
-def measured_traffic(precision, mask_name, frames):
-    """HBM bytes per launch from the committed rocprofv3 PMC profile of this kernel configuration
-    (bytes per frame x frames of this launch); None when no profile matches."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
+def kernel_profile(precision, mask_name, workload):
+    """The committed rocprofv3 profile of this configuration (profiles/kernel_profiles.json, written from
+    tools/profile_config.py runs): HBM bytes and VALU-pipe cycles per frame, the kernels of one step, and what the
+    counters say limits it.  None when the configuration was not profiled."""
+    p = os.path.join(ROOT, "profiles", "kernel_profiles.json")
     if not os.path.exists(p):
         return None
     try:
-        t = json.load(open(p)).get(f"{mask_name}_{precision}")
-        return None if t is None else t["bytes_per_frame"] * frames
+        key = workload if workload != "c2" else f"{mask_name}_{precision}"
+        return json.load(open(p)).get(key)
     except Exception:
         return None
+
+
+def secondary_rate(plan, mask, buffers, steps=5):
+    """frames/s of another descriptor set on the same synthetic PCM (reported beside the headline)."""
+    b = plan.batch(make_buffers(buffers, 777), mask)
+    for _ in range(2):
+        b.run()
+    b.sync()
+    ms = b.run_timed(steps) / steps
+    frames = b.total_frames
+    b.close()
+    return frames / (ms * 1e-3)
 
 
 def main():
@@ -220,9 +254,23 @@ def main():
         single = FRAMES_PER_BUFFER / (one.run_timed(50) / 50 * 1e-3)
         one.close()
 
+    # the descriptor set north_star names and the full spectral set as secondary numbers (16 buffers each)
+    star_rate = all_rate = None
+    if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
+        star_rate = secondary_rate(plan, star, 16)
+        all_rate = secondary_rate(plan, afx.D_ALL_LOW_LEVEL, 16)
+
     if rank == 0:
         launch_ms = ev_ms / args.steps
         achieved = bytes_per_frame * frames / (launch_ms * 1e-3) / 1e9
+        prof = kernel_profile(args.precision, args.mask, args.workload)
+        valu = None
+        if prof and prof.get("valu_cycles_per_frame"):
+            # f64 VALU ceiling of this instruction mix: 4 SIMDs x 256 CUs x clock / pipe cycles per frame
+            ceiling = 4 * 256 * prof["clock_ghz"] * 1e9 / prof["valu_cycles_per_frame"]
+            valu = {"cycles_per_frame": prof["valu_cycles_per_frame"], "instructions_per_frame": prof["valu_instructions_per_frame"],
+                    "clock_ghz": prof["clock_ghz"], "ceiling_frames_s": ceiling,
+                    "frac": frames / (launch_ms * 1e-3) / ceiling, "source": prof["source"]}
         out = {
             "metric": "audio frames/sec low-level crawl, 44.1kHz 1024-hop",
             "value": frames_all * args.steps / seconds,
@@ -249,17 +297,24 @@ def main():
                 "frames_per_gpu_per_step": frames,
                 "files_per_gpu_per_step": n_bufs,
                 "single_10k_frame_buffer_frames_per_s": single,
+                "star_descriptor_set_frames_per_s": star_rate,
+                "all_spectral_descriptors_frames_per_s": all_rate,
                 "pcm": "f32 resident in HBM" if pcm_kind == afx.PCM_F32 else "f64 (LoadSample output) resident in HBM",
                 "parallelism": f"replicas x{world} (buffers sharded, no collective)",
             },
+            # "bound": the roofline the path is priced against (a streaming scan of PCM: HBM).  What the
+            # counters say actually limits these f64 kernels is in "limiter" / "valu": the vector ALU, not HBM.
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.precision, args.mask if args.workload == "c2" else args.workload, frames),
-                "kernel": "frames_kernel",
+                "traffic": None if not prof else prof["bytes_per_frame"] * frames,
+                "kernel": prof["dominant_kernel"] if prof else None,
+                "kernels_timed": prof["kernels"] if prof else None,
+                "limiter": prof["limiter"] if prof else None,
+                "valu": valu,
                 "algorithmic_bytes_per_frame": bytes_per_frame,
                 "launch_ms": launch_ms,
             },

@@ -174,9 +174,9 @@ typedef struct {
 
 /* Per-buffer statistics (AFX_D_STATISTICS): the same fields as afx_out, each an array
  * [n_bufs][W][AFX_NUM_STATISTICS] of doubles (W = 1 for scalar series), in the order of
- * TFramedScalarData's members (SampleDescriptors.h:172-186).  Series of more than 1024 frames (only
- * possible with the 20 s cap disabled) are not reduced: their buffer gets AFX_ERR_UNSUPPORTED in
- * stats_status and NaNs in the arrays. */
+ * TFramedScalarData's members (SampleDescriptors.h:172-186).  Series of any length are reduced (those of more
+ * than 1024 frames, possible only with the 20 s cap disabled, by a streaming kernel); stats_status repeats
+ * buf_status. */
 #define AFX_NUM_STATISTICS 13
 enum {
   AFX_S_MIN = 0, AFX_S_MAX, AFX_S_MEDIAN, AFX_S_MEAN, AFX_S_GMEAN, AFX_S_VARIANCE, AFX_S_CENTROID,

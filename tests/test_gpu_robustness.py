@@ -142,3 +142,45 @@ def test_vanishing_amplitudes_flush_like_the_reference():
         _tol.check(field, got[keep], ref[keep, a:b], rtol, atol, what="vanishing ")
     assert res["spectral_flatness"][-1] == 1.0 and not res["sub_complexity"][-1].any()
     plan.close()
+
+
+def test_fetch_before_run_is_refused_and_outputs_are_validated():
+    """Workspaces are pooled: a fetch before afx_batch_run would hand back another batch's results."""
+    plan = afx.Plan()
+    x = np.random.default_rng(3).uniform(-1, 1, 2048 + 1024 * 5).astype(np.float32)
+    plan.extract([x], afx.D_ALL_LOW_LEVEL)            # leaves results in the pooled workspace
+    b = plan.batch([x], afx.D_MFCC | afx.D_STATISTICS)
+    with pytest.raises(afx.AfxError) as ei:
+        b.fetch()
+    assert ei.value.status == -1
+    with pytest.raises(afx.AfxError):
+        b.fetch_statistics()
+    b.run()
+    assert b.fetch()["mfcc"].shape == (6, 14)
+    b.close()
+    plan.close()
+
+
+def test_plan_destroyed_before_its_batch():
+    """afx_plan_destroy is deferred while batches of the plan are alive (interpreter exit order, user code)."""
+    plan = afx.Plan()
+    x = np.random.default_rng(4).uniform(-1, 1, 2048 + 1024 * 9).astype(np.float32)
+    want = plan.extract([x], afx.D_MFCC)["mfcc"].copy()
+    b = plan.batch([x], afx.D_MFCC)
+    L, handle = plan.L, plan.h
+    plan.h = None                      # keep Plan.close() from touching it again
+    L.afx_plan_destroy(handle)         # the C-ABI call, with the batch still alive
+    b.run()
+    np.testing.assert_array_equal(b.fetch()["mfcc"], want)
+    b.close()                          # the last reference frees the plan
+
+
+def test_mixed_pcm_types_in_one_call_flag_the_minority():
+    plan = afx.Plan()
+    rng = np.random.default_rng(6)
+    a = rng.uniform(-1, 1, 2048 + 1024 * 3).astype(np.float32)
+    d = rng.uniform(-1, 1, 2048 + 1024 * 2)
+    res = plan.extract([a, d, a], afx.D_MFCC)
+    assert res["buf_status"].tolist() == [0, -6, 0]
+    assert res["frame_offset"].tolist() == [0, 4, 4, 8]
+    plan.close()

@@ -70,14 +70,28 @@ def test_statistics_end_to_end_against_oracle():
     plan.close()
 
 
-def test_statistics_over_1024_frames_is_flagged():
+def test_statistics_of_series_longer_than_1024_frames():
+    """With the 20 s cap off a series has any length (C2's buffers: 10 000 frames): streamed moments and an
+    exact radix-select median, against Calc on the GPU's own series."""
     rng = np.random.default_rng(23)
-    x = rng.uniform(-1, 1, 2048 + 1024 * 1100).astype(np.float32)
+    lens = [2048 + 1024 * 1024, 2048 + 1024 * 1100, 5000, 2048 + 1024 * 9999]
+    bufs = [(rng.uniform(-1, 1, n) * np.linspace(1.0, 0.2, n)).astype(np.float32) for n in lens]
+    bufs[1][200000:300000] = 0.0     # a stretch of identical values (ties in the radix select)
     plan = afx.Plan(max_analysis_ms=0)
-    b = plan.batch([x, x[:5000]], afx.D_SPECTRAL_RMS | afx.D_STATISTICS)
+    b = plan.batch(bufs, afx.D_MFCC | afx.D_SPECTRAL_RMS | afx.D_SPECTRAL_CENTROID | afx.D_STATISTICS)
     b.run()
+    series = b.fetch()
     st = b.fetch_statistics()
-    assert st["stats_status"].tolist() == [-2, 0]
-    assert np.all(np.isnan(st["spectral_rms"][0])) and np.all(np.isfinite(st["spectral_rms"][1]))
+    assert st["stats_status"].tolist() == [0, 0, 0, 0]
+    off = series["frame_offset"]
+    for name, width in (("mfcc", 14), ("spectral_rms", 1), ("spectral_centroid", 1)):
+        vals = series[name].reshape(series[name].shape[0], -1)
+        got = st[name].reshape(len(bufs), width, 13)
+        for i in range(len(bufs)):
+            for w in range(width):
+                want = ref_stats(vals[off[i]:off[i + 1], w])
+                assert got[i, w, 2] == want[2], (name, i, w, "median", got[i, w, 2], want[2])   # an element of the series
+                err = np.abs(got[i, w] - want)
+                assert np.all(err <= RTOL * np.abs(want) + ATOL), (name, i, w, got[i, w], want)
     b.close()
     plan.close()

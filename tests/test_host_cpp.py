@@ -173,9 +173,56 @@ def test_descriptor_database_is_the_references_schema(tmp_path):
     assert msgpack.unpackb(ok["spectral_centroid_VR"]) == column_values(5, 0, 1).tolist()
     assert msgpack.unpackb(ok["cepstrum_bands_VVR"]) == column_values(5, 14, 3).tolist()
     assert msgpack.unpackb(ok["cepstrum_bands_mean_VR"]) == [b / 4.0 for b in range(14)]
-    assert ok["rhythm_final_tempo_R"] is None and ok["rhythm_complex_onsets_VR"] is None     # not computed here
+    # descriptors this library does not compute (the rhythm tracker): well-formed placeholders, read back the way the
+    # reference reads a "succeeded" row (every BLOB through msgpack, SqliteSampleDescriptorPool.cpp:1004-1014)
+    assert ok["rhythm_final_tempo_R"] == 0.0 and msgpack.unpackb(ok["rhythm_complex_onsets_VR"]) == []
+    for name, kind in full_schema():
+        if kind == "BLOB":
+            assert isinstance(msgpack.unpackb(ok[name]), list), name
+        elif kind == "REAL":
+            assert isinstance(ok[name], float), name
     bad = con.execute("SELECT * FROM assets WHERE filename = 'Kicks/broken.wav'").fetchone()
     assert all(bad[k] is None for k in bad.keys() if k not in ("filename", "modtime", "status"))
+    con.close()
+
+
+def test_descriptor_database_version_rules(tmp_path):
+    """TSqliteSampleDescriptorPool::InitializeDatabase (SqliteSampleDescriptorPool.cpp:1224-1300): a newer database is
+    refused, an older one is thrown away and recreated, a current one is kept."""
+    import sqlite3
+
+    build()
+    # newer: refused, untouched
+    newer = str(tmp_path / "newer.db")
+    con = sqlite3.connect(newer)
+    con.execute("CREATE TABLE assets(filename TEXT PRIMARY KEY, x REAL)")
+    con.execute("PRAGMA user_version = 3")
+    con.commit(); con.close()
+    out = subprocess.run([BIN, "sqlite", newer], capture_output=True, text=True)
+    assert out.returncode != 0 and "Unknown database version" in (out.stdout + out.stderr)
+    con = sqlite3.connect(newer)
+    assert con.execute("PRAGMA user_version").fetchone()[0] == 3
+    assert [r[1] for r in con.execute("PRAGMA table_info(assets)")] == ["filename", "x"]
+    con.close()
+    # older: dropped and recreated with the current schema
+    older = str(tmp_path / "older.db")
+    con = sqlite3.connect(older)
+    con.execute("CREATE TABLE assets(filename TEXT PRIMARY KEY, old_column REAL)")
+    con.execute("INSERT INTO assets VALUES ('stale.wav', 1.0)")
+    con.execute("PRAGMA user_version = 1")
+    con.commit(); con.close()
+    out = subprocess.run([BIN, "sqlite", older], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    con = sqlite3.connect(older)
+    assert con.execute("PRAGMA user_version").fetchone()[0] == 2
+    assert [(r[1], r[2]) for r in con.execute("PRAGMA table_info(assets)")] == full_schema()
+    assert con.execute("SELECT count(*) FROM assets WHERE filename = 'stale.wav'").fetchone()[0] == 0
+    con.close()
+    # current: rows of an earlier run survive a second run
+    out = subprocess.run([BIN, "sqlite", older], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    con = sqlite3.connect(older)
+    assert con.execute("SELECT count(*) FROM assets").fetchone()[0] == 2
     con.close()
 
 

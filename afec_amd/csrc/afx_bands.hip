@@ -10,11 +10,14 @@
 //
 //   rms, flatness(dB), flux      masked per-band sums, reduced 16 bands at a time (wave_sum16)
 //   complexity                   band maximum (wave_max16) -> threshold -> strict local maxima
-//   contrast                     one 1024-slot bitonic sort in registers on the 32-bit key
-//                                (band << 27 | float bits >> 4); after the sort every band
-//                                occupies a fixed range of positions, so "mean of the n lowest /
-//                                highest" (std::sort + two loops, SA:2200-2228) is a sum over
-//                                fixed position ranges of the LDS-staged sorted values
+//   contrast                     "mean of the n lowest / highest bins of the band" (std::sort + two loops,
+//                                SA:2200-2228) as an exact selection: one 1024-slot bitonic sort in registers
+//                                on the 32-bit key (band << 27 | float bits >> 4) only finds, per band, the
+//                                key at the cut; the sums are then taken over the ORIGINAL doubles of the bins
+//                                whose key lies on the right side of the cut.  Bins whose keys tie with the
+//                                cut's (values equal to 19 mantissa bits) are all on one side in the common
+//                                case; when the cut goes through such a tie class it is resolved exactly on
+//                                the doubles (exact_cut_sum)
 
 #include <hip/hip_runtime.h>
 
@@ -30,26 +33,26 @@ constexpr int kSubStart[kNumSub + 1] = {1, 3, 7, 13, 23, 35, 50, 67, 90, 119, 16
 constexpr int kSubNeigh[kNumSub] = {1, 1, 1, 3, 3, 4, 5, 6, 8, 12, 18, 28, 44, 86};
 constexpr int kRows = 12;  // bins 0..767
 
-constexpr bool sub_touches(int b, int r) { return kSubStart[b] <= 64 * r + 63 && kSubStart[b + 1] - 1 >= 64 * r; }
+__attribute__((always_inline)) constexpr bool sub_touches(int b, int r) { return kSubStart[b] <= 64 * r + 63 && kSubStart[b + 1] - 1 >= 64 * r; }
 // position range of band b in the sorted array (bands are sorted by id first)
-constexpr int sub_pos0(int b) { return kSubStart[b] - 1; }
-constexpr bool pos_touches(int lo, int hi, int lane_lo) { return lo <= lane_lo + 15 && hi - 1 >= lane_lo; }
+__attribute__((always_inline)) constexpr int sub_pos0(int b) { return kSubStart[b] - 1; }
+__attribute__((always_inline)) constexpr bool pos_touches(int lo, int hi, int lane_lo) { return lo <= lane_lo + 15 && hi - 1 >= lane_lo; }
 
 __device__ __forceinline__ bool in_band(int b, int r, int lane) {
   const int k = 64 * r + lane;
   return k >= kSubStart[b] && k < kSubStart[b + 1];
 }
 // does band b cover every bin of row r?
-constexpr bool sub_covers(int b, int r) { return kSubStart[b] <= 64 * r && kSubStart[b + 1] - 1 >= 64 * r + 63; }
+__attribute__((always_inline)) constexpr bool sub_covers(int b, int r) { return kSubStart[b] <= 64 * r && kSubStart[b + 1] - 1 >= 64 * r + 63; }
 // (band, row) pairs that touch, in band-major order
-constexpr int sub_pair_count() {
+__attribute__((always_inline)) constexpr int sub_pair_count() {
   int n = 0;
   for (int b = 0; b < kNumSub; ++b)
     for (int r = 0; r < kRows; ++r) n += sub_touches(b, r) ? 1 : 0;
   return n;
 }
 constexpr int kSubPairs = sub_pair_count();   // 25
-constexpr int sub_pair_index(int b, int r) {
+__attribute__((always_inline)) constexpr int sub_pair_index(int b, int r) {
   int n = 0;
   for (int bb = 0; bb < kNumSub; ++bb)
     for (int rr = 0; rr < kRows; ++rr) {
@@ -160,14 +163,85 @@ __device__ __forceinline__ void sort_level(u32 (&key)[16], int lane) {
   if constexpr (K >= 4) merge_tail<K, K / 4>(key, lane);
 }
 
+// sort key of a magnitude inside band b: band << 27 | float bits >> 4 (rounded): 19 mantissa bits order the values
+__device__ __forceinline__ u32 sort_key(int band, double v) {
+  return ((u32)band << 27) | ((__float_as_uint((float)fabs(v)) + 8u) >> 4);
+}
+
+// Sum of the take smallest (valley) or largest (peak) magnitudes of band b when the cut falls inside a class of
+// bins with equal sort keys: the bins strictly beyond the cut key are summed as they are, the tie class is
+// resolved on the doubles themselves (all equal -> a multiple of the value; else smallest / largest first, a value
+// at a time).  Wave-uniform b; x: this lane's magnitudes.  Rare (and cheap for silence: every bin is 0).
+template <bool VALLEY>
+__device__ __noinline__ double exact_cut_sum(const double* cur, int b, u32 cut_key, int lane) {
+  // b is wave-uniform: select chains on the scalar unit instead of run-time indexed tables (which would live in
+  // scratch).  The band's bins are re-read from the spectrum (cache-resident) in rolled loops: this path must not
+  // cost the main loop registers.
+  int start = 0, end = 0, take = 1;
+#pragma unroll
+  for (int i = 0; i < kNumSub; ++i) {
+    start = (b == i) ? kSubStart[i] : start;
+    end = (b == i) ? kSubStart[i + 1] : end;
+    take = (b == i) ? kSubNeigh[i] : take;
+  }
+  const int r0 = start >> 6, r1 = (end - 1) >> 6;
+  double strict = 0.0, tlo = __builtin_huge_val(), thi = -__builtin_huge_val();
+  int n_strict = 0;
+#pragma unroll 1
+  for (int r = r0; r <= r1; ++r) {
+    const int k = 64 * r + lane;
+    const bool inb = k >= start && k < end;
+    const double xv = cur[k];
+    const u32 kx = sort_key(b, xv);
+    const bool beyond = inb && (VALLEY ? kx < cut_key : kx > cut_key);
+    const bool tie = inb && kx == cut_key;
+    strict += beyond ? xv : 0.0;
+    n_strict += __popcll(__ballot(beyond));
+    tlo = tie ? fmin(tlo, xv) : tlo;
+    thi = tie ? fmax(thi, xv) : thi;
+  }
+  strict = wave_sum(strict);
+  tlo = wave_min(tlo);
+  thi = wave_max(thi);
+  int need = take - n_strict;          // >= 1
+  if (tlo == thi) return strict + (double)need * tlo;
+  // distinct values inside the tie class: take them in order; everything up to `last` is already taken
+  double tsum = 0.0, last = VALLEY ? -__builtin_huge_val() : __builtin_huge_val();
+  while (need > 0) {                   // wave-uniform
+    double v = VALLEY ? __builtin_huge_val() : -__builtin_huge_val();
+#pragma unroll 1
+    for (int r = r0; r <= r1; ++r) {
+      const int k = 64 * r + lane;
+      const double xv = cur[k];
+      const bool left = k >= start && k < end && sort_key(b, xv) == cut_key && (VALLEY ? xv > last : xv < last);
+      v = left ? (VALLEY ? fmin(v, xv) : fmax(v, xv)) : v;
+    }
+    v = VALLEY ? wave_min(v) : wave_max(v);
+    int c = 0;
+#pragma unroll 1
+    for (int r = r0; r <= r1; ++r) {
+      const int k = 64 * r + lane;
+      const double xv = cur[k];
+      c += __popcll(__ballot(k >= start && k < end && xv == v && sort_key(b, xv) == cut_key));
+    }
+    const int t = c < need ? c : need;
+    tsum += (double)t * v;
+    need -= t;
+    last = v;
+  }
+  return strict + tsum;
+}
+
 __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int stride = gridDim.x * 4;
   __shared__ double s_thr[4][16];
-  __shared__ float s_sorted[4][1024];
+  __shared__ u32 s_sorted[4][1024];
+  __shared__ u32 s_cut[4][32];
   double* const thr = s_thr[threadIdx.x >> 6];
-  float* const sorted = s_sorted[threadIdx.x >> 6];
+  u32* const sorted = s_sorted[threadIdx.x >> 6];
+  u32* const cut = s_cut[threadIdx.x >> 6];      // [0..15] valley cut key per band, [16..31] peak cut key
 
   // lane-only facts, once per wave: membership masks of the (band, row) pairs, the band of each of the
   // lane's bins, the analysis-range masks of the first and last row
@@ -286,43 +360,60 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
 #pragma unroll
     for (int i = 0; i < kNumSub; ++i) cnt = (((lane_v >> 2) & 15) == i) ? peaks[i] : cnt;
 
-    // ---- contrast: sort (band, value) keys, then fixed position ranges ----
-    // key = band << 27 | float bits >> 4 (rounded): 19 mantissa bits order the values, and the sums
-    // below are rebuilt from the keys (relative error <= 2^-20 per element, far inside the 1e-4 bar)
+    // ---- contrast: sort (band, value) keys to find the key at each band's two cuts, then exact sums ----
     u32 key[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      if (r < kRows) {
-        const u32 bits = __float_as_uint((float)fabs(x[r]));
-        key[r] = ((u32)bid[r] << 27) | ((bits + 8u) >> 4);
-      } else {
-        key[r] = 0x7FFFFFFFu;
-      }
-    }
+    for (int r = 0; r < 16; ++r) key[r] = (r < kRows) ? sort_key(bid[r], x[r]) : 0x7FFFFFFFu;
     sort_level<1024>(key, lane_v);
-    // sorted position p = 16 lane + i; stage the values in LDS in position order
+    // sorted position p = 16 lane + i; band b sits at [pos0, pos0 + n): the nn lowest end at pos0 + nn - 1, the nn
+    // highest start at pos0 + n - nn
     wave_lds_fence();
 #pragma unroll
-    for (int i = 0; i < 16; ++i) sorted[16 * lane_v + i] = __uint_as_float((key[i] & 0x07FFFFFFu) << 4);
+    for (int i = 0; i < 16; ++i) sorted[16 * lane_v + i] = key[i];
     wave_lds_fence();
-    // band b sits at [pos0, pos0 + n): valley = first nn, peak = last nn (nn <= 86 -> two passes of 64 lanes).
-    double valley_acc[16], peak_acc[16];
+    mask64 ties_v, ties_p;   // bands whose cut goes through a class of equal keys
+    {
+      const int bl = lane_v & 15;
+      int pv = 0, pp = 1;
 #pragma unroll
-    for (int b = 0; b < 16; ++b) {
-      valley_acc[b] = 0.0;
-      peak_acc[b] = 0.0;
-      if (b < kNumSub) {
-        const int lo = sub_pos0(b), n = kSubN[b], nn = kSubNeigh[b];
-#pragma unroll
-        for (int t0 = 0; t0 < nn; t0 += 64) {
-          const int t = t0 + lane_v;
-          valley_acc[b] += (t < nn) ? (double)sorted[lo + (t < nn ? t : 0)] : 0.0;
-          peak_acc[b] += (t < nn) ? (double)sorted[lo + n - nn + (t < nn ? t : 0)] : 0.0;
-        }
+      for (int i = 0; i < kNumSub; ++i) {
+        pv = (bl == i) ? sub_pos0(i) + kSubNeigh[i] - 1 : pv;
+        pp = (bl == i) ? sub_pos0(i) + kSubN[i] - kSubNeigh[i] : pp;
       }
+      const bool band_lane = lane_v < kNumSub;
+      const u32 kv = sorted[pv], kv_next = sorted[pv + 1], kp = sorted[pp], kp_prev = sorted[pp - 1];
+      // a bin outside every band (bid 15) meets cut keys 0 / ~0: never below the one, never above the other
+      if (lane_v < 16) {
+        cut[lane_v] = band_lane ? kv : 0u;
+        cut[16 + lane_v] = band_lane ? kp : 0xFFFFFFFFu;
+      }
+      // the valley's cut goes through a tie class when the bin right after it has the same key (nn < n always);
+      // the peak's when the bin right before it has
+      ties_v = __ballot(band_lane && kv_next == kv);
+      ties_p = __ballot(band_lane && kp_prev == kp);
     }
-    const double vsum = wave_sum16(valley_acc, lane_v);
-    const double psum = wave_sum16(peak_acc, lane_v);
+    wave_lds_fence();
+    double vsum, psum;
+    {
+      double xs[kRows];
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) xs[r] = (sort_key(bid[r], x[r]) <= cut[bid[r]]) ? x[r] : 0.0;
+      vsum = band_sum([&](int r) { return xs[r]; }, bm, lane_v);
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) xs[r] = (sort_key(bid[r], x[r]) >= cut[16 + bid[r]]) ? x[r] : 0.0;
+      psum = band_sum([&](int r) { return xs[r]; }, bm, lane_v);
+    }
+    // cuts inside a tie class: exact resolution, band by band (wave-uniform loops; rare)
+    for (mask64 m = ties_v; m; m &= m - 1) {
+      const int bb = __ffsll((unsigned long long)m) - 1;
+      const double sv = exact_cut_sum<true>(cur, bb, cut[bb], lane_v);
+      vsum = (((lane_v >> 2) & 15) == bb) ? sv : vsum;
+    }
+    for (mask64 m = ties_p; m; m &= m - 1) {
+      const int bb = __ffsll((unsigned long long)m) - 1;
+      const double sp = exact_cut_sum<false>(cur, bb, cut[16 + bb], lane_v);
+      psum = (((lane_v >> 2) & 15) == bb) ? sp : psum;
+    }
 
     // ---- per-band results: every lane_v finishes the band (lane_v >> 2) & 15 ----
     const int b = (lane_v >> 2) & 15;

@@ -114,6 +114,13 @@ __device__ __forceinline__ double wave_max(double v) {
   v = fmax(v, dpp_mov<kDppMirror>(v));
   return fmax(fmax(read_lane<0>(v), read_lane<16>(v)), fmax(read_lane<32>(v), read_lane<48>(v)));
 }
+__device__ __forceinline__ double wave_min(double v) {
+  v = fmin(v, dpp_mov<kDppXor1>(v));
+  v = fmin(v, dpp_mov<kDppXor2>(v));
+  v = fmin(v, dpp_mov<kDppHalfMirror>(v));
+  v = fmin(v, dpp_mov<kDppMirror>(v));
+  return fmin(fmin(read_lane<0>(v), read_lane<16>(v)), fmin(read_lane<32>(v), read_lane<48>(v)));
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

@@ -75,16 +75,6 @@ __device__ __forceinline__ double key_value(u64 k) {
   return __longlong_as_double((long long)b);
 }
 
-__device__ __forceinline__ double wave_min(double v) {
-  v = fmin(v, dpp_mov<kDppXor1>(v));
-  v = fmin(v, dpp_mov<kDppXor2>(v));
-  v = fmin(v, dpp_mov<kDppHalfMirror>(v));
-  v = fmin(v, dpp_mov<kDppMirror>(v));
-  v = fmin(v, __shfl_xor(v, 16));
-  v = fmin(v, __shfl_xor(v, 32));
-  return v;
-}
-
 // statistics of one series held as x[reg] = series[R lane + reg]; n >= 2
 template <int R>
 __device__ void series_stats(const double* col, int64_t cstride, int n, int lane, double* out) {

@@ -52,7 +52,6 @@ __device__ __forceinline__ void load16(const double* p, double (&x)[16]) {
 }
 
 using mask64 = unsigned long long;
-__device__ __forceinline__ double wave_min(double v) { return -wave_max(-v); }
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));

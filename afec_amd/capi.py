@@ -55,7 +55,7 @@ EXPORTS = [
     "afx_extract_batch", "afx_batch_create", "afx_batch_total_frames", "afx_batch_run",
     "afx_batch_sync", "afx_batch_run_timed", "afx_batch_fetch", "afx_batch_fetch_statistics", "afx_batch_destroy",
     "afx_algorithmic_bytes_per_frame", "afx_batch_create_from_raw", "afx_batch_fetch_samples",
-    "afx_host_alloc", "afx_host_free",
+    "afx_host_alloc", "afx_host_free", "afx_batch_record_layout", "afx_batch_fetch_records",
 ]
 RAW_I16, RAW_I24, RAW_F32 = 0, 1, 2
 

@@ -804,6 +804,17 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   return AFX_OK;
 }
 
+// bytes per sample of the decoded PCM formats (0: unknown format)
+int raw_bytes_per_sample(int format) {
+  switch (format) {
+    case AFX_RAW_I16: return 2;
+    case AFX_RAW_I24: return 3;
+    case AFX_RAW_F32: case AFX_RAW_I32: return 4;
+    case AFX_RAW_F64: return 8;
+    default: return 0;
+  }
+}
+
 // which of the two statistics kernels the batch needs (afx_stats.hip)
 void stats_regimes(const afx_batch* b, afx::StatsArgs* sa) {
   sa->small_rows = 0;
@@ -890,7 +901,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
   int64_t raw_bytes = 0;
   for (int i = 0; i < n_bufs; ++i) {
     const afx_raw& r = raws[i];
-    const int bps = r.format == AFX_RAW_I16 ? 2 : (r.format == AFX_RAW_I24 ? 3 : (r.format == AFX_RAW_F32 ? 4 : 0));
+    const int bps = raw_bytes_per_sample(r.format);
     // SampleAnalyser.cpp:472-482: 1..8 channels, non-empty; resampling (sample_rate != plan rate,
     // SampleAnalyser.cpp:563-607) is not part of this front end
     const bool good = bps && r.data && r.n_frames > 0 && r.n_frames < 0x7FFFFFFF && r.channels >= 1 && r.channels <= 8 &&
@@ -916,12 +927,26 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     if ((e = ws_reserve(ws->scan, scan.size() * sizeof(afx::LoadScan))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(scan)"));
     if ((e = ws_reserve(ws->partial, (size_t)n_bufs * afx::load_scan_blocks_per_file(n_bufs) * 16)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(partial)"));
     d_raw = (unsigned char*)ws->raw.p; d_files = (afx::LoadFile*)ws->files.p; d_scan = (afx::LoadScan*)ws->scan.p;
-    for (int i = 0; i < n_bufs; ++i)
+    // Files that lie back to back in host memory, each starting at the next 16-byte boundary (a pipeline's staging
+    // buffer), have the layout of the device arena: one transfer moves them all.  Otherwise one transfer per file
+    // (each costs ~10 us of runtime overhead, which dominates for thousands of short files).
+    bool contiguous = true;
+    const char* base = nullptr;
+    for (int i = 0; i < n_bufs && contiguous; ++i)
       if (status[i] == AFX_OK) {
-        const int bps = raws[i].format == AFX_RAW_I16 ? 2 : (raws[i].format == AFX_RAW_I24 ? 3 : 4);
-        if ((e = hipMemcpyAsync(d_raw + files[i].raw_off, raws[i].data, (size_t)raws[i].n_frames * raws[i].channels * bps,
-                                hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
+        if (!base) base = (const char*)raws[i].data - files[i].raw_off;
+        contiguous = ((const char*)raws[i].data == base + files[i].raw_off);
       }
+    if (contiguous && base) {
+      if ((e = hipMemcpyAsync(d_raw, base, (size_t)raw_bytes, hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
+    } else {
+      for (int i = 0; i < n_bufs; ++i)
+        if (status[i] == AFX_OK) {
+          const int bps = raw_bytes_per_sample(raws[i].format);
+          if ((e = hipMemcpyAsync(d_raw + files[i].raw_off, raws[i].data, (size_t)raws[i].n_frames * raws[i].channels * bps,
+                                  hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
+        }
+    }
     if ((e = hipMemcpyAsync(d_files, files.data(), files.size() * sizeof(afx::LoadFile), hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(files)"));
     // -48 dB of full scale (MSilenceThresholdDb, SampleAnalyser.cpp:51, 648-649)
     const double silence_floor = 32768.0 * std::exp(-48.0 * (std::log(10.0) / 20.0));
@@ -1125,7 +1150,9 @@ int afx_batch_fetch(afx_batch* b, afx_out* out) {
   for (const Field& f : fields)
     if (f.dst && f.off < 0) return fail(AFX_ERR_INVALID_ARG, "output requested that is not in the batch mask");
   if (out->magnitude && !(b->mask & AFX_D_MAGNITUDE)) return fail(AFX_ERR_INVALID_ARG, "magnitude not in the batch mask");
-  if (l.stride > 0) {
+  bool any_series = false;
+  for (const Field& f : fields) any_series = any_series || f.dst != nullptr;
+  if (l.stride > 0 && any_series) {
     std::vector<double> rec((size_t)F * l.stride);
     HIP_TRY(hipMemcpy(rec.data(), b->d_rec, rec.size() * sizeof(double), hipMemcpyDeviceToHost));
     for (const Field& f : fields) {
@@ -1163,6 +1190,41 @@ int afx_batch_fetch_statistics(afx_batch* b, afx_stats_out* out) {
     for (int32_t i = 0; i < b->n_bufs; ++i) {
       out->stats_status[i] = b->buf_status[i];
     }
+  return AFX_OK;
+}
+
+int afx_batch_record_layout(const afx_batch* b, int32_t* stride, int32_t* offsets, int32_t* widths) {
+  if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
+  static_assert(sizeof(kFields) / sizeof(kFields[0]) == AFX_NUM_SERIES, "AFX_NUM_SERIES out of date");
+  if (stride) *stride = b->lay.stride;
+  int i = 0;
+  for (const FieldDesc& d : kFields) {
+    if (offsets) offsets[i] = b->lay.*(d.off);
+    if (widths) widths[i] = d.width;
+    ++i;
+  }
+  return AFX_OK;
+}
+
+int afx_batch_fetch_records(afx_batch* b, double* records, double* statistics, int64_t* frame_offset, int32_t* buf_status,
+                            double* effective_length) {
+  if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
+  if (!b->ran) return fail(AFX_ERR_INVALID_ARG, "afx_batch_fetch_records before afx_batch_run");
+  if (statistics && !b->d_stats && b->n_bufs > 0) return fail(AFX_ERR_INVALID_ARG, "AFX_D_STATISTICS was not in the batch mask");
+  HIP_TRY(hipSetDevice(b->plan->desc.device));
+  const size_t rec_bytes = (size_t)b->total_frames * b->lay.stride * sizeof(double);
+  const size_t stat_bytes = (size_t)b->n_bufs * b->lay.stride * 13 * sizeof(double);
+  if (records && rec_bytes) HIP_TRY(hipMemcpyAsync(records, b->d_rec, rec_bytes, hipMemcpyDeviceToHost, b->stream));
+  if (statistics && stat_bytes) HIP_TRY(hipMemcpyAsync(statistics, b->d_stats, stat_bytes, hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  if (frame_offset) std::memcpy(frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t));
+  if (buf_status) std::memcpy(buf_status, b->buf_status.data(), b->buf_status.size() * sizeof(int32_t));
+  if (effective_length) {
+    afx_out tmp = {};
+    tmp.effective_length = effective_length;
+    const int st = afx_batch_fetch(b, &tmp);
+    if (st != AFX_OK) return st;
+  }
   return AFX_OK;
 }
 

@@ -24,7 +24,12 @@ __device__ __forceinline__ float to_16bit_float(const unsigned char* raw, int fo
     const int v = (int)(((unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)b[2] << 16)) << 8);
     return (float)((double)v * 32768.0 / 2147483648.0);
   }
-  const double d = (double)reinterpret_cast<const float*>(raw)[idx] * 32768.0;        // :529-533
+  if (format == 3) {                                                                  // :514-518 (32-bit signed)
+    const float v = (float)((double)reinterpret_cast<const int*>(raw)[idx] * 32768.0 / 2147483648.0);
+    return fmaxf(-32768.0f, fminf(32767.0f, v));
+  }
+  // normalised floats, 32 or 64 bit (S0To1FloatTo16BitFloat takes a double)                 :529-533
+  const double d = (format == 4 ? reinterpret_cast<const double*>(raw)[idx] : (double)reinterpret_cast<const float*>(raw)[idx]) * 32768.0;
   return (float)(d < -32768.0 ? -32768.0 : (d > 32767.0 ? 32767.0 : d));
 }
 

@@ -1,0 +1,351 @@
+// afec_amd/host/Crawler.cpp -- see Crawler.h.
+#include "Crawler.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
+
+#include "../../include/afx.h"
+#include "SqlitePool.h"
+#include "WaveFile.h"
+
+namespace afec {
+
+namespace {
+
+double Now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// page-locked host memory (afx_host_alloc), grown on demand
+struct TPinned {
+  void* mp = nullptr;
+  size_t mBytes = 0;
+  ~TPinned() { afx_host_free(mp); }
+  void Reserve(size_t Bytes) {
+    if (Bytes <= mBytes) return;
+    afx_host_free(mp);
+    mBytes = Bytes + Bytes / 4;
+    mp = afx_host_alloc((int64_t)mBytes);
+    if (!mp) { mBytes = 0; throw TReadableException("page-locked host memory exhausted"); }
+  }
+};
+
+// page-locking memory costs milliseconds per allocation: result buffers are recycled between the workers (which fill
+// them) and the writer (which hands them back)
+class TPinnedPool {
+public:
+  std::unique_ptr<TPinned> Acquire(size_t Bytes) {
+    std::unique_ptr<TPinned> p;
+    {
+      std::lock_guard<std::mutex> Lock(mMutex);
+      // the smallest free buffer that is large enough, else the largest one (it is grown)
+      size_t Best = mFree.size();
+      for (size_t i = 0; i < mFree.size(); ++i) {
+        const bool Fits = mFree[i]->mBytes >= Bytes;
+        if (Best == mFree.size()) Best = i;
+        else {
+          const bool BestFits = mFree[Best]->mBytes >= Bytes;
+          if ((Fits && (!BestFits || mFree[i]->mBytes < mFree[Best]->mBytes)) || (!Fits && !BestFits && mFree[i]->mBytes > mFree[Best]->mBytes)) Best = i;
+        }
+      }
+      if (Best < mFree.size()) {
+        p = std::move(mFree[Best]);
+        mFree.erase(mFree.begin() + (long)Best);
+      }
+    }
+    if (!p) p.reset(new TPinned);
+    p->Reserve(Bytes);
+    return p;
+  }
+  void Release(std::unique_ptr<TPinned> p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> Lock(mMutex);
+    mFree.push_back(std::move(p));
+  }
+
+private:
+  std::mutex mMutex;
+  std::vector<std::unique_ptr<TPinned>> mFree;
+};
+
+// what a worker hands to the writer: one analysed batch (its result buffers travel with it)
+struct TFinishedBatch {
+  std::vector<const TCrawlFile*> mFiles;
+  std::vector<TFileProperties> mProperties;
+  std::vector<std::string> mFailed;          // non-empty: the file is a failed sample with this reason
+  std::vector<int> mBatchIndex;              // file -> index inside mResults, -1 for files that never reached the GPU
+  TRecordBatch mResults;
+  std::unique_ptr<TPinned> mpRecords, mpStatistics;
+};
+
+class TBoundedQueue {
+public:
+  explicit TBoundedQueue(size_t Capacity) : mCapacity(Capacity) {}
+  void Push(std::unique_ptr<TFinishedBatch> p) {
+    std::unique_lock<std::mutex> Lock(mMutex);
+    mNotFull.wait(Lock, [&] { return mItems.size() < mCapacity; });
+    mItems.push_back(std::move(p));
+    mNotEmpty.notify_one();
+  }
+  // nullptr once Close() was called and the queue has drained
+  std::unique_ptr<TFinishedBatch> Pop() {
+    std::unique_lock<std::mutex> Lock(mMutex);
+    mNotEmpty.wait(Lock, [&] { return !mItems.empty() || mClosed; });
+    if (mItems.empty()) return nullptr;
+    std::unique_ptr<TFinishedBatch> p = std::move(mItems.front());
+    mItems.pop_front();
+    mNotFull.notify_one();
+    return p;
+  }
+  void Close() {
+    std::lock_guard<std::mutex> Lock(mMutex);
+    mClosed = true;
+    mNotEmpty.notify_all();
+  }
+
+private:
+  std::mutex mMutex;
+  std::condition_variable mNotFull, mNotEmpty;
+  std::deque<std::unique_ptr<TFinishedBatch>> mItems;
+  size_t mCapacity;
+  bool mClosed = false;
+};
+
+}  // namespace
+
+TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCrawlOptions& Options) {
+  const int G = (int)Options.mDevices.size();
+  if (G < 1) throw TReadableException("CrawlWaveFiles: no device given");
+  const int W = Options.mWorkersPerDevice < 1 ? 1 : Options.mWorkersPerDevice;
+  const int FilesPerBatch = Options.mFilesPerBatch < 1 ? 1 : Options.mFilesPerBatch;
+
+  // one analyser (plan) per device, shared by that device's workers like the reference's const analyser
+  std::vector<std::unique_ptr<TSampleAnalyser>> Analysers;
+  for (int d = 0; d < G; ++d)
+    Analysers.emplace_back(new TSampleAnalyser(Options.mSampleRate, Options.mFftFrameSize, Options.mHopFrameSize, Options.mDevices[d]));
+  std::unique_ptr<TSqliteSampleDescriptorPool> pPool;
+  if (!Options.mDatabasePath.empty()) pPool.reset(new TSqliteSampleDescriptorPool(Options.mDatabasePath));
+
+  // shards: file i -> device i mod G, in crawl order
+  std::vector<std::vector<const TCrawlFile*>> Shard((size_t)G);
+  for (size_t i = 0; i < Files.size(); ++i) Shard[(size_t)ShardOfFile((int64_t)i, G)].push_back(&Files[i]);
+  std::vector<std::atomic<size_t>> Cursor((size_t)G);
+  for (auto& c : Cursor) c = 0;
+
+  TCrawlStatistics Total;
+  Total.mFilesPerDevice.assign((size_t)G, 0);
+  double PhaseSeconds[2] = {0, 0};   // summed over workers: parse + staging copy, GPU round trip
+  std::mutex StatMutex;
+  TBoundedQueue Queue((size_t)(2 * G * W));
+  TPinnedPool Pool;
+  std::atomic<bool> Abort(false);
+  std::string FirstError;
+
+  auto Worker = [&](int d) {
+    try {
+      const TSampleAnalyser& Analyser = *Analysers[(size_t)d];
+      TPinned Staging;
+      std::vector<std::unique_ptr<TWaveFile>> Waves;
+      std::vector<std::vector<unsigned char>> Widened;
+      for (;;) {
+        if (Abort) return;
+        const size_t Begin = Cursor[(size_t)d].fetch_add((size_t)FilesPerBatch);
+        if (Begin >= Shard[(size_t)d].size()) return;
+        const size_t End = std::min(Begin + (size_t)FilesPerBatch, Shard[(size_t)d].size());
+        std::unique_ptr<TFinishedBatch> pDone(new TFinishedBatch);
+        TFinishedBatch& Done = *pDone;
+        const size_t n = End - Begin;
+        Done.mFiles.assign(Shard[(size_t)d].begin() + (long)Begin, Shard[(size_t)d].begin() + (long)End);
+        Done.mProperties.resize(n);
+        Done.mFailed.assign(n, std::string());
+        Done.mBatchIndex.assign(n, -1);
+        // parse; lay the data chunks out in the page-locked staging buffer
+        const double tParse0 = Now();
+        Waves.clear();
+        Widened.assign(n, std::vector<unsigned char>());
+        std::vector<TDecodedSample> Decoded;
+        std::vector<size_t> Offset;
+        size_t Bytes = 0;
+        int64_t PcmBytes = 0;
+        for (size_t i = 0; i < n; ++i) {
+          Waves.emplace_back(new TWaveFile);
+          try {
+            const TCrawlFile& f = *Done.mFiles[i];
+            if (f.mpImage) Waves[i]->OpenForRead(f.mpImage, f.mImageSize, f.mFileName);
+            else Waves[i]->OpenForRead(f.mFileName);
+            TDecodedSample s = Waves[i]->DecodedSample(Widened[i]);
+            TFileProperties& p = Done.mProperties[i];
+            p.mFileType = "wav";
+            p.mFileSize = (int)Waves[i]->FileSizeInBytes();
+            p.mFileLength = (double)Waves[i]->NumSamples() / (double)Waves[i]->SamplingRate();
+            p.mFileSampleRate = Waves[i]->SamplingRate();
+            p.mFileChannelCount = Waves[i]->NumChannels();
+            p.mFileBitDepth = Waves[i]->BitsPerSample();
+            const size_t bps = s.mFormat == AFX_RAW_I16 ? 2 : (s.mFormat == AFX_RAW_I24 ? 3 : (s.mFormat == AFX_RAW_F64 ? 8 : 4));
+            const size_t Size = (size_t)s.mNumberOfSampleFrames * (size_t)s.mNumberOfChannels * bps;
+            Done.mBatchIndex[i] = (int)Decoded.size();
+            Decoded.push_back(s);
+            Offset.push_back(Bytes);
+            Bytes += (Size + 15) & ~(size_t)15;   // the device arena's layout: the C-ABI then uploads the batch in one transfer
+            PcmBytes += (int64_t)Size;
+          } catch (const TReadableException& e) {
+            Done.mFailed[i] = e.what();
+          }
+        }
+        Staging.Reserve(Bytes + 64);
+        for (size_t k = 0; k < Decoded.size(); ++k) {
+          const size_t bps = Decoded[k].mFormat == AFX_RAW_I16 ? 2 : (Decoded[k].mFormat == AFX_RAW_I24 ? 3 : (Decoded[k].mFormat == AFX_RAW_F64 ? 8 : 4));
+          const size_t Size = (size_t)Decoded[k].mNumberOfSampleFrames * (size_t)Decoded[k].mNumberOfChannels * bps;
+          std::memcpy((char*)Staging.mp + Offset[k], Decoded[k].mpInterleavedSamples, Size);
+          Decoded[k].mpInterleavedSamples = (char*)Staging.mp + Offset[k];
+        }
+        const double tGpu0 = Now();
+        // GPU: LoadSample + descriptors + statistics; results straight into page-locked buffers
+        int64_t Frames = 0, ResultBytes = 0;
+        if (!Decoded.empty()) {
+          Done.mpStatistics = Pool.Acquire(Decoded.size() * (size_t)TSampleAnalyser::kMaxStride * 13 * sizeof(double));
+          // frames are at most samples / hop + 2 per file (LoadSample pads by up to a frame)
+          size_t MaxFrames = 0;
+          for (const TDecodedSample& s : Decoded) MaxFrames += (size_t)(s.mNumberOfSampleFrames / Options.mHopFrameSize) + 3;
+          size_t Capacity = MaxFrames * (size_t)TSampleAnalyser::kMaxStride;
+          for (;;) {
+            if (Done.mpRecords) Done.mpRecords->Reserve(Capacity * sizeof(double));
+            else Done.mpRecords = Pool.Acquire(Capacity * sizeof(double));
+            if (Analyser.AnalyzeToRecords(Decoded, (double*)Done.mpRecords->mp, Done.mpRecords->mBytes / sizeof(double),
+                                          (double*)Done.mpStatistics->mp, Done.mResults))
+              break;
+            Capacity *= 2;
+          }
+          Frames = Done.mResults.mFrameOffset.back();
+          ResultBytes = (Frames * Done.mResults.mStride + (int64_t)Decoded.size() * Done.mResults.mStride * 13) * 8;
+          for (size_t i = 0; i < n; ++i) {
+            const int k = Done.mBatchIndex[i];
+            if (k >= 0 && Done.mResults.mStatus[(size_t)k] != AFX_OK)
+              Done.mFailed[i] = std::string(afx_status_str(Done.mResults.mStatus[(size_t)k]));
+          }
+        }
+        const double tGpu1 = Now();
+        {
+          std::lock_guard<std::mutex> Lock(StatMutex);
+          PhaseSeconds[0] += tGpu0 - tParse0;
+          PhaseSeconds[1] += tGpu1 - tGpu0;
+          Total.mFiles += (int64_t)n;
+          Total.mFrames += Frames;
+          Total.mPcmBytes += PcmBytes;
+          Total.mResultBytes += ResultBytes;
+          Total.mFilesPerDevice[(size_t)d] += (int64_t)n;
+        }
+        Queue.Push(std::move(pDone));
+      }
+    } catch (const std::exception& e) {
+      std::lock_guard<std::mutex> Lock(StatMutex);
+      if (FirstError.empty()) FirstError = e.what();
+      Abort = true;
+    }
+  };
+
+  // the single writer (SampleAnalyser.cpp:413-415: one mutex around the pool)
+  std::thread Writer([&] {
+    while (std::unique_ptr<TFinishedBatch> p = Queue.Pop()) {
+      const double t0 = Now();
+      int64_t Failed = 0;
+      for (size_t i = 0; i < p->mFiles.size(); ++i) {
+        const TCrawlFile& f = *p->mFiles[i];
+        try {
+          if (!p->mFailed[i].empty()) {
+            ++Failed;
+            if (pPool) pPool->InsertFailedSample(f.mFileName, f.mModificationTime, p->mFailed[i]);
+          } else if (pPool) {
+            const int k = p->mBatchIndex[i];
+            const TSampleDescriptors Results = p->mResults.Descriptors(k);
+            pPool->InsertSample(f.mFileName, f.mModificationTime, p->mProperties[i], Results, &p->mResults.mInfo[(size_t)k]);
+          }
+        } catch (const std::exception& e) {
+          std::lock_guard<std::mutex> Lock(StatMutex);
+          if (FirstError.empty()) FirstError = e.what();
+          Abort = true;
+        }
+      }
+      Pool.Release(std::move(p->mpRecords));
+      Pool.Release(std::move(p->mpStatistics));
+      std::lock_guard<std::mutex> Lock(StatMutex);
+      Total.mFailedFiles += Failed;
+      if (pPool) Total.mWriterSeconds += Now() - t0;
+    }
+  });
+
+  const double Start = Now();
+  std::vector<std::thread> Workers;
+  for (int d = 0; d < G; ++d)
+    for (int w = 0; w < W; ++w) Workers.emplace_back(Worker, d);
+  for (std::thread& t : Workers) t.join();
+  Queue.Close();
+  Writer.join();
+  Total.mSeconds = Now() - Start;
+  if (std::getenv("AFEC_CRAWL_TIMING"))
+    std::fprintf(stderr, "[afec crawl] %.1f ms wall; worker time summed over %d workers: parse + staging %.1f ms, GPU round trip %.1f ms\n",
+                 Total.mSeconds * 1e3, G * W, PhaseSeconds[0] * 1e3, PhaseSeconds[1] * 1e3);
+  if (!FirstError.empty()) throw TReadableException(FirstError);
+  return Total;
+}
+
+}  // namespace afec
+
+extern "C" int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
+                                      const int32_t* devices, int32_t n_devices, int32_t workers_per_device,
+                                      int32_t files_per_batch, const char* database_path, double* stats, char* error,
+                                      int32_t error_size) {
+  try {
+    std::vector<afec::TCrawlFile> Files((size_t)n_files);
+    for (int32_t i = 0; i < n_files; ++i) {
+      Files[(size_t)i].mFileName = names[i];
+      Files[(size_t)i].mModificationTime = 1700000000 + i;
+      Files[(size_t)i].mpImage = images ? images[i] : nullptr;
+      Files[(size_t)i].mImageSize = images ? (size_t)sizes[i] : 0;
+    }
+    afec::TCrawlOptions Options;
+    Options.mDevices.assign(devices, devices + n_devices);
+    if (workers_per_device > 0) Options.mWorkersPerDevice = workers_per_device;
+    if (files_per_batch > 0) Options.mFilesPerBatch = files_per_batch;
+    if (database_path) Options.mDatabasePath = database_path;
+    const afec::TCrawlStatistics s = afec::CrawlWaveFiles(Files, Options);
+    if (stats) {
+      stats[0] = (double)s.mFiles; stats[1] = (double)s.mFailedFiles; stats[2] = (double)s.mFrames; stats[3] = (double)s.mPcmBytes;
+      stats[4] = (double)s.mResultBytes; stats[5] = s.mSeconds; stats[6] = s.mWriterSeconds;
+      for (int32_t d = 0; d < n_devices; ++d) stats[7 + d] = (double)s.mFilesPerDevice[(size_t)d];
+    }
+    return 0;
+  } catch (const std::exception& e) {
+    if (error && error_size > 0) std::snprintf(error, (size_t)error_size, "%s", e.what());
+    return -1;
+  }
+}
+
+extern "C" int afec_wave_probe(const void* image, int64_t size, int64_t* props, void* payload, int64_t payload_capacity,
+                               char* error, int32_t error_size) {
+  try {
+    afec::TWaveFile Wave;
+    Wave.OpenForRead(image, (size_t)size);
+    std::vector<unsigned char> Storage;
+    const afec::TDecodedSample s = Wave.DecodedSample(Storage);
+    const int64_t bps = s.mFormat == AFX_RAW_I16 ? 2 : (s.mFormat == AFX_RAW_I24 ? 3 : (s.mFormat == AFX_RAW_F64 ? 8 : 4));
+    const int64_t Bytes = s.mNumberOfSampleFrames * s.mNumberOfChannels * bps;
+    props[0] = Wave.NumChannels(); props[1] = Wave.SamplingRate(); props[2] = Wave.BitsPerSample();
+    props[3] = (int64_t)Wave.SampleType(); props[4] = Wave.NumSamples(); props[5] = s.mFormat; props[6] = Bytes;
+    if (payload && Bytes <= payload_capacity) std::memcpy(payload, s.mpInterleavedSamples, (size_t)Bytes);
+    return 0;
+  } catch (const std::exception& e) {
+    if (error && error_size > 0) std::snprintf(error, (size_t)error_size, "%s", e.what());
+    return -1;
+  }
+}
+
+extern "C" int afec_shard_of_file(int64_t file_index, int32_t n_devices) { return afec::ShardOfFile(file_index, n_devices); }

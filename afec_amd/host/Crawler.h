@@ -1,0 +1,70 @@
+// afec_amd/host/Crawler.h -- streaming, sharded host driver above the C-ABI: the analogue of the
+// reference crawler's worker pool (Source/Crawler/XCrawler/Source/Crawler.cpp:599, 706-728: one self-contained
+// task per file on a thread pool that shares one const analyser) and of its single database writer
+// (SampleAnalyser.cpp:413-415), for GPUs:
+//
+//   * file i of a crawl belongs to device i mod G (ShardOfFile): no exchange between devices, no collective;
+//   * every device is fed by W worker threads; a worker owns one page-locked staging buffer, fills it with the data
+//     chunks of its next batch of WAV files (TWaveFile), and runs LoadSample + every per-frame descriptor + the
+//     statistics on the GPU (afx_batch_create_from_raw / run); the C-ABI gives every batch its own stream and
+//     workspace, so the upload of one worker's batch overlaps the kernels of another's and the download of a third;
+//   * results come back as the raw per-frame records and statistics (one transfer each, afx_batch_fetch_records)
+//     and go through a bounded queue to ONE writer, which materialises TSampleDescriptors per file and inserts them
+//     into the reference's `assets` table (TSqliteSampleDescriptorPool) -- or just counts them.
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "SampleAnalyser.h"
+
+namespace afec {
+
+struct TCrawlFile {
+  std::string mFileName;            // the database key (the crawler stores paths relative to the crawl root)
+  int mModificationTime = 0;
+  const void* mpImage = nullptr;    // the file's bytes when it is already in memory; nullptr: read mFileName
+  size_t mImageSize = 0;
+};
+
+struct TCrawlOptions {
+  std::vector<int> mDevices = {0};  // HIP device ordinals
+  int mWorkersPerDevice = 4;        // host threads (= batches in flight) per device
+  int mFilesPerBatch = 128;         // measured best on one MI355X for 1 s stereo files (profiles/r02/README.md)
+  std::string mDatabasePath;        // empty: results are counted, not stored
+  int mSampleRate = 44100, mFftFrameSize = 2048, mHopFrameSize = 1024;
+};
+
+struct TCrawlStatistics {
+  int64_t mFiles = 0, mFailedFiles = 0, mFrames = 0;
+  int64_t mPcmBytes = 0;            // bytes of PCM uploaded
+  int64_t mResultBytes = 0;         // bytes of records + statistics downloaded
+  double mSeconds = 0;              // first file read .. last result delivered to the writer
+  double mWriterSeconds = 0;        // time the writer spent inserting (0 without a database)
+  std::vector<int64_t> mFilesPerDevice;
+};
+
+// file i -> device index i mod G
+inline int ShardOfFile(int64_t FileIndex, int NumberOfDevices) { return (int)(FileIndex % NumberOfDevices); }
+
+// analyse every file; throws TReadableException when a device or the database cannot be set up (single files
+// that cannot be read or analysed are counted / inserted as failed samples, SampleAnalyser.cpp:397-408)
+TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCrawlOptions& Options);
+
+}  // namespace afec
+
+extern "C" {
+// C entry point of CrawlWaveFiles for callers without C++ (bench.py, tests): file images in memory.
+// stats: [files, failed, frames, pcm_bytes, result_bytes, seconds, writer_seconds, files on device 0, 1, ...];
+// returns 0, or -1 with the message in error.
+int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
+                           const int32_t* devices, int32_t n_devices, int32_t workers_per_device, int32_t files_per_batch,
+                           const char* database_path, double* stats, char* error, int32_t error_size);
+// TWaveFile::OpenForRead on a file image: props = {channels, sampling rate, bits per sample, TSampleType, sample
+// frames, AFX_RAW_* format of the decoded payload, payload bytes}; when payload is not NULL the decoded payload
+// (8-bit files widened to int16) is copied there (payload_capacity bytes).  Returns 0, or -1 with the reader's message.
+int afec_wave_probe(const void* image, int64_t size, int64_t* props /* [7] */, void* payload, int64_t payload_capacity,
+                    char* error, int32_t error_size);
+int afec_shard_of_file(int64_t file_index, int32_t n_devices);
+}

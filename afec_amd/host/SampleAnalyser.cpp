@@ -198,6 +198,85 @@ std::vector<TSampleDescriptors> Collect(TBatchGuard& Batch, int32_t n, std::vect
 }
 }  // namespace
 
+namespace {
+// the series of afx_batch_record_layout, in its order
+double* afx_out::* const kRecordOrder[AFX_NUM_SERIES] = {
+    &afx_out::mfcc, &afx_out::spectral_rms, &afx_out::spectral_centroid, &afx_out::spectral_spread, &afx_out::spectral_skewness,
+    &afx_out::spectral_kurtosis, &afx_out::spectral_rolloff, &afx_out::spectral_flatness, &afx_out::spectral_flux,
+    &afx_out::spectrum_bands, &afx_out::amplitude_peak, &afx_out::amplitude_rms, &afx_out::sub_rms, &afx_out::sub_flatness,
+    &afx_out::sub_flux, &afx_out::sub_complexity, &afx_out::sub_contrast, &afx_out::spectral_contrast,
+    &afx_out::amplitude_silence, &afx_out::amplitude_envelope, &afx_out::spectral_complexity, &afx_out::auto_correlation,
+    &afx_out::f0, &afx_out::f0_confidence, &afx_out::failsafe_f0, &afx_out::spectral_inharmonicity, &afx_out::tristimulus1,
+    &afx_out::tristimulus2, &afx_out::tristimulus3};
+int SeriesIndex(double* afx_out::*pMember) {
+  for (int i = 0; i < AFX_NUM_SERIES; ++i)
+    if (kRecordOrder[i] == pMember) return i;
+  return -1;
+}
+void FillStrided(TFramedScalarData& Dst, const double* pSrc, int64_t Frames, int Stride) {
+  Dst.mValues.resize((size_t)Frames);
+  for (int64_t f = 0; f < Frames; ++f) Dst.mValues[(size_t)f] = pSrc[f * Stride];
+}
+template <int W>
+void FillStrided(TFramedVectorData<W>& Dst, const double* pSrc, int64_t Frames, int Stride) {
+  Dst.mValues.resize((size_t)Frames);
+  for (int64_t f = 0; f < Frames; ++f)
+    for (int b = 0; b < W; ++b) Dst.mValues[(size_t)f][b] = pSrc[f * Stride + b];
+}
+}  // namespace
+
+TSampleDescriptors TRecordBatch::Descriptors(int i) const {
+  TSampleDescriptors R;
+  const int64_t f0 = mFrameOffset[(size_t)i], nf = mFrameOffset[(size_t)i + 1] - f0;
+  R.mEffectiveLength48dB = mEffectiveLength[(size_t)i * 3];
+  R.mEffectiveLength24dB = mEffectiveLength[(size_t)i * 3 + 1];
+  R.mEffectiveLength12dB = mEffectiveLength[(size_t)i * 3 + 2];
+  const double* const pRows = mpRecords + f0 * mStride;
+  const double* const pStats = mpStatistics + (size_t)i * mStride * AFX_NUM_STATISTICS;
+  auto Each = [&](auto& Series) {
+    for (const auto& S : Series) {
+      const int k = SeriesIndex(S.mpOut);
+      if (k < 0 || mOffsets[k] < 0) continue;
+      FillStrided(R.*(S.mpDst), pRows + mOffsets[k], nf, mStride);
+      FillStatistics(R.*(S.mpDst), pStats + (size_t)mOffsets[k] * AFX_NUM_STATISTICS);
+    }
+  };
+  Each(kScalarSeries);
+  Each(kSubBandSeries);
+  Each(kBandSeries);
+  return R;
+}
+
+bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files, double* pRecords, size_t RecordCapacity,
+                                       double* pStatistics, TRecordBatch& Result) const {
+  const int32_t n = (int32_t)Files.size();
+  std::vector<afx_raw> Raws((size_t)n);
+  for (int32_t i = 0; i < n; ++i)
+    Raws[i] = {Files[i].mpInterleavedSamples, Files[i].mFormat, Files[i].mNumberOfChannels, Files[i].mSampleRate, 0,
+               Files[i].mNumberOfSampleFrames};
+  std::vector<afx_load_info> Info((size_t)n);
+  TBatchGuard Batch;
+  int Status = afx_batch_create_from_raw(mpPlan, Raws.data(), n, kEverything, &Batch.mpBatch, Info.data());
+  if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
+  Result = TRecordBatch();
+  afx_batch_record_layout(Batch.mpBatch, &Result.mStride, Result.mOffsets, Result.mWidths);
+  const size_t Frames = (size_t)afx_batch_total_frames(Batch.mpBatch);
+  if (Frames * (size_t)Result.mStride > RecordCapacity || Result.mStride > kMaxStride) return false;
+  Status = afx_batch_run(Batch.mpBatch);
+  Result.mFrameOffset.resize((size_t)n + 1);
+  Result.mStatus.resize((size_t)n);
+  Result.mEffectiveLength.resize((size_t)n * 3);
+  if (Status == AFX_OK)
+    Status = afx_batch_fetch_records(Batch.mpBatch, pRecords, pStatistics, Result.mFrameOffset.data(), Result.mStatus.data(),
+                                     Result.mEffectiveLength.data());
+  if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
+  Result.mpRecords = pRecords;
+  Result.mpStatistics = pStatistics;
+  Result.mInfo.resize((size_t)n);
+  for (int32_t i = 0; i < n; ++i) Result.mInfo[i] = {Info[i].peak_value, Info[i].rms_value, Info[i].data_offset, Info[i].n_samples};
+  return true;
+}
+
 TSampleDescriptors TSampleAnalyser::AnalyzeLowLevelDescriptors(const std::vector<double>& SampleData,
                                                                bool WithMagnitudes) const {
   std::vector<std::string> Failed;

@@ -75,6 +75,22 @@ struct TSampleDataInfo {
   int64_t mNumberOfSamples;   // size of the normalised, trimmed, padded mono buffer
 };
 
+// One GPU batch's results as they come off the device (afx_batch_fetch_records): per-frame records
+// double[frames][stride], statistics double[files][stride][13].  The buffers are the caller's (page-locked memory
+// keeps the transfers direct); Descriptors(i) materialises file i the way TSampleAnalyser::Analyze returns it.
+struct TRecordBatch {
+  int mStride = 0;
+  int mOffsets[32] = {}, mWidths[32] = {};          // per series, afx_batch_record_layout
+  const double* mpRecords = nullptr;                // [frames][stride]
+  const double* mpStatistics = nullptr;             // [files][stride][13]
+  std::vector<int64_t> mFrameOffset;                // [files + 1]
+  std::vector<int32_t> mStatus;                     // [files]: AFX_OK or the per-buffer error
+  std::vector<double> mEffectiveLength;             // [files][3]
+  std::vector<TSampleDataInfo> mInfo;               // [files]
+  int NumberOfFiles() const { return (int)mStatus.size(); }
+  TSampleDescriptors Descriptors(int FileIndex) const;
+};
+
 class TSampleAnalyser {
 public:
   // Device: HIP device ordinal.  Throws TReadableException when the GPU path cannot be set up.
@@ -99,6 +115,13 @@ public:
   std::vector<TSampleDescriptors> Analyze(const std::vector<TDecodedSample>& Files,
                                           std::vector<TSampleDataInfo>* pInfo = nullptr,
                                           std::vector<std::string>* pFailed = nullptr) const;
+
+  // LoadSample + descriptors + statistics for decoded files, results left as raw records in caller memory:
+  // pRecords must hold RecordCapacity doubles, pStatistics Files.size() * 134 * 13 (kMaxStride columns).  Returns
+  // false (and leaves Batch empty) when the records do not fit RecordCapacity: call again with a larger buffer.
+  enum { kMaxStride = 134 };
+  bool AnalyzeToRecords(const std::vector<TDecodedSample>& Files, double* pRecords, size_t RecordCapacity,
+                        double* pStatistics, TRecordBatch& Batch) const;
 
 private:
   afx_plan* mpPlan;

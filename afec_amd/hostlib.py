@@ -1,0 +1,64 @@
+"""ctypes access to the C entry points of afec_amd/lib/libafx_host.so, the C++ host layer above the C-ABI
+(afec_amd/host: WAV reader, streaming sharded crawler, sqlite descriptor pool)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repository root
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "afec_amd", "csrc")], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "afec_amd", "host")], stdout=subprocess.DEVNULL)
+        L = ctypes.CDLL(os.path.join(ROOT, "afec_amd", "lib", "libafx_host.so"))
+        L.afec_wave_probe.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
+                                      ctypes.c_int64, ctypes.c_char_p, ctypes.c_int32]
+        L.afec_shard_of_file.argtypes = [ctypes.c_int64, ctypes.c_int32]
+        L.afec_crawl_wave_images.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_void_p),
+                                             ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p,
+                                             ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int32]
+        _lib = L
+    return _lib
+
+
+def wave_probe(image):
+    """-> (dict of properties, decoded payload bytes) or raises RuntimeError with the reader's message."""
+    L = lib()
+    buf = np.frombuffer(image, dtype=np.uint8)
+    props = (ctypes.c_int64 * 7)()
+    err = ctypes.create_string_buffer(256)
+    payload = np.zeros(2 * len(image) + 16, dtype=np.uint8)
+    rc = L.afec_wave_probe(buf.ctypes.data, len(image), props, payload.ctypes.data, payload.size, err, 256)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    keys = ["channels", "rate", "bits", "sample_type", "frames", "raw_format", "payload_bytes"]
+    d = dict(zip(keys, [int(v) for v in props]))
+    return d, payload[:d["payload_bytes"]].tobytes()
+
+
+def crawl(images, names=None, devices=(0,), workers=3, files_per_batch=256, database=None):
+    """images: list of bytes (WAV file images).  -> dict of statistics."""
+    L = lib()
+    n = len(images)
+    names = names or [f"file{i:06d}.wav" for i in range(n)]
+    keep = [np.frombuffer(b, dtype=np.uint8) for b in images]
+    c_names = (ctypes.c_char_p * n)(*[s.encode() for s in names])
+    c_images = (ctypes.c_void_p * n)(*[k.ctypes.data for k in keep])
+    c_sizes = (ctypes.c_int64 * n)(*[len(b) for b in images])
+    c_dev = (ctypes.c_int32 * len(devices))(*devices)
+    stats = (ctypes.c_double * (7 + len(devices)))()
+    err = ctypes.create_string_buffer(512)
+    rc = L.afec_crawl_wave_images(c_names, c_images, c_sizes, n, c_dev, len(devices), workers, files_per_batch,
+                                  database.encode() if database else None, stats, err, 512)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    keys = ["files", "failed", "frames", "pcm_bytes", "result_bytes", "seconds", "writer_seconds"]
+    out = dict(zip(keys, list(stats)[:7]))
+    out["files_per_device"] = [int(v) for v in list(stats)[7:]]
+    return out

@@ -236,6 +236,22 @@ int afx_batch_fetch(afx_batch* batch, afx_out* out);    /* D2H + unpack, synchro
 int afx_batch_fetch_statistics(afx_batch* batch, afx_stats_out* out); /* needs AFX_D_STATISTICS in the mask */
 void afx_batch_destroy(afx_batch* batch);
 
+/* Raw results for pipelines that keep many batches in flight: the per-frame records exactly as the kernels leave
+ * them, double[total_frames][stride], and the statistics double[n_bufs][stride][AFX_NUM_STATISTICS], each moved by
+ * ONE device-to-host transfer into caller memory (page-locked memory from afx_host_alloc makes it a direct DMA; no
+ * intermediate copy, no per-field unpack).  offsets[i] is the first record column of the i-th series, -1 when the
+ * series is not in the batch mask; widths[i] its number of columns.  Series order (= record order): mfcc,
+ * spectral_rms, spectral_centroid, spectral_spread, spectral_skewness, spectral_kurtosis, spectral_rolloff,
+ * spectral_flatness, spectral_flux, spectrum_bands, amplitude_peak, amplitude_rms, sub_rms, sub_flatness, sub_flux,
+ * sub_complexity, sub_contrast, spectral_contrast, amplitude_silence, amplitude_envelope, spectral_complexity,
+ * auto_correlation, f0, f0_confidence, failsafe_f0, spectral_inharmonicity, tristimulus1, tristimulus2, tristimulus3.
+ * Either destination may be NULL. */
+#define AFX_NUM_SERIES 29
+int afx_batch_record_layout(const afx_batch* batch, int32_t* stride, int32_t* offsets /* [AFX_NUM_SERIES] */,
+                            int32_t* widths /* [AFX_NUM_SERIES] */);
+int afx_batch_fetch_records(afx_batch* batch, double* records, double* statistics, int64_t* frame_offset /* [n_bufs+1] */,
+                            int32_t* buf_status /* [n_bufs] */, double* effective_length /* [n_bufs][3] or NULL */);
+
 /* ---- LoadSample front end: TSampleAnalyser::LoadSample, SampleAnalyser.cpp:484-718 ---- *
  * Decoded, interleaved PCM of a file in; on the GPU: conversion to the reference's "16-bit float"
  * range, mono mix-down, peak / rms, peak normalisation, -48 dB leading / trailing silence trim, and the
@@ -245,7 +261,9 @@ void afx_batch_destroy(afx_batch* batch);
 enum {
   AFX_RAW_I16 = 0, /* int16                      (S16BitSignedTo16BitFloat, SampleConverter.h:446-449) */
   AFX_RAW_I24 = 1, /* packed little-endian int24 (S24BitTo16BitFloat, SampleConverter.h:474-486)       */
-  AFX_RAW_F32 = 2  /* float in [-1, 1]           (S0To1FloatTo16BitFloat, SampleConverter.h:529-533)   */
+  AFX_RAW_F32 = 2, /* float in [-1, 1]           (S0To1FloatTo16BitFloat, SampleConverter.h:529-533)   */
+  AFX_RAW_I32 = 3, /* int32                      (S32BitSignedTo16BitFloat, SampleConverter.h:514-518) */
+  AFX_RAW_F64 = 4  /* double in [-1, 1]          (S0To1FloatTo16BitFloat, SampleConverter.h:529-533)   */
 };
 typedef struct {
   const void* data;    /* host pointer, interleaved by channel */

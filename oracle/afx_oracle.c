@@ -710,8 +710,13 @@ static float to_16bit_float(const void* pcm, int format, int64_t idx) {
     const int32_t v = (int32_t)(((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16)) << 8);
     return (float)(v * 32768.0 / 2147483648.0);
   }
-  {                                                                     /* SampleConverter.h:529-533 */
-    const double d = (double)((const float*)pcm)[idx] * 32768.0;
+  if (format == 3) {                                                    /* SampleConverter.h:514-518 */
+    const double dv = (double)((const int32_t*)pcm)[idx] * 32768.0 / 2147483648.0;
+    const float f = (float)dv;
+    return f < -32768.0f ? -32768.0f : (f > 32767.0f ? 32767.0f : f);
+  }
+  {                                                                     /* SampleConverter.h:529-533 (float32 / float64) */
+    const double d = (format == 4 ? ((const double*)pcm)[idx] : (double)((const float*)pcm)[idx]) * 32768.0;
     return (float)(d < -32768.0 ? -32768.0 : (d > 32767.0 ? 32767.0 : d));
   }
 }

@@ -413,13 +413,13 @@ static int CmdNeighbours(const char* in, const char* outp, bool cap) {
 // The member body (decoder plumbing, TArray/TList buffers, logging) does not link here; its flow is restated
 // on already-decoded interleaved PCM, with the reference's own TSampleConverter conversions
 // (SampleConverter.h:446-449, 474-486, 529-533), TMathT<float>::GetMinMax, TAudioMath::DbToLin and constants.
-// in.bin : int32 format (0 int16, 1 packed int24, 2 float32), int32 channels, int64 frames, raw samples
+// in.bin : int32 format (0 int16, 1 packed int24, 2 float32, 3 int32, 4 float64), int32 channels, int64 frames, raw samples
 // out.bin: float peak, float rms, int32 data_offset, int32 lead, int32 trail, int32 pad, int64 n, double[n]
 static int CmdLoad(const char* in, const char* outp) {
   FILE* fi = fopen(in, "rb"); if (!fi) return 1;
   int32_t format = 0, channels = 0; int64_t frames = 0;
   if (fread(&format, 4, 1, fi) != 1 || fread(&channels, 4, 1, fi) != 1 || fread(&frames, 8, 1, fi) != 1) return 1;
-  const size_t bps = format == 0 ? 2 : (format == 1 ? 3 : 4);
+  const size_t bps = format == 0 ? 2 : (format == 1 ? 3 : (format == 4 ? 8 : (format == 5 ? 1 : 4)));   // 5: 8-bit unsigned
   std::vector<unsigned char> raw((size_t)frames * channels * bps);
   if (!raw.empty() && fread(raw.data(), 1, raw.size(), fi) != raw.size()) return 1;
   fclose(fi);
@@ -432,6 +432,9 @@ static int CmdLoad(const char* in, const char* outp) {
       if (format == 0) { TInt16 s; memcpy(&s, p, 2); v = TSampleConverter::S16BitSignedTo16BitFloat(s); }
       else if (format == 1) { TSampleConverter::T24Pack t; t.mFirst = (TInt8)p[0]; t.mSecond = (TInt8)p[1]; t.mThird = (TInt8)p[2];
                               v = TSampleConverter::S24BitTo16BitFloat(t); }
+      else if (format == 3) { TInt32 s; memcpy(&s, p, 4); v = TSampleConverter::S32BitSignedTo16BitFloat(s); }
+      else if (format == 4) { double d; memcpy(&d, p, 8); v = TSampleConverter::S0To1FloatTo16BitFloat(d); }
+      else if (format == 5) { v = TSampleConverter::S8BitUnsignedTo16BitFloat((TUInt8)p[0]); }
       else { float f; memcpy(&f, p, 4); v = TSampleConverter::S0To1FloatTo16BitFloat(f); }
       chan[(size_t)c][(size_t)n] = v;
     }

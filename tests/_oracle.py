@@ -103,6 +103,10 @@ def load_sample(data, channels, fft=2048):
         fmt, frames = 0, data.size // channels
     elif data.dtype == np.uint8:
         fmt, frames = 1, data.size // (3 * channels)
+    elif data.dtype == np.int32:
+        fmt, frames = 3, data.size // channels
+    elif data.dtype == np.float64:
+        fmt, frames = 4, data.size // channels
     else:
         data = data.astype(np.float32)
         fmt, frames = 2, data.size // channels

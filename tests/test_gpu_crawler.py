@@ -1,0 +1,133 @@
+"""The streaming, sharded host driver (afec_amd/host/Crawler.cpp) end to end on the GPU: WAV file images in (C3 /
+C4-shaped synthetic files, every WAV sample type, and files the reader must reject) -> WAV reader -> page-locked
+staging -> LoadSample + every per-frame descriptor + statistics on the GPU -> raw record download -> ONE writer ->
+the reference's sqlite `assets` table, read back with Python's sqlite3 + msgpack and compared with the oracle."""
+import os
+import sqlite3
+
+import numpy as np
+import pytest
+
+import afec_amd as afx
+from tests import _host, _oracle, _tol
+from tests._oracle import FIELDS, Oracle
+from tests._wav import wav_bytes
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "load_wav.npz")
+# series name in the C-ABI -> descriptor base name in the database (SampleDescriptors.cpp:150-205)
+DB_NAME = {"spectral_rms": "spectral_rms", "spectral_centroid": "spectral_centroid", "spectral_rolloff": "spectral_rolloff",
+           "spectral_flatness": "spectral_flatness", "amplitude_peak": "amplitude_peak", "amplitude_rms": "amplitude_rms",
+           "mfcc": "cepstrum_bands", "spectrum_bands": "frequency_bands", "sub_rms": "spectral_rms_bands",
+           "sub_contrast": "spectral_contrast_bands"}
+
+
+def synth(rng, seconds, stereo):
+    n = int(44100 * seconds)
+    t = np.arange(n) / 44100.0
+    x = np.zeros(n)
+    for _ in range(int(rng.integers(1, 4))):
+        x += rng.uniform(0.2, 0.6) * np.sin(2 * np.pi * rng.uniform(110.0, 4000.0) * t + rng.uniform(0, 6.28))
+    x += rng.uniform(0.2, 0.8) * rng.uniform(-1, 1, n) * np.exp(-t / rng.uniform(0.05, 0.5))
+    x[:2205] = 0.0
+    x *= rng.uniform(0.1, 0.9) / np.max(np.abs(x))
+    if stereo:
+        return np.stack([x, 0.8 * np.roll(x, 7)], axis=1), 2
+    return x, 1
+
+
+def make_crawl(n_files=120):
+    rng = np.random.default_rng(91)
+    z = np.load(GOLD)
+    images, names, decoded = [], [], {}
+    for i in range(n_files):
+        x, ch = synth(rng, 2.0 if i % 2 == 0 else 1.0, stereo=(i % 2 == 1))
+        pcm = np.round(x * 32767).astype(np.int16)
+        names.append(f"Synth/{'stereo' if ch == 2 else 'mono'}_{i:04d}.wav")
+        images.append(wav_bytes(pcm, ch, 16, extra_chunks=(i % 7 == 0)))
+        decoded[names[-1]] = (pcm, ch)
+    for k in ("u8_mono", "i24_mono", "i32_stereo", "f32_mono", "f64_stereo"):
+        names.append(f"Formats/{k}.wav")
+        images.append(z["wav_" + k].tobytes())
+    names.append("Broken/_Not A Wavefile.wav")
+    images.append(b"RIFF....this is not a wave file" * 8)
+    names.append("Broken/48k.wav")
+    images.append(wav_bytes(np.zeros(6000, np.int16), 1, 16, rate=48000))     # not at the analyser's rate: resampling stays with the caller
+    return images, names, decoded
+
+
+def test_crawl_into_the_descriptor_database(tmp_path):
+    import msgpack
+    images, names, decoded = make_crawl()
+    db = str(tmp_path / "afec-ll.db")
+    st = _host.crawl(images, names, devices=(0,), workers=3, files_per_batch=16, database=db)
+    assert st["files"] == len(images) and st["failed"] == 2 and st["files_per_device"] == [len(images)]
+    con = sqlite3.connect(db)
+    con.row_factory = sqlite3.Row
+    assert con.execute("PRAGMA user_version").fetchone()[0] == 2
+    rows = {r["filename"]: r for r in con.execute("SELECT * FROM assets")}
+    assert len(rows) == len(images)
+    assert rows["Broken/_Not A Wavefile.wav"]["status"] == "error: Not a valid WAV file."
+    assert rows["Broken/48k.wav"]["status"].startswith("error: ")
+    assert sum(1 for r in rows.values() if r["status"] != "succeeded") == 2          # cf. UnitTests.cpp:338-350
+    z = np.load(GOLD)
+    ora = Oracle()
+    rng = np.random.default_rng(5)
+    picks = list(rng.choice(120, 6, replace=False))
+    for i in picks:
+        name = names[i]
+        r = rows[name]
+        pcm, ch = decoded[name]
+        assert (r["file_type_S"], r["file_sample_rate_R"], r["file_channel_count_R"], r["file_bit_depth_R"]) == ("wav", 44100, ch, 16)
+        assert abs(r["file_length_R"] - pcm.reshape(-1).size / ch / 44100.0) < 1e-9
+        mono, info = _oracle.load_sample(pcm, ch)
+        ref = ora.run(mono, cap=True)
+        for field, base in DB_NAME.items():
+            a, b = FIELDS[field]
+            rtol, atol = _tol.GPU_TOL[field]
+            col = base + ("_VR" if b - a == 1 else "_VVR")
+            got = np.array(msgpack.unpackb(r[col]), dtype=np.float64).reshape(ref.shape[0], -1)
+            _tol.check(field, got, ref[:, a:b], rtol, atol, what=f"{name} {col} ")
+            # statistics columns: the mean of the series
+            want_mean = ref[:, a:b].mean(axis=0)
+            if b - a == 1:
+                assert abs(r[base + "_mean_R"] - want_mean[0]) <= 1e-4 * abs(want_mean[0]) + 1e-7
+            else:
+                got_mean = np.array(msgpack.unpackb(r[base + "_mean_VR"]))
+                assert np.all(np.abs(got_mean - want_mean) <= 1e-4 * np.abs(want_mean) + 1e-7)
+        eff = ora.effective_length(mono)
+        assert abs(r["effectve_length_48dB_R"] - eff[0]) < 1e-9
+    # the WAV sample types: the normalised buffer's length is what the reference's converters give
+    for k in ("u8_mono", "i24_mono", "i32_stereo", "f32_mono", "f64_stereo"):
+        r = rows[f"Formats/{k}.wav"]
+        assert r["status"] == "succeeded" and r["file_bit_depth_R"] == int(z["props_" + k][2])
+        mono = z["data_" + k]
+        ref = ora.run(mono, cap=True)
+        got = np.array(msgpack.unpackb(r["cepstrum_bands_VVR"]))
+        a, b = FIELDS["mfcc"]
+        _tol.check("mfcc", got, ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=k + " ")
+    con.close()
+
+
+def test_crawl_without_a_database_and_small_batches():
+    images, names, _ = make_crawl(40)
+    a = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=1000)
+    b = _host.crawl(images, names, devices=(0,), workers=4, files_per_batch=3)
+    for k in ("files", "failed", "frames", "pcm_bytes", "result_bytes"):
+        assert a[k] == b[k], k
+    assert a["failed"] == 2 and a["frames"] > 0 and a["writer_seconds"] == 0.0
+
+
+def test_crawl_is_sharded_over_devices():
+    import ctypes
+    n = ctypes.c_int(0)
+    hip = ctypes.CDLL("libamdhip64.so")
+    if hip.hipGetDeviceCount(ctypes.byref(n)) != 0 or n.value < 2:
+        pytest.skip("needs two GPUs")
+    images, names, _ = make_crawl(60)
+    one = _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=8)
+    two = _host.crawl(images, names, devices=(0, 1), workers=2, files_per_batch=8)
+    assert two["files_per_device"] == [(len(images) + 1) // 2, len(images) // 2]
+    for k in ("files", "failed", "frames"):
+        assert one[k] == two[k]

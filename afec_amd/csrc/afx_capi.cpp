@@ -246,30 +246,6 @@ int upload_tables_typed(afx_plan* p) {
   return AFX_OK;
 }
 
-// the pitch / autocorrelation kernels always run in double
-int upload_double_twiddles(afx_plan* p) {
-  using C = cpx<double>;
-  std::vector<C> t1(64), t2(1024), post(1024);
-  for (int n = 0; n < 1024; ++n) post[n] = twiddle<double>(n, 2048);
-  for (int jh = 0; jh < 4; ++jh)
-    for (int m2 = 0; m2 < 4; ++m2)
-      for (int jl = 0; jl < 4; ++jl) t1[16 * jh + 4 * m2 + jl] = twiddle<double>((long long)m2 * (4 * jh + jl), 64);
-  for (int g = 0; g < 16; ++g)
-    for (int lane = 0; lane < 64; ++lane) {
-      const int j2 = g >> 2, jl = g & 3, jh = lane >> 4, n2 = lane & 15;
-      t2[64 * g + lane] = twiddle<double>((long long)n2 * (4 * jh + jl + 16 * j2), 1024);
-    }
-  auto up = [](void** dst, const void* src, size_t bytes) -> hipError_t {
-    hipError_t e = hipMalloc(dst, bytes);
-    if (e != hipSuccess) return e;
-    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-  };
-  HIP_TRY(up(&p->dev.t1_f64, t1.data(), t1.size() * sizeof(C)));
-  HIP_TRY(up(&p->dev.t2_f64, t2.data(), t2.size() * sizeof(C)));
-  HIP_TRY(up(&p->dev.post_f64, post.data(), post.size() * sizeof(C)));
-  return AFX_OK;
-}
-
 // tables of the half-wave kernels (afx_frames32.hip): bin / sample index = q + 32 row, always double
 int upload_halfwave_tables(afx_plan* p) {
   using C = cpx<double>;
@@ -304,10 +280,8 @@ int upload_halfwave_tables(afx_plan* p) {
 }
 
 int upload_tables(afx_plan* p) {
-  int st = (p->desc.precision == AFX_PRECISION_F64) ? upload_tables_typed<double>(p)
-                                                    : upload_tables_typed<float>(p);
+  int st = upload_tables_typed<double>(p);
   if (st != AFX_OK) return st;
-  if (p->desc.precision != AFX_PRECISION_F64 && (st = upload_double_twiddles(p)) != AFX_OK) return st;
   if ((st = upload_halfwave_tables(p)) != AFX_OK) return st;
   // packed mel rows: one 64-lane row per (r, f) pair the static cover lists, in the kernel's precision
   std::vector<double> melw((size_t)afx::kMelPairs * 64, 0.0);
@@ -319,14 +293,8 @@ int upload_tables(afx_plan* p) {
           melw[(size_t)idx * 64 + lane] = p->mel[(size_t)f * afx::kHalf + 64 * r + lane];
         ++idx;
       }
-  if (p->desc.precision == AFX_PRECISION_F64) {
-    HIP_TRY(hipMalloc(&p->dev.melw, melw.size() * sizeof(double)));
-    HIP_TRY(hipMemcpy(p->dev.melw, melw.data(), melw.size() * sizeof(double), hipMemcpyHostToDevice));
-  } else {
-    std::vector<float> melf(melw.begin(), melw.end());
-    HIP_TRY(hipMalloc(&p->dev.melw, melf.size() * sizeof(float)));
-    HIP_TRY(hipMemcpy(p->dev.melw, melf.data(), melf.size() * sizeof(float), hipMemcpyHostToDevice));
-  }
+  HIP_TRY(hipMalloc(&p->dev.melw, melw.size() * sizeof(double)));
+  HIP_TRY(hipMemcpy(p->dev.melw, melw.data(), melw.size() * sizeof(double), hipMemcpyHostToDevice));
   // DCT-II basis exactly as xtract_dct evaluates it (vector.c:381-385)
   std::vector<double> dct(14 * 16, 0.0);
   for (int n = 0; n < 14; ++n)
@@ -515,6 +483,10 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
       (desc->fft_size & (desc->fft_size - 1)) || desc->max_analysis_ms < 0 ||
       (desc->precision != AFX_PRECISION_F64 && desc->precision != AFX_PRECISION_F32))
     return fail(AFX_ERR_INVALID_ARG, "bad plan descriptor");
+  if (desc->precision == AFX_PRECISION_F32)
+    return fail(AFX_ERR_UNSUPPORTED,
+                "AFX_PRECISION_F32 was removed: narrower than the reference's arithmetic (it missed the parity bar on tonal "
+                "input) and no faster than the double path since the half-wave kernel");
   if (desc->sample_rate != afx::kSampleRate || desc->fft_size != afx::kFft || desc->hop_size != afx::kHop)
     return fail(AFX_ERR_UNSUPPORTED,
                 "the HIP kernels are specialised for 44100 Hz / 2048 / 1024 (Crawler.cpp:41-43)");

@@ -450,12 +450,9 @@ hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int g
                          hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
   const int feat = frames_feature_class(a.mask);
-  if (precision == 0) {
-    return pcm_dtype == 0 ? launch_typed<double, float>(a, feat, grid_blocks, stream)
-                          : launch_typed<double, double>(a, feat, grid_blocks, stream);
-  }
-  return pcm_dtype == 0 ? launch_typed<float, float>(a, feat, grid_blocks, stream)
-                        : launch_typed<float, double>(a, feat, grid_blocks, stream);
+  if (precision != 0) return hipErrorInvalidValue;   // the float STFT mode is gone (include/afx.h, AFX_PRECISION_F32)
+  return pcm_dtype == 0 ? launch_typed<double, float>(a, feat, grid_blocks, stream)
+                        : launch_typed<double, double>(a, feat, grid_blocks, stream);
 }
 
 }  // namespace afx

@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--buffers", type=int, default=64, help="10k-frame buffers per GPU per step")
-    ap.add_argument("--precision", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--precision", choices=["f64"], default="f64", help="the arithmetic the path computes in (the reference's)")
     ap.add_argument("--mask", default="c2", choices=["c2", "star", "stats", "all", "frame", "neighbours"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2: --buffers x 10k-frame buffers (headline); c3: 1000 synthetic 2.0 s files, full "
@@ -270,7 +270,7 @@ def main():
             afx.D_SPECTRAL_FLATNESS)
     mask = {"c2": afx.D_C2, "star": star, "stats": afx.D_MFCC | afx.D_SPECTRAL_STATS,
             "all": afx.D_ALL_LOW_LEVEL, "frame": afx.D_ALL_PER_FRAME, "neighbours": afx.D_NEIGHBOURS}[args.mask]
-    precision = afx.PRECISION_F64 if args.precision == "f64" else afx.PRECISION_F32
+    precision = afx.PRECISION_F64
     # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)
     device = int(os.environ.get("AFX_BENCH_DEVICE", local))
     plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0)

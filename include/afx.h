@@ -45,8 +45,8 @@ enum {
 /* ---- internal arithmetic of the STFT ---- */
 enum {
   AFX_PRECISION_F64 = 0, /* default: IEEE double end to end, like the reference             */
-  AFX_PRECISION_F32 = 1  /* float butterflies, double descriptor accumulation (see DESIGN.md
-                            for the input class on which this meets the 1e-4 bar)           */
+  AFX_PRECISION_F32 = 1  /* REMOVED (afx_plan_create answers AFX_ERR_UNSUPPORTED): float butterflies missed the
+                            1e-4 bar on tonal input and were no faster than the double half-wave kernel */
 };
 
 /* ---- descriptor selection (bit mask) ---- *

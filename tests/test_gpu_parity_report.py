@@ -35,6 +35,87 @@ def c3_like_files(n_files, seed):
     return out
 
 
+def _rows_statistics_load_and_lengths():
+    """SURVEY 8(f) rows f1 (per-file statistics), f3 (LoadSample front end) and the effective lengths: observed
+    errors on 24 C3-like 16-bit files and the reference-generated load goldens."""
+    from tests import _oracle
+    lines = ["", "## Per-file statistics (f1), LoadSample front end (f3), effective lengths", ""]
+    rng = np.random.default_rng(7)
+    files = [(np.round(x * 32767 * rng.uniform(0.2, 0.95)).astype(np.int16), 1) for x in c3_like_files(24, 123)]
+    plan = afx.Plan()
+    mask = afx.D_ALL_LOW_LEVEL | afx.D_STATISTICS | afx.D_EFFECTIVE_LENGTH
+    batch, infos = plan.batch_from_raw(files, mask)
+    batch.run()
+    res, stats = batch.fetch(), batch.fetch_statistics()
+    off = res["frame_offset"]
+    ora = Oracle()
+    names = afx.capi.STAT_NAMES
+    own = np.zeros(13)     # kernel alone: statistics of the GPU's own series vs TStatistics::Calc restated
+    e2e = np.zeros(13)     # end to end: vs the oracle pipeline (series differ by the FFT's rounding)
+    load_max, info_bad, eff_max, peak_bad = 0.0, 0, 0.0, 0
+    for i, (data, ch) in enumerate(files):
+        mono, info = _oracle.load_sample(data, ch)
+        nf = plan.num_frames(info["n_samples"])
+        kept = (nf - 1) * 1024 + 2048 if nf > 0 else 0
+        got = batch.fetch_samples(i, kept)
+        load_max = max(load_max, float(np.max(np.abs(got - mono[:kept]))) if kept else 0.0)
+        info_bad += int(infos[i]["n_samples"] != info["n_samples"] or infos[i]["data_offset"] != info["data_offset"])
+        peak_bad += int(infos[i]["peak_value"] != info["peak_value"])
+        eff_max = max(eff_max, float(np.max(np.abs(res["effective_length"][i] - np.array(ora.effective_length(mono))))))
+        ref = ora.run(mono, cap=True)
+        for field, (a, b) in FIELDS.items():
+            if field in ("mag", "spectral_rolloff", "sub_complexity"):
+                continue
+            width = b - a
+            gs = stats[field].reshape(len(files), width, 13)[i]
+            series = res[field][off[i]:off[i + 1]].reshape(-1, width)
+            for w in range(width):
+                want_own = _oracle.calc_statistics(series[:, w], np.zeros(13))
+                want_e2e = _oracle.calc_statistics(ref[:, a + w], np.zeros(13))
+                scale_own = np.maximum(np.abs(want_own), 1e-9 * (1 + np.abs(want_own).max()))
+                err_own = np.abs(gs[w] - want_own) / scale_own
+                # TStatistics::Centroid / Spread / Skewness / Kurtosis / Flatness divide by the sum (mean) of the series: for
+                # a series that sums to rounding residue (band flux values of +-1) the last bit of the sum decides them
+                well = abs(ref[:, a + w].sum()) > 1e-6 * np.abs(ref[:, a + w]).sum()
+                if not well:
+                    err_own[[6, 7, 8, 9, 10]] = 0.0
+                own = np.maximum(own, err_own)
+                if well:
+                    scale = np.maximum(np.abs(want_e2e), 1e-6 * (1 + np.abs(want_e2e).max()))
+                    e2e = np.maximum(e2e, np.abs(gs[w] - want_e2e) / scale)
+    batch.close()
+    plan.close()
+    lines += ["24 C3-like 2 s 16-bit files through afx_batch_create_from_raw; every series of the spectral set x 13 statistics.", "",
+              "| statistic | kernel alone (GPU series -> Calc), max rel err | end to end vs oracle pipeline, max rel err |", "|---|---|---|"]
+    for k, n in enumerate(names):
+        lines.append(f"| {n} | {own[k]:.2e} | {e2e[k]:.2e} |")
+    z = np.load(os.path.join(GOLD, "load.npz"))
+    plan = afx.Plan(max_analysis_ms=0)      # the goldens hold whole buffers, also beyond the analysed 20 s
+    gold_max, gold_bad, ng = 0.0, 0, 0
+    for k in z.files:
+        if not k.startswith("raw_"):
+            continue
+        name = k[4:]
+        b, infos = plan.batch_from_raw([(z[k], int(z["channels_" + name]))], afx.D_MFCC)
+        want = z["data_" + name]
+        nf = plan.num_frames(want.size)
+        kept = (nf - 1) * 1024 + 2048 if nf > 0 else 0          # the arena keeps the analysed prefix
+        got = b.fetch_samples(0, kept)
+        gold_max = max(gold_max, float(np.max(np.abs(got - want[:kept]))) if kept else 0.0)
+        gold_bad += int([infos[0]["data_offset"], infos[0]["silent_leading"], infos[0]["silent_trailing"], infos[0]["n_samples"]] != z["info_" + name].tolist())
+        b.close()
+        ng += 1
+    plan.close()
+    lines += ["", "| LoadSample / effective length | observed |", "|---|---|",
+              f"| normalised samples vs oracle, 24 files: max abs difference | {load_max:.1e} (bit-exact when 0) |",
+              f"| data offset / length mismatches vs oracle | {info_bad} of 24 |",
+              f"| peak value mismatches vs oracle | {peak_bad} of 24 |",
+              f"| normalised samples vs reference goldens (load.npz, {ng} files): max abs difference | {gold_max:.1e} |",
+              f"| offsets / trims / lengths mismatching the reference goldens | {gold_bad} of {ng} |",
+              f"| effective lengths (3 floors) vs oracle: max abs difference, seconds | {eff_max:.1e} |"]
+    return lines
+
+
 def test_write_parity_report():
     plan, oracle = afx.Plan(max_analysis_ms=0), Oracle()
     acc = {}   # field -> list of (relative errors array, error in units of the tolerance)
@@ -88,6 +169,7 @@ def test_write_parity_report():
         worst_overall = max(worst_overall, worst)
         lines.append(f"| {field} | {rel.size} | {rel.max():.2e} | {rel.mean():.2e} | "
                      + ("exact" if rel.max() == 0 else f"{worst:.3g}") + " |")
+    lines += _rows_statistics_load_and_lengths()
     text = "\n".join(lines) + "\n"
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:

@@ -461,12 +461,20 @@ static void frame_descriptors(const afx_oracle* o, const double* x, const double
   xt_mfcc(o, mag, out + AFXO_MFCC); /* CalcCepstrumBands, SA.cpp:2052-2063 */
 }
 
-int64_t afx_oracle_num_frames(const afx_oracle* o, int64_t n_samples, int apply_cap) {
-  int64_t len = n_samples, f = 0, n;
+int afx_oracle_sample_rate(const afx_oracle* o) { return o->sample_rate; }
+
+int64_t afx_oracle_analysed_length(const afx_oracle* o, int64_t n_samples, int apply_cap) {
+  int64_t len = n_samples;
   if (apply_cap) { /* MAnalyzationDurationMaxInMs = 1000*20, SA.cpp:37, 760-764 */
     const int64_t cap = ms_to_samples(o->sample_rate, 1000 * 20);
     if (cap < len) len = cap;
   }
+  return len;
+}
+
+int64_t afx_oracle_num_frames(const afx_oracle* o, int64_t n_samples, int apply_cap) {
+  const int64_t len = afx_oracle_analysed_length(o, n_samples, apply_cap);
+  int64_t f = 0, n;
   for (n = 0; (n + o->fft - 1) < len; n += o->hop) ++f; /* SA.cpp:814 */
   return f;
 }

@@ -99,6 +99,28 @@ double* afx_oracle_load_sample(const void* pcm, int format, int channels, int64_
                                afx_oracle_load_info* info);
 void afx_oracle_free(void* p);
 
+/* ---- rhythm tracker: the 512/128 loop behind the per-frame loop (SampleAnalyser.cpp:983-1048), afx_oracle_rhythm.c ----
+ * PARTLY PINNED, see the header of afx_oracle_rhythm.c: the onset STFT front end and the aubio beat-tracking pass are
+ * pinned against the reference's own objects (ref_driver `onsetfft`, `beattrack`); TOnsetDetector / TRhythmTracker /
+ * TCannyWindow do not link here, their restatement is "parity unpinned". */
+int afx_oracle_sample_rate(const afx_oracle*);
+int64_t afx_oracle_analysed_length(const afx_oracle*, int64_t n_samples, int apply_cap);
+int64_t afx_oracle_rhythm_frames(const afx_oracle*, int64_t n_samples, int apply_cap);
+/* onsets [2][T] (0 = complex, 1 = percussive; TRhythmTracker::Onsets), optional sharpened [2][T] (Canny window) and
+ * odf [2][T] (onset function before median removal); out14 = per type {onset_count, tempo, tempo_confidence,
+ * onset_frequency_mean, onset_strength, onset_contrast}, then final_tempo, final_tempo_confidence.
+ * original_rate / original_samples / data_offset: TSampleData::mOriginalSampleRate, mOriginalNumberOfSamples,
+ * mDataOffset (SampleAnalyser.cpp:1001-1004).  Returns T. */
+int64_t afx_oracle_run_rhythm(const afx_oracle*, const double* x, int64_t n_samples, int apply_cap,
+                              int original_rate, int64_t original_samples, int data_offset, double* onsets,
+                              double* sharpened, double* odf, double* out14);
+/* TOnsetFftProcessor::LoadFrame on one 512-sample frame: DC, "Nyquist", magnitude[255], phase[255] as floats */
+void afx_oracle_onset_polar(const double* x512, float* dc, float* nyquist, float* mag255, float* phase255);
+/* one aubio_beattracking_do on a fresh tracker: bpm and the [taktik] confidence (beattracking.c) */
+void afx_oracle_beattrack(const double* df, int winlen, int hop, int rate, double* bpm, double* confidence);
+/* TCannyWindow(12, 16).Apply in place (CannyWindow.cpp:27-68) */
+void afx_oracle_canny(double* x, int n);
+
 #ifdef __cplusplus
 }
 #endif

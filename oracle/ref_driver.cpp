@@ -18,6 +18,8 @@
 //   ref_driver load    <in.bin> <out.bin>        LoadSample normalisation front end (SampleAnalyser.cpp:484-718)
 //   ref_driver efflen  <in.bin> <out.bin>        effective lengths at -48/-24/-12 dB per buffer (3 doubles each)
 //   ref_driver msgpack <in.bin> <out.bin>        BLOB encoding of a VR / VVR column (SqliteSampleDescriptorPool.cpp:596-713)
+//   ref_driver onsetfft <in.bin> <out.bin>       onset STFT front end of the rhythm tracker (OnsetDetector.cpp:116-160)
+//   ref_driver beattrack <in.bin> <out.bin>      aubio beat tracking pass of TRhythmTracker::CalculateTempo (bpm, confidence)
 //   ref_driver time    <n_frames> <seed>         C2 subset timing (STFT + MFCC), prints frames/s
 //
 // in.bin : int64 n_bufs ; per buffer: int64 n_samples, double[n_samples]
@@ -44,9 +46,11 @@ extern "C" {
 #include "AudioTypes/Export/AudioTypes.h"
 #include "AudioTypes/Export/Envelopes.h"
 #include "FeatureExtraction/Source/Autocorrelation.h"
+#include "AudioTypes/Export/Fourier.h"
 #include <msgpack.hpp>   // 3rdParty/Msgpack/Dist/include (header-only, version 2.1), as SqliteSampleDescriptorPool.cpp uses it
 extern "C" {
 #include "aubio.h"   // 3rdParty/Aubio/Dist/src, smpl_t = double (HAVE_AUBIO_DOUBLE, as Export/Aubio.h sets it)
+#include "tempo/beattracking.h"   // as 3rdParty/Aubio/Export/Aubio.h:21 includes it
 }
 
 static const int kSampleRate = 44100, kFft = 2048, kHop = 1024;
@@ -564,6 +568,77 @@ static int CmdTime(int64_t nframes, unsigned seed) {
   return 0;
 }
 
+// TOnsetFftProcessor::LoadFrame (OnsetDetector.cpp:116-160) for every 512/128 frame of each buffer (the loop of
+// SampleAnalyser.cpp:991-998, no duration cap): the class itself does not link here (TArray -> TMemory -> TString),
+// so its flow is restated around the reference's own TFftWindow::SFillBuffer, ooura_cdft (as TFftTransformComplex's
+// generic branch calls it, Fourier.cpp:243-262, kNoDiv), TAudioMath::Magnitude and TAudioMath::Phase.
+// out.bin: int64 frames; per frame float[2 + 255 + 255] = mDC, mNyquist, mBin[].mMagn, mBin[].mPhase
+static int CmdOnsetFft(const char* in, const char* outp) {
+  const int Fft = 512, Hop = 128, Bins = Fft / 2 - 1;
+  std::vector<double> Window(Fft), Re(Fft), Im(Fft), Inter(2 * Fft), W(Fft), Magnitude(Bins), Phase(Bins);
+  std::vector<int> Ip(Fft);
+  TFftWindow::SFillBuffer(TFftWindow::kHanning, Window.data(), Fft);
+  FILE* fi = fopen(in, "rb"); if (!fi) return 1;
+  int64_t nb = 0; if (fread(&nb, 8, 1, fi) != 1) return 1;
+  std::vector<float> res;
+  int64_t frames = 0;
+  for (int64_t b = 0; b < nb; ++b) {
+    int64_t ns = 0; if (fread(&ns, 8, 1, fi) != 1) return 1;
+    std::vector<double> x((size_t)ns);
+    if (ns && fread(x.data(), 8, (size_t)ns, fi) != (size_t)ns) return 1;
+    for (int64_t n = 0; (n + Fft - 1) < ns; n += Hop, ++frames) {
+      memcpy(Re.data(), x.data() + n, Fft * sizeof(double));     // CopyBuffer / ClearBuffer are TMemory::Copy / Zero
+      TAudioMath::MultiplyBuffers(Window.data(), Re.data(), Re.data(), Fft);
+      memset(Im.data(), 0, Fft * sizeof(double));
+      for (int i = 0; i < Fft; ++i) { Inter[2*i] = Re[i]; Inter[2*i+1] = Im[i]; }
+      Ip[0] = 0;
+      ooura_cdft(2 * Fft, 1, Inter.data(), Ip.data(), W.data());
+      for (int i = 0; i < Fft; ++i) { Re[i] = Inter[2*i]; Im[i] = Inter[2*i+1]; }
+      TAudioMath::Magnitude(Re.data(), Im.data(), Magnitude.data(), Bins);
+      TAudioMath::Phase(Re.data(), Im.data(), Phase.data(), Bins);
+      res.push_back((float)Re[0]);
+      res.push_back((float)Im[0]);
+      for (int i = 0; i < Bins; ++i) res.push_back((float)Magnitude[i]);
+      for (int i = 0; i < Bins; ++i) res.push_back((float)Phase[i]);
+    }
+  }
+  fclose(fi);
+  FILE* fo = fopen(outp, "wb"); if (!fo) return 1;
+  fwrite(&frames, 8, 1, fo);
+  fwrite(res.data(), 4, res.size(), fo);
+  fclose(fo);
+  return 0;
+}
+
+// the aubio part of TRhythmTracker::CalculateTempo (RhythmTracker.cpp:176-197): a fresh tracker of the length of the
+// (sharpened) onset series, one aubio_beattracking_do, bpm and confidence.  Each buffer of in.bin is one onset series.
+// out.bin: per buffer double bpm, double confidence
+static int CmdBeatTrack(const char* in, const char* outp) {
+  FILE* fi = fopen(in, "rb"); if (!fi) return 1;
+  int64_t nb = 0; if (fread(&nb, 8, 1, fi) != 1) return 1;
+  std::vector<double> res;
+  for (int64_t b = 0; b < nb; ++b) {
+    int64_t ns = 0; if (fread(&ns, 8, 1, fi) != 1) return 1;
+    std::vector<double> Onsets((size_t)ns);
+    if (ns && fread(Onsets.data(), 8, (size_t)ns, fi) != (size_t)ns) return 1;
+    aubio_beattracking_t* pBeatTracker = ::new_aubio_beattracking((uint_t)ns, 128, kSampleRate);
+    fvec_t BeatTrackInputVector;
+    BeatTrackInputVector.length = (uint_t)ns;
+    BeatTrackInputVector.data = Onsets.data();
+    fvec_t* pBeatTrackOutputVector = new_fvec((uint_t)ns);
+    ::aubio_beattracking_do(pBeatTracker, &BeatTrackInputVector, pBeatTrackOutputVector);
+    res.push_back(::aubio_beattracking_get_bpm(pBeatTracker));
+    res.push_back(::aubio_beattracking_get_confidence(pBeatTracker));
+    ::del_fvec(pBeatTrackOutputVector);
+    ::del_aubio_beattracking(pBeatTracker);
+  }
+  fclose(fi);
+  FILE* fo = fopen(outp, "wb"); if (!fo) return 1;
+  fwrite(res.data(), 8, res.size(), fo);
+  fclose(fo);
+  return 0;
+}
+
 int main(int argc, char** argv) {
   if (argc >= 3 && !strcmp(argv[1], "tables")) return CmdTables(argv[2]);
   if (argc >= 4 && !strcmp(argv[1], "frames")) return CmdFrames(argv[2], argv[3], argc >= 5 && atoi(argv[4]) != 0);
@@ -572,7 +647,9 @@ int main(int argc, char** argv) {
   if (argc >= 4 && !strcmp(argv[1], "load")) return CmdLoad(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "efflen")) return CmdEffectiveLength(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "msgpack")) return CmdMsgpack(argv[2], argv[3]);
+  if (argc >= 4 && !strcmp(argv[1], "onsetfft")) return CmdOnsetFft(argv[2], argv[3]);
+  if (argc >= 4 && !strcmp(argv[1], "beattrack")) return CmdBeatTrack(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "time")) return CmdTime(atoll(argv[2]), (unsigned)atoi(argv[3]));
-  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|load|efflen|msgpack|peakstest|time ...\n");
+  fprintf(stderr, "usage: ref_driver tables|frames|neighbours|load|efflen|msgpack|onsetfft|beattrack|peakstest|time ...\n");
   return 2;
 }

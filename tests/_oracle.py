@@ -41,7 +41,8 @@ def lib():
     if _lib is None:
         so = os.path.join(ORACLE_DIR, "libafx_oracle.so")
         src = os.path.join(ORACLE_DIR, "afx_oracle.c")
-        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        srcs = [src, os.path.join(ORACLE_DIR, "afx_oracle_rhythm.c"), os.path.join(ORACLE_DIR, "afx_oracle.h")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "libafx_oracle.so"],
                                   stdout=subprocess.DEVNULL)
         L = ctypes.CDLL(so)
@@ -169,6 +170,26 @@ class Oracle:
         self.L.afx_oracle_effective_length(self.h, x.ctypes.data, x.size, out.ctypes.data)
         return out
 
+    def rhythm_frames(self, n, cap=False):
+        self.L.afx_oracle_rhythm_frames.restype = ctypes.c_int64
+        self.L.afx_oracle_rhythm_frames.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int]
+        return int(self.L.afx_oracle_rhythm_frames(self.h, int(n), int(cap)))
+
+    def run_rhythm(self, x, original_rate=44100, original_samples=None, data_offset=0, cap=False):
+        """The 512/128 rhythm tracker loop: dict with onsets [2][T], sharpened [2][T], odf [2][T] and the 14 scalars
+        (RHYTHM_SCALARS order)."""
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        t = self.rhythm_frames(x.size, cap)
+        onsets, sharp, odf = (np.zeros((2, t)) for _ in range(3))
+        out = np.zeros(14)
+        self.L.afx_oracle_run_rhythm.restype = ctypes.c_int64
+        self.L.afx_oracle_run_rhythm.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                                 ctypes.c_int, ctypes.c_int64, ctypes.c_int] + [ctypes.c_void_p] * 4
+        self.L.afx_oracle_run_rhythm(self.h, x.ctypes.data, x.size, int(cap), int(original_rate),
+                                     int(x.size if original_samples is None else original_samples), int(data_offset),
+                                     onsets.ctypes.data, sharp.ctypes.data, odf.ctypes.data, out.ctypes.data)
+        return {"onsets": onsets, "sharpened": sharp, "odf": odf, "scalars": out}
+
     def run_mfcc(self, x):
         x = np.ascontiguousarray(x, dtype=np.float64)
         nf = self.num_frames(x.size, False)
@@ -176,6 +197,45 @@ class Oracle:
         if nf:
             self.L.afx_oracle_run_mfcc(self.h, x.ctypes.data, x.size, out.ctypes.data)
         return out
+
+
+RHYTHM_SCALARS = [f"rhythm_{k}_{n}" for k in ("complex", "percussive")
+                  for n in ("onset_count", "tempo", "tempo_confidence", "onset_frequency_mean", "onset_strength",
+                            "onset_contrast")] + ["rhythm_final_tempo", "rhythm_final_tempo_confidence"]
+
+
+def onset_polar(x512):
+    """TOnsetFftProcessor::LoadFrame on one frame -> float32 [2 + 255 + 255]: dc, nyquist, magnitudes, phases."""
+    x = np.ascontiguousarray(x512, dtype=np.float64)
+    assert x.size == 512
+    out = np.zeros(512, dtype=np.float32)
+    L = lib()
+    L.afx_oracle_onset_polar.restype = None
+    L.afx_oracle_onset_polar.argtypes = [ctypes.c_void_p] * 5
+    b = out.ctypes.data
+    L.afx_oracle_onset_polar(x.ctypes.data, b, b + 4, b + 8, b + 8 + 4 * 255)
+    return out
+
+
+def beattrack(df, hop=128, rate=44100):
+    """one aubio beat-tracking pass on an onset series -> (bpm, confidence)"""
+    df = np.ascontiguousarray(df, dtype=np.float64)
+    bpm, conf = ctypes.c_double(), ctypes.c_double()
+    L = lib()
+    L.afx_oracle_beattrack.restype = None
+    L.afx_oracle_beattrack.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                       ctypes.c_void_p]
+    L.afx_oracle_beattrack(df.ctypes.data, df.size, hop, rate, ctypes.byref(bpm), ctypes.byref(conf))
+    return bpm.value, conf.value
+
+
+def canny(x):
+    x = np.ascontiguousarray(x, dtype=np.float64).copy()
+    L = lib()
+    L.afx_oracle_canny.restype = None
+    L.afx_oracle_canny.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.afx_oracle_canny(x.ctypes.data, x.size)
+    return x
 
 
 def _vec(x):

@@ -10,6 +10,6 @@ from .capi import (  # noqa: F401
     D_SPECTRAL_KURTOSIS, D_SPECTRAL_ROLLOFF, D_SPECTRAL_FLATNESS, D_SPECTRAL_FLUX,
     D_SPECTRUM_BANDS, D_BAND_FEATURES, D_AMPLITUDE_PEAK, D_AMPLITUDE_RMS, D_MAGNITUDE, D_STATISTICS, NUM_STATISTICS, STAT_NAMES,
     D_AMPLITUDE_SILENCE, D_AMPLITUDE_ENVELOPE, D_SPECTRAL_COMPLEXITY, D_AUTO_CORRELATION, D_F0,
-    D_SPECTRAL_INHARMONICITY, D_TRISTIMULUS, D_EFFECTIVE_LENGTH, D_NEIGHBOURS, D_ALL_PER_FRAME,
+    D_SPECTRAL_INHARMONICITY, D_TRISTIMULUS, D_EFFECTIVE_LENGTH, D_RHYTHM, RHYTHM_SCALARS, D_NEIGHBOURS, D_ALL_PER_FRAME,
     D_C2, D_SPECTRAL_STATS, D_ALL_LOW_LEVEL, PRECISION_F64, PRECISION_F32, PCM_F32, PCM_F64,
 )

@@ -37,6 +37,10 @@ D_F0 = 1 << 19
 D_SPECTRAL_INHARMONICITY = 1 << 20
 D_TRISTIMULUS = 1 << 21
 D_EFFECTIVE_LENGTH = 1 << 22   # per buffer: [n_bufs][3]
+D_RHYTHM = 1 << 23             # per buffer: the 512/128 rhythm tracker (fetch_rhythm)
+RHYTHM_SCALARS = [f"rhythm_{k}_{n}" for k in ("complex", "percussive")
+                  for n in ("onset_count", "tempo", "tempo_confidence", "onset_frequency_mean", "onset_strength",
+                            "onset_contrast")] + ["rhythm_final_tempo", "rhythm_final_tempo_confidence"]
 NUM_STATISTICS = 13
 STAT_NAMES = ["min", "max", "median", "mean", "gmean", "variance", "centroid", "spread", "skewness",
               "kurtosis", "flatness", "dmean", "dvariance"]
@@ -56,6 +60,7 @@ EXPORTS = [
     "afx_batch_sync", "afx_batch_run_timed", "afx_batch_fetch", "afx_batch_fetch_statistics", "afx_batch_destroy",
     "afx_algorithmic_bytes_per_frame", "afx_batch_create_from_raw", "afx_batch_fetch_samples",
     "afx_host_alloc", "afx_host_free", "afx_batch_record_layout", "afx_batch_fetch_records",
+    "afx_batch_set_file_info", "afx_batch_rhythm_frames", "afx_batch_fetch_rhythm", "afx_batch_fetch_onset_functions",
 ]
 RAW_I16, RAW_I24, RAW_F32 = 0, 1, 2
 
@@ -184,6 +189,11 @@ def load_library():
     L.afx_host_alloc.argtypes = [i64]
     L.afx_host_free.argtypes = [vp]
     L.afx_host_free.restype = None
+    L.afx_batch_set_file_info.argtypes = [vp, vp]
+    L.afx_batch_rhythm_frames.restype = i64
+    L.afx_batch_rhythm_frames.argtypes = [vp, vp]
+    L.afx_batch_fetch_rhythm.argtypes = [vp, vp, vp, vp]
+    L.afx_batch_fetch_onset_functions.argtypes = [vp, vp]
     L.afx_algorithmic_bytes_per_frame.restype = i64
     L.afx_algorithmic_bytes_per_frame.argtypes = [vp, u32, i32]
     _lib = L
@@ -389,6 +399,37 @@ class Batch:
         out.stats_status = st.ctypes.data
         _check(self.L, self.L.afx_batch_fetch_statistics(self.h, ctypes.byref(out)))
         res["stats_status"] = st[:self.n_bufs]
+        return res
+
+    def set_file_info(self, info):
+        """info: per buffer (original_sample_rate, data_offset, original_samples) -- what TSampleData carries besides
+        the samples; the rhythm tracker's duration heuristics use it (SampleAnalyser.cpp:1001-1004)."""
+        a = np.zeros(max(1, self.n_bufs), dtype=[("rate", np.int32), ("offset", np.int32), ("samples", np.int64)])
+        for i, (rate, offset, samples) in enumerate(info):
+            a[i] = (rate, offset, samples)
+        _check(self.L, self.L.afx_batch_set_file_info(self.h, a.ctypes.data))
+
+    def rhythm_frames(self):
+        off = np.zeros(self.n_bufs + 1, dtype=np.int64)
+        self.L.afx_batch_rhythm_frames(self.h, off.ctypes.data)
+        return off
+
+    def fetch_rhythm(self, statistics=False, onset_functions=False):
+        """dict: "offsets" [n_bufs+1], "onsets" [T][2] (complex, percussive), "scalars" [n_bufs][14] (RHYTHM_SCALARS
+        order), optionally "onset_statistics" [n_bufs][2][13] and "onset_functions" float32 [T][2]."""
+        off = self.rhythm_frames()
+        rows = int(off[-1])
+        res = {"offsets": off, "onsets": np.zeros((rows, 2)), "scalars": np.zeros((self.n_bufs, len(RHYTHM_SCALARS)))}
+        st = np.zeros((self.n_bufs, 2, NUM_STATISTICS)) if statistics else None
+        _check(self.L, self.L.afx_batch_fetch_rhythm(self.h, res["onsets"].ctypes.data if rows else None,
+                                                     res["scalars"].ctypes.data if self.n_bufs else None,
+                                                     st.ctypes.data if statistics and self.n_bufs else None))
+        if statistics:
+            res["onset_statistics"] = st
+        if onset_functions:
+            odf = np.zeros((max(rows, 1), 2), dtype=np.float32)
+            _check(self.L, self.L.afx_batch_fetch_onset_functions(self.h, odf.ctypes.data))
+            res["onset_functions"] = odf[:rows]
         return res
 
     def close(self):

@@ -134,6 +134,12 @@ struct DeviceTables {
   void* tw32 = nullptr;
   void* post32 = nullptr;
   void* melw32 = nullptr;
+  // rhythm tracker (afx_rhythm.hip)
+  double* rt_window = nullptr;
+  double* rt_tw = nullptr;
+  double* rt_ut = nullptr;
+  double* rt_canny = nullptr;
+  double* rt_rayleigh = nullptr;
 };
 
 }  // namespace
@@ -150,9 +156,11 @@ struct Workspace {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
   Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
+  Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff;   // rhythm tracker
   size_t bytes() const {
     return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
-           efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap + queue.cap;
+           efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap + queue.cap + rt_files.cap + rt_odf.cap +
+           rt_onsets.cap + rt_scratch.cap + rt_scalars.cap + rt_stats.cap + rt_foff.cap;
   }
 };
 
@@ -201,6 +209,19 @@ struct afx_batch {
   double* d_stats = nullptr;
   unsigned* d_queue = nullptr;   // work-queue counter of the half-wave frame kernel (lives in the workspace)
   std::vector<int64_t> arena_off, used;  // per buffer: start and length (samples) of its analysed prefix in d_pcm
+  // rhythm tracker (AFX_D_RHYTHM)
+  std::vector<int64_t> rt_offset;          // [n_bufs+1]: rows of the 512/128 frames
+  std::vector<afx::RhythmFile> rt_files;   // [n_bufs]
+  std::vector<int64_t> file_samples;       // [n_bufs]: mOriginalNumberOfSamples default (the buffer's / file's own length)
+  std::vector<int32_t> file_offset;        // [n_bufs]: mDataOffset default
+  bool rt_files_dirty = false;
+  afx::RhythmFile* d_rt_files = nullptr;
+  float* d_rt_odf = nullptr;
+  double* d_rt_onsets = nullptr;
+  double* d_rt_scratch = nullptr;
+  double* d_rt_scalars = nullptr;
+  double* d_rt_stats = nullptr;
+  int64_t* d_rt_foff = nullptr;
   bool mag_wanted = false;
   bool ran = false;        // afx_batch_run has been enqueued at least once: the fetches have something to fetch
   bool halfwave = false;   // frames by the half-wave kernel: a wave walks two chunks at a time
@@ -279,10 +300,43 @@ int upload_halfwave_tables(afx_plan* p) {
   return AFX_OK;
 }
 
+// tables of the rhythm tracker (afx_rhythm.hip); transcendental values come from the host's libm like the reference's
+int upload_rhythm_tables(afx_plan* p) {
+  using C = cpx<double>;
+  const int n = 512;
+  std::vector<double> win((size_t)n);
+  const double delta = 1.0 / (double)(n - 1);   // TFftWindow::SFillBuffer, kHanning (Fourier.cpp:505, 545-551)
+  for (int i = 0; i < n; ++i) win[(size_t)i] = 0.5 * (0.5 * (1.0 - std::cos(6.2831853071795864769252867665590 * (double)i * delta)));
+  std::vector<C> tw(256), ut(256);
+  for (int n2 = 0; n2 < 16; ++n2)
+    for (int k1 = 0; k1 < 16; ++k1) tw[(size_t)n2 * 16 + k1] = twiddle<double>((long long)n2 * k1, 256);
+  for (int r = 0; r < 16; ++r)
+    for (int q = 0; q < 16; ++q) ut[(size_t)r * 16 + q] = twiddle<double>(q + 16 * r, 512);
+  std::vector<double> canny(25);                // TCannyWindow(12, 16.0)::WindowValue, CannyWindow.cpp:72-78
+  const double sq = 16.0 * 16.0;
+  for (int i = -12; i <= 12; ++i) canny[(size_t)(i + 12)] = (double)i / sq * std::exp(-1.0 * (i * i) / (2.0 * sq));
+  std::vector<double> ray((size_t)afx::kRayleighTable);   // rwv, beattracking.c:65, 105-108
+  const double rayparam = 60. * p->desc.sample_rate / 120. / 128;
+  for (int i = 0; i < afx::kRayleighTable; ++i)
+    ray[(size_t)i] = ((double)(i + 1.) / (rayparam * rayparam)) * std::exp((-((i + 1.) * (i + 1.)) / (2. * (rayparam * rayparam))));
+  auto up = [](double** dst, const void* src, size_t bytes) -> hipError_t {
+    hipError_t e = hipMalloc((void**)dst, bytes);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  HIP_TRY(up(&p->dev.rt_window, win.data(), win.size() * sizeof(double)));
+  HIP_TRY(up(&p->dev.rt_tw, tw.data(), tw.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.rt_ut, ut.data(), ut.size() * sizeof(C)));
+  HIP_TRY(up(&p->dev.rt_canny, canny.data(), canny.size() * sizeof(double)));
+  HIP_TRY(up(&p->dev.rt_rayleigh, ray.data(), ray.size() * sizeof(double)));
+  return AFX_OK;
+}
+
 int upload_tables(afx_plan* p) {
   int st = upload_tables_typed<double>(p);
   if (st != AFX_OK) return st;
   if ((st = upload_halfwave_tables(p)) != AFX_OK) return st;
+  if ((st = upload_rhythm_tables(p)) != AFX_OK) return st;
   // packed mel rows: one 64-lane row per (r, f) pair the static cover lists, in the kernel's precision
   std::vector<double> melw((size_t)afx::kMelPairs * 64, 0.0);
   int idx = 0;
@@ -309,13 +363,15 @@ void free_tables(afx_plan* p) {
   hipFree(p->dev.win); hipFree(p->dev.t1); hipFree(p->dev.t2); hipFree(p->dev.post);
   hipFree(p->dev.melw); hipFree(p->dev.dct);
   hipFree(p->dev.win32); hipFree(p->dev.tw32); hipFree(p->dev.post32); hipFree(p->dev.melw32);
+  hipFree(p->dev.rt_window); hipFree(p->dev.rt_tw); hipFree(p->dev.rt_ut); hipFree(p->dev.rt_canny); hipFree(p->dev.rt_rayleigh);
   p->dev = DeviceTables{};
 }
 
 void ws_free(Workspace* w) {
   if (!w) return;
   for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
-                            &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place, &w->queue}) hipFree(b->p);
+                            &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place, &w->queue, &w->rt_files, &w->rt_odf,
+                            &w->rt_onsets, &w->rt_scratch, &w->rt_scalars, &w->rt_stats, &w->rt_foff}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->stream) hipStreamDestroy(w->stream);
@@ -435,12 +491,18 @@ uint32_t frames_mask(uint32_t mask) {
   return m;
 }
 
-int64_t num_frames(const afx_plan* p, int64_t n_samples) {
+// SampleDataAnalyzationLength, SampleAnalyser.cpp:760-764
+int64_t analysed_length(const afx_plan* p, int64_t n_samples) {
   int64_t len = n_samples;
   if (p->desc.max_analysis_ms > 0) {
     const int64_t cap = ms_to_samples(p->desc.sample_rate, (float)p->desc.max_analysis_ms);
     len = std::min(len, cap);
   }
+  return len;
+}
+
+int64_t num_frames(const afx_plan* p, int64_t n_samples) {
+  const int64_t len = analysed_length(p, n_samples);
   if (len < p->desc.fft_size) return 0;
   return (len - p->desc.fft_size) / p->desc.hop_size + 1;  // SampleAnalyser.cpp:814
 }
@@ -586,13 +648,28 @@ int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int
 
 namespace {
 
+// SampleDurationInSeconds / OnsetOffsetInSeconds of every buffer (SampleAnalyser.cpp:1001-1004): TAudioMath::SamplesToMs
+// is float arithmetic (AudioMath.inl:134-137) and the division by the int 1000 stays in float
+void set_rhythm_context(afx_batch* b, const afx_file_info* info) {
+  for (int32_t i = 0; i < b->n_bufs; ++i) {
+    const int rate = (info && info[i].original_sample_rate > 0) ? info[i].original_sample_rate : b->plan->desc.sample_rate;
+    const int samples = (int)(info ? info[i].original_samples : b->file_samples[(size_t)i]);
+    const int offset = info ? info[i].data_offset : b->file_offset[(size_t)i];
+    afx::RhythmFile& rf = b->rt_files[(size_t)i];
+    rf.duration_s = (double)(((float)samples / ((float)rate / 1000.0f)) / 1000);
+    rf.offset_s = (double)(((float)offset / ((float)rate / 1000.0f)) / 1000);
+  }
+  b->rt_files_dirty = true;
+}
+
 // Common tail of batch creation: lengths[i] = samples of buffer i as AnalyzeLowLevelDescriptors would
 // see them; fill() puts the analysed prefix of every buffer at arena_off[i] of b->d_pcm (element
 // size esz) using b->stream.
 template <typename Fill>
 int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const std::vector<int64_t>& lengths,
                 const std::vector<int32_t>& status, bool zero_arena, Fill fill, afx_batch** out_batch,
-                Workspace* acquired = nullptr) {
+                Workspace* acquired = nullptr, const std::vector<int64_t>* file_samples = nullptr,
+                const std::vector<int32_t>* file_offset = nullptr) {
   const bool want_stats = (mask & AFX_D_STATISTICS) != 0;
   mask &= ~(uint32_t)AFX_D_STATISTICS;   // the kernels see the descriptor bits only
 
@@ -632,6 +709,8 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
       if (mask & AFX_D_AUTO_CORRELATION) keep = std::min<int64_t>(lengths[i], keep + 64);
       frames += f;
     }
+    // the rhythm tracker's 512/128 frames reach up to the end of the analysed prefix (SampleAnalyser.cpp:991)
+    if (mask & AFX_D_RHYTHM) keep = std::max(keep, analysed_length(plan, lengths[i]));
     // CalcEffectiveLength scans the whole buffer, also beyond the analysed 20 s (SampleAnalyser.cpp:754)
     if (mask & AFX_D_EFFECTIVE_LENGTH) keep = lengths[i];
     if (keep > 0) {
@@ -771,6 +850,44 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     if ((e = ws_reserve(w.stats, (size_t)n_bufs * b->lay.stride * 13 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stats)"));
     b->d_stats = (double*)w.stats.p;
   }
+  if ((mask & AFX_D_RHYTHM) && n_bufs > 0) {
+    // 512/128 frames of every buffer's analysed prefix: for (n = 0; n + 511 < length; n += 128), SampleAnalyser.cpp:991
+    b->rt_offset.assign((size_t)n_bufs + 1, 0);
+    b->rt_files.assign((size_t)n_bufs, afx::RhythmFile{});
+    b->file_samples.assign((size_t)n_bufs, 0);
+    b->file_offset.assign((size_t)n_bufs, 0);
+    int64_t rows = 0;
+    for (int i = 0; i < n_bufs; ++i) {
+      b->rt_offset[(size_t)i] = rows;
+      afx::RhythmFile& rf = b->rt_files[(size_t)i];
+      rf.sample_off = b->arena_off[i];
+      rf.frame0 = rows;
+      const int64_t len = (b->buf_status[i] == AFX_OK) ? std::min(analysed_length(plan, lengths[i]), b->used[i]) : 0;
+      rf.frames = (len >= 512) ? (int32_t)((len - 512) / 128 + 1) : 0;
+      rows += rf.frames;
+      b->file_samples[(size_t)i] = file_samples ? (*file_samples)[(size_t)i] : lengths[i];
+      b->file_offset[(size_t)i] = file_offset ? (*file_offset)[(size_t)i] : 0;
+    }
+    b->rt_offset[(size_t)n_bufs] = rows;
+    set_rhythm_context(b, nullptr);
+    if ((e = ws_reserve(w.rt_files, b->rt_files.size() * sizeof(afx::RhythmFile))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm files)"));
+    b->d_rt_files = (afx::RhythmFile*)w.rt_files.p;
+    if ((e = ws_reserve(w.rt_scalars, (size_t)n_bufs * AFX_NUM_RHYTHM_SCALARS * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm scalars)"));
+    b->d_rt_scalars = (double*)w.rt_scalars.p;
+    if (rows > 0) {
+      if ((e = ws_reserve(w.rt_odf, (size_t)rows * 2 * sizeof(float))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(onset functions)"));
+      if ((e = ws_reserve(w.rt_onsets, (size_t)rows * 2 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(onsets)"));
+      if ((e = ws_reserve(w.rt_scratch, (size_t)rows * 8 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm scratch)"));
+      b->d_rt_odf = (float*)w.rt_odf.p; b->d_rt_onsets = (double*)w.rt_onsets.p; b->d_rt_scratch = (double*)w.rt_scratch.p;
+    }
+    if (want_stats) {
+      if ((e = ws_reserve(w.rt_foff, b->rt_offset.size() * sizeof(int64_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm offsets)"));
+      b->d_rt_foff = (int64_t*)w.rt_foff.p;
+      if ((e = hipMemcpyAsync(b->d_rt_foff, b->rt_offset.data(), b->rt_offset.size() * sizeof(int64_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(rhythm offsets)"));
+      if ((e = ws_reserve(w.rt_stats, (size_t)n_bufs * 2 * 13 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm stats)"));
+      b->d_rt_stats = (double*)w.rt_stats.p;
+    }
+  }
   if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
   *out_batch = b;
   return AFX_OK;
@@ -787,20 +904,57 @@ int raw_bytes_per_sample(int format) {
   }
 }
 
-// which of the two statistics kernels the batch needs (afx_stats.hip)
-void stats_regimes(const afx_batch* b, afx::StatsArgs* sa) {
+// which of the two statistics kernels a set of series needs (afx_stats.hip)
+void stats_regimes(const std::vector<int64_t>& offset, afx::StatsArgs* sa) {
   sa->small_rows = 0;
   sa->need_long = 0;
-  for (int32_t i = 0; i < b->n_bufs; ++i) {
-    const int64_t n = b->frame_offset[i + 1] - b->frame_offset[i];
+  for (size_t i = 0; i + 1 < offset.size(); ++i) {
+    const int64_t n = offset[i + 1] - offset[i];
     if (n >= 2 && n <= 128) sa->small_rows = std::max<int32_t>(sa->small_rows, (int32_t)n);
     else sa->need_long = 1;
   }
 }
+void stats_regimes(const afx_batch* b, afx::StatsArgs* sa) { stats_regimes(b->frame_offset, sa); }
+
+// the rhythm tracker's kernels + the statistics of the two onset series (TSampleAnalyser::CalcStatistics covers them)
+int run_rhythm(afx_batch* b) {
+  if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0) return AFX_OK;
+  const afx_plan* plan = b->plan;
+  if (b->rt_files_dirty) {
+    HIP_TRY(hipMemcpyAsync(b->d_rt_files, b->rt_files.data(), b->rt_files.size() * sizeof(afx::RhythmFile), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));   // rt_files is pageable host memory that may change again
+    b->rt_files_dirty = false;
+  }
+  const float rate = (float)plan->desc.sample_rate;
+  afx::RhythmArgs ra{};
+  ra.pcm = b->d_pcm; ra.pcm_dtype = b->pcm_dtype; ra.n_files = b->n_bufs; ra.files = b->d_rt_files;
+  ra.total_frames = b->rt_offset.back(); ra.sample_rate = plan->desc.sample_rate; ra.rayleigh_n = afx::kRayleighTable;
+  ra.window = plan->dev.rt_window; ra.tw256 = plan->dev.rt_tw; ra.ut512 = plan->dev.rt_ut; ra.canny = plan->dev.rt_canny;
+  ra.rayleigh = plan->dev.rt_rayleigh;
+  // TOnsetFftProcessor::SetRelaxTime(25.0f) (OnsetDetector.cpp:105-112; MOnsetWhiteningRelaxTime, RhythmTracker.cpp:21)
+  ra.relax_coef = (float)(std::exp((-2.30258509 * (float)128) / ((float)25.0 * rate)));
+  ra.norm_complex = (float)(231.70475 / std::pow((double)512, 1.5));   // kFunctionRComplex, OnsetDetector.cpp:300-302
+  ra.norm_power = 2560.f / (float)(257 * 512);                          // kFunctionPower, OnsetDetector.cpp:277-279
+  ra.thresh[0] = (float)0.2; ra.thresh[1] = (float)0.8;                 // RhythmTracker.cpp:26, 32
+  ra.medspan = std::max(3, (int)((rate * (float)0.2) / (float)128 + 0.5f));      // OnsetDetector.cpp:262-264
+  ra.mingap[0] = (int)((rate * (float)0.06) / (float)128 + 0.5f);                 // OnsetDetector.cpp:272; RhythmTracker.cpp:28, 34
+  ra.mingap[1] = (int)((rate * (float)0.12) / (float)128 + 0.5f);
+  if (ra.medspan > 256) return fail(AFX_ERR_UNSUPPORTED, "sample rate too high for the onset detector's median span");
+  ra.odf = b->d_rt_odf; ra.onsets = b->d_rt_onsets; ra.scratch = b->d_rt_scratch; ra.scalars = b->d_rt_scalars;
+  HIP_TRY(afx::launch_rhythm(ra, b->stream));
+  if (b->d_rt_stats) {
+    afx::StatsArgs sa{};
+    sa.rec = b->d_rt_onsets; sa.frame_offset = b->d_rt_foff; sa.n_bufs = b->n_bufs; sa.stride = 2;
+    sa.stats = b->d_rt_stats;
+    stats_regimes(b->rt_offset, &sa);
+    HIP_TRY(afx::launch_stats(sa, b->stream));
+  }
+  return AFX_OK;
+}
 
 bool mask_ok(uint32_t mask) {
   return (mask & ~(uint32_t)AFX_D_STATISTICS) != 0 &&
-         !(mask & ~(uint32_t)(AFX_D_ALL_PER_FRAME | AFX_D_MAGNITUDE | AFX_D_STATISTICS | AFX_D_EFFECTIVE_LENGTH));
+         !(mask & ~(uint32_t)(AFX_D_ALL_PER_FRAME | AFX_D_MAGNITUDE | AFX_D_STATISTICS | AFX_D_EFFECTIVE_LENGTH | AFX_D_RHYTHM));
 }
 
 // first valid buffer's PCM type (the arena of a call is homogeneous); -1 when there is none
@@ -964,7 +1118,15 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     return e2 == hipSuccess ? AFX_OK : hip_fail(e2, "load_write");
   };
   // the workspace (with the staged PCM in it) moves into the batch; build_batch releases it on failure
-  return build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch, ws);
+  std::vector<int64_t> file_samples((size_t)n_bufs, 0);
+  std::vector<int32_t> file_offset((size_t)n_bufs, 0);
+  for (int i = 0; i < n_bufs; ++i)
+    if (status[i] == AFX_OK) {
+      file_samples[(size_t)i] = files[i].n_frames;                                // mOriginalNumberOfSamples, SampleAnalyser.cpp:464
+      file_offset[(size_t)i] = (int32_t)(-place[i].lead + place[i].start_pad);    // mDataOffset, SampleAnalyser.cpp:701
+    }
+  return build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch, ws, &file_samples,
+                     &file_offset);
 }
 
 int afx_batch_fetch_samples(afx_batch* b, int32_t buf, double* dst, int64_t n) {
@@ -997,7 +1159,7 @@ int afx_batch_run(afx_batch* b) {
       stats_regimes(b, &sa);
       HIP_TRY(afx::launch_stats(sa, b->stream));
     }
-    return AFX_OK;
+    return run_rhythm(b);
   }
   const DeviceTables& t = b->plan->dev;
   if (frames_mask(b->mask)) {
@@ -1058,6 +1220,10 @@ int afx_batch_run(afx_batch* b) {
     sa.stats = b->d_stats;
     stats_regimes(b, &sa);
     HIP_TRY(afx::launch_stats(sa, b->stream));
+  }
+  {
+    const int st = run_rhythm(b);
+    if (st != AFX_OK) return st;
   }
   return AFX_OK;
 }
@@ -1197,6 +1363,48 @@ int afx_batch_fetch_records(afx_batch* b, double* records, double* statistics, i
     const int st = afx_batch_fetch(b, &tmp);
     if (st != AFX_OK) return st;
   }
+  return AFX_OK;
+}
+
+int afx_batch_set_file_info(afx_batch* b, const afx_file_info* info) {
+  if (!b || !info) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  if (!(b->mask & AFX_D_RHYTHM)) return fail(AFX_ERR_INVALID_ARG, "AFX_D_RHYTHM was not in the batch mask");
+  if (b->n_bufs > 0) set_rhythm_context(b, info);
+  return AFX_OK;
+}
+
+int64_t afx_batch_rhythm_frames(const afx_batch* b, int64_t* offsets) {
+  if (!b || b->rt_offset.empty()) {
+    if (b && offsets) std::memset(offsets, 0, ((size_t)b->n_bufs + 1) * sizeof(int64_t));
+    return 0;
+  }
+  if (offsets) std::memcpy(offsets, b->rt_offset.data(), b->rt_offset.size() * sizeof(int64_t));
+  return b->rt_offset.back();
+}
+
+int afx_batch_fetch_rhythm(afx_batch* b, double* onsets, double* scalars, double* onset_statistics) {
+  if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
+  if (!(b->mask & AFX_D_RHYTHM)) return fail(AFX_ERR_INVALID_ARG, "AFX_D_RHYTHM was not in the batch mask");
+  if (!b->ran) return fail(AFX_ERR_INVALID_ARG, "afx_batch_fetch_rhythm before afx_batch_run");
+  if (b->n_bufs == 0) return AFX_OK;
+  if (onset_statistics && !b->d_rt_stats) return fail(AFX_ERR_INVALID_ARG, "AFX_D_STATISTICS was not in the batch mask");
+  HIP_TRY(hipSetDevice(b->plan->desc.device));
+  const size_t rows = (size_t)b->rt_offset.back();
+  if (onsets && rows) HIP_TRY(hipMemcpyAsync(onsets, b->d_rt_onsets, rows * 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  if (scalars) HIP_TRY(hipMemcpyAsync(scalars, b->d_rt_scalars, (size_t)b->n_bufs * AFX_NUM_RHYTHM_SCALARS * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  if (onset_statistics) HIP_TRY(hipMemcpyAsync(onset_statistics, b->d_rt_stats, (size_t)b->n_bufs * 2 * 13 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
+  return AFX_OK;
+}
+
+int afx_batch_fetch_onset_functions(afx_batch* b, float* odf) {
+  if (!b || !odf) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  if (!(b->mask & AFX_D_RHYTHM)) return fail(AFX_ERR_INVALID_ARG, "AFX_D_RHYTHM was not in the batch mask");
+  if (!b->ran) return fail(AFX_ERR_INVALID_ARG, "afx_batch_fetch_onset_functions before afx_batch_run");
+  HIP_TRY(hipSetDevice(b->plan->desc.device));
+  const size_t rows = b->rt_offset.empty() ? 0 : (size_t)b->rt_offset.back();
+  if (rows) HIP_TRY(hipMemcpyAsync(odf, b->d_rt_odf, rows * 2 * sizeof(float), hipMemcpyDeviceToHost, b->stream));
+  HIP_TRY(hipStreamSynchronize(b->stream));
   return AFX_OK;
 }
 

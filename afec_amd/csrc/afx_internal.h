@@ -203,6 +203,40 @@ struct StatsArgs {
 };
 hipError_t launch_stats(const StatsArgs& a, hipStream_t stream);
 
+// ---- rhythm tracker (SampleAnalyser.cpp:983-1048; afx_rhythm.hip) ----
+struct RhythmFile {
+  int64_t sample_off;   // first sample of the buffer in the PCM arena
+  int64_t frame0;       // first row of the buffer's 512/128 frames in the batch-wide arrays
+  int32_t frames;       // 512/128 frames of the analysed prefix (SampleAnalyser.cpp:991)
+  int32_t pad;
+  double duration_s;    // SampleDurationInSeconds (SampleAnalyser.cpp:1001-1002)
+  double offset_s;      // OnsetOffsetInSeconds    (SampleAnalyser.cpp:1003-1004)
+};
+constexpr int kRayleighTable = 8192;   // beyond it the Rayleigh weight of the beat tracker has underflowed to 0
+struct RhythmArgs {
+  const void* pcm;
+  int32_t pcm_dtype;            // AFX_PCM_*
+  int32_t n_files;
+  const RhythmFile* files;
+  int64_t total_frames;
+  int32_t sample_rate;
+  int32_t rayleigh_n;
+  const double* window;         // [512]: 0.5 x Hanning (the 1/2 of the real-input untangle folded in)
+  const double* tw256;          // [16][16] complex: w256^(n2 k1) at [n2][k1]
+  const double* ut512;          // [16][16] complex: w512^(q + 16 r) at [r][q]
+  const double* canny;          // [25]: TCannyWindow(12, 16) coefficients
+  const double* rayleigh;       // [rayleigh_n]: rwv of aubio's beat tracker
+  float relax_coef, norm_complex, norm_power;
+  float thresh[2];              // complex, percussive
+  int32_t medspan;
+  int32_t mingap[2];
+  float* odf;                   // [total_frames][2]: onset functions before median removal
+  double* onsets;               // [total_frames][2]: TRhythmTracker::Onsets (complex, percussive)
+  double* scratch;              // [8][total_frames]
+  double* scalars;              // [n_files][14]
+};
+hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream);
+
 // ---- LoadSample front end (SampleAnalyser.cpp:484-718) ----
 struct LoadFile {
   int64_t raw_off;   // byte offset of the interleaved PCM in the raw arena

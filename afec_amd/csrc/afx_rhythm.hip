@@ -1,0 +1,627 @@
+// afec_amd/csrc/afx_rhythm.hip -- the rhythm tracker behind the per-frame loop: the second, 512/128
+// loop of TSampleAnalyser::AnalyzeLowLevelDescriptors (SampleAnalyser.cpp:983-1048).
+//   TRhythmTracker                       Source/Crawler/FeatureExtraction/Source/RhythmTracker.cpp   ("RT.cpp")
+//   TOnsetFftProcessor / TOnsetDetector  Source/Core/AudioTypes/Source/OnsetDetector.cpp             ("OD.cpp")
+//   TCannyWindow                         Source/Crawler/FeatureExtraction/Source/CannyWindow.cpp     ("CW.cpp")
+//   aubio beat tracking                  3rdParty/Aubio/Dist/src/tempo/beattracking.c ("bt.c"), mathutils.c
+//
+// Two kernels, one workgroup (256 threads) per file:
+//   onset_function_kernel  rounds of 16 frames: (1) one 16-lane group per frame computes the 512-point real FFT as a
+//                          256-point complex FFT (16 x 16 in registers, one LDS exchange) + untangle, magnitude and phase
+//                          of bins 0..254 as float; (2) thread = bin walks the 16 frames in order: adaptive-max whitening
+//                          follower (double state per bin), the power term and the rectified-complex deviation of the bin;
+//                          (3) one lane per (frame, function) adds the 255 terms in the reference's order.  Nothing but the
+//                          two onset-function values per frame leaves the CU.
+//   rhythm_post_kernel     per file and function: sliding median removal + detection, Canny sharpening, autocorrelation +
+//                          comb filterbank + Rayleigh weighting of the beat tracker, peaks, strength, contrast, and the
+//                          duration heuristics of the final tempo.  Sums the reference accumulates serially are
+//                          accumulated serially here (staged through LDS, one lane adds): their value depends on the order.
+//
+// Float semantics: the reference keeps the polar spectrum, the whitened magnitudes and both onset functions in `float`;
+// every expression below has the type of its counterpart and the file is compiled without FMA contraction.  The only
+// operations that are not the reference's bit for bit are libm calls: cosf (here: double cos rounded to float, equal
+// to glibc's cosf for ~98.7 % of arguments, 1 ulp otherwise), atan2 / sqrt of FFT outputs that differ in the last
+// bits, pow / log of the contrast.
+#include "afx_internal.h"
+
+#include "afx_device.h"
+#include "afx_fft32.h"
+
+#pragma clang fp contract(off)
+
+namespace afx {
+namespace {
+
+constexpr int kRtHop = 128, kRtBins = 255;   // TempoHopSize (SampleAnalyser.cpp:986); mNumbins = 512/2 - 1 (OD.cpp:43)
+constexpr int kRound = 16;                   // frames per round
+constexpr int kRow = 257;                    // floats per row of the polar / term planes (bank spread)
+constexpr int kPlane = 272;                  // doubles per exchange plane of a 16-lane group (16 x 17)
+
+using C = f32x32::cx<double>;
+
+__device__ __forceinline__ float phase_rewrap(float p) {   // SPhaseRewrap, OD.cpp:18-22
+  constexpr float pi = (float)3.1415926535897932384626433832795, two_pi = (float)6.2831853071795864769252867665590,
+                  inv = (float)0.15915494309189533576888376337251;
+  return (p > -pi && p < pi) ? p : p + two_pi * (1.f + floorf((-pi - p) * inv));
+}
+
+__device__ __forceinline__ void load2(const float* p, double& a, double& b) {
+  const float2 v = *reinterpret_cast<const float2*>(p);
+  a = (double)v.x; b = (double)v.y;
+}
+__device__ __forceinline__ void load2(const double* p, double& a, double& b) {
+  const double2 v = *reinterpret_cast<const double2*>(p);
+  a = v.x; b = v.y;
+}
+
+// natural-order 16-point forward DFT of v (first radix-4 stage + the rest, afx_fft32.h)
+__device__ __forceinline__ void dft16(C (&v)[16]) {
+#pragma unroll
+  for (int b = 0; b < 4; ++b) f32x32::radix4(v[b], v[b + 4], v[b + 8], v[b + 12]);
+  f32x32::dft16_rest(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
+}
+
+template <typename PCM>
+__global__ __launch_bounds__(256) void onset_function_kernel(RhythmArgs a) {
+  __shared__ double s_x[kRound * kPlane];   // 34,816 B: exchange planes of the FFT stage, then the float polar / term rows
+  const RhythmFile f = a.files[blockIdx.x];
+  const int T = f.frames;
+  if (T <= 0) return;
+  const int tid = threadIdx.x, g = tid >> 4, q = tid & 15;
+  const PCM* x = reinterpret_cast<const PCM*>(a.pcm) + f.sample_off;
+  double* xg = s_x + g * kPlane;
+  float* plane_p = reinterpret_cast<float*>(s_x);      // [16][257]: magnitudes, then the power terms m^2
+  float* plane_c = plane_p + kRound * kRow;            // [16][257]: phases, then the complex-domain deviations
+  const C* tw = reinterpret_cast<const C*>(a.tw256);   // [n2][k1]: w256^(n2 k1)
+  const C* ut = reinterpret_cast<const C*>(a.ut512);   // [r][q]:   w512^(q + 16 r)
+  // state of bin `tid` across the frames of the file
+  double psp = 0.0;                         // whitening follower, OD.cpp:63-65, 186-230
+  float pred_mag = 0.f, yester_phase = 0.f, yester_diff = 0.f;   // mpOther, OD.cpp:300-305
+
+  for (int t0 = 0; t0 < T; t0 += kRound) {
+    const int nf = min(kRound, T - t0);
+    float magf[16], phf[16];
+    if (g < nf) {
+      // ---- TOnsetFftProcessor::LoadFrame (OD.cpp:116-160): window, FFT, magnitude and phase of bins 0..254 ----
+      // z[j] = (w x)[2j] + i (w x)[2j+1], j = 16 n1 + n2: lane n2 = q holds n1 = 0..15.  The window table carries the
+      // 1/2 of the real-input untangle (an exact scaling).
+      C v[16];
+      const PCM* xf = x + (int64_t)(t0 + g) * kRtHop;
+#pragma unroll
+      for (int n1 = 0; n1 < 16; ++n1) {
+        const int j = 16 * n1 + q;
+        double x0, x1, w0, w1;
+        load2(xf + 2 * j, x0, x1);
+        load2(a.window + 2 * j, w0, w1);
+        v[n1] = {w0 * x0, w1 * x1};
+      }
+      dft16(v);                                         // Y[k1][n2 = q]
+      C u[16];
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + q] = v[k1].re;
+      wave_lds_fence();
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) u[n2].re = xg[q * 17 + n2];
+      wave_lds_fence();
+#pragma unroll
+      for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + q] = v[k1].im;
+      wave_lds_fence();
+#pragma unroll
+      for (int n2 = 0; n2 < 16; ++n2) u[n2].im = xg[q * 17 + n2];
+      wave_lds_fence();
+      // lane k1 = q: factors w256^(n2 k1) fused into the first radix-4 stage of the DFT over n2
+      {
+        C w[16];
+#pragma unroll
+        for (int n2 = 1; n2 < 16; ++n2) w[n2] = tw[n2 * 16 + q];
+        f32x32::radix4_tw3(u[0], u[4], u[8], u[12], w[4], w[8], w[12]);
+#pragma unroll
+        for (int b = 1; b < 4; ++b) f32x32::radix4_tw4(u[b], u[b + 4], u[b + 8], u[b + 12], w[b], w[b + 4], w[b + 8], w[b + 12]);
+      }
+      f32x32::dft16_rest(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7], u[8], u[9], u[10], u[11], u[12], u[13], u[14], u[15]);
+      // u[r] = Z[k], k = q + 16 r.  Untangle with the partner Z[(256 - k) & 255] through the group's plane.
+      C p[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xg[q + 16 * r] = u[r].re;
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r].re = xg[(256 - (q + 16 * r)) & 255];
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) xg[q + 16 * r] = u[r].im;
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < 16; ++r) p[r].im = xg[(256 - (q + 16 * r)) & 255];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const C A = u[r], B = p[r], w = ut[r * 16 + q];
+        const double er = A.re + B.re, ei = A.im - B.im, orr = A.im + B.im, oi = B.re - A.re;
+        const double re = er + (w.re * orr - w.im * oi);
+        // the reference transform is e^{+i} (ooura_cdft(.., 1, ..), Fourier.cpp:243-262): conjugate of this one
+        double im = -(ei + (w.re * oi + w.im * orr));
+        if (q + 16 * r == 0) im = 0.0;                          // Im[0] of a real frame is +0
+        magf[r] = (float)sqrt(re * re + im * im);               // TAudioMath::Magnitude, AudioMath.cpp:497-503
+        phf[r] = (float)atan2(im, re);                          // TAudioMath::Phase, AudioMath.cpp:637-643
+      }
+    }
+    __syncthreads();   // every group is done with its exchange plane: the polar rows take the space
+    if (g < nf) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        plane_p[g * kRow + q + 16 * r] = magf[r];
+        plane_c[g * kRow + q + 16 * r] = phf[r];
+      }
+    }
+    __syncthreads();
+    // ---- thread = bin: Whiten (OD.cpp:186-240) + the terms of both onset functions (OD.cpp:380-458), frame by frame ----
+    if (tid < kRtBins) {
+      for (int fr = 0; fr < nf; ++fr) {
+        const float mg = plane_p[fr * kRow + tid], ph = plane_c[fr * kRow + tid];
+        double value = (double)fabsf(mg);
+        const double old = psp;
+        if (value < old) value = value + (old - value) * (double)a.relax_coef;
+        psp = value;
+        const double fl = (double)0.1f;                                     // mWhiteningFloor, OD.cpp:47
+        const float m = mg / (float)((fl > psp) ? fl : psp);
+        const float cur = fabsf(m);
+        float dev = 0.f;
+        if (cur > 0.01f) {                                                  // mOdfparam, OD.cpp:299
+          if (!(cur < pred_mag)) {                                          // Rectify: ignore decreasing bins
+            const float pred_phase = yester_phase + yester_diff;
+            float d = pred_phase - ph;
+            d = phase_rewrap(d);
+            const float cs = (float)cos((double)d);
+            dev = sqrtf(pred_mag * pred_mag + cur * cur - pred_mag * cur * cs);
+          }
+        }
+        pred_mag = cur;
+        const float diff = ph - yester_phase;
+        yester_phase = ph;
+        yester_diff = phase_rewrap(diff);
+        const float pw = m * m;
+        plane_p[fr * kRow + tid] = pw;
+        plane_c[fr * kRow + tid] = dev;
+        // mDC is (float)Re[0] and mBin[0].mMagn is |Re[0]|: the same float up to sign, whitened by the same follower
+        // values (psp[0] and psp[1] see the same input), so mDC^2 is the power term of bin 0
+        if (tid == 0) plane_p[fr * kRow + 255] = pw;
+      }
+    }
+    __syncthreads();
+    // ---- one lane per (frame, function): the sums in the reference's order ----
+    if (tid < 2 * nf) {
+      const int fr = tid >> 1, type = tid & 1;
+      float v;
+      if (type == 0) {          // kFunctionRComplex: double sum of the float deviations, OD.cpp:398-458
+        const float* row = plane_c + fr * kRow;
+        double total = 0.0;
+        for (int i = 0; i < kRtBins; ++i) total += (double)row[i];
+        v = (float)total;
+        v *= a.norm_complex;
+      } else {                  // kFunctionPower: float sum, OD.cpp:380-388 (mNyquist = Im[0] = 0)
+        const float* row = plane_p + fr * kRow;
+        v = (0.f * 0.f) + row[255];
+        for (int i = 0; i < kRtBins; ++i) v += row[i];
+        v *= a.norm_power;
+      }
+      a.odf[(f.frame0 + t0 + fr) * 2 + type] = v;
+    }
+    __syncthreads();
+  }
+}
+
+// ---- post kernel helpers ----------------------------------------------------------------------------------------
+
+constexpr int kStage = 1024;
+
+// sum of gen(0) .. gen(n-1) accumulated in index order (TStatistics::Sum, Statistics.cpp:236-245; fvec_sum): the terms are
+// produced by all threads, one lane adds them.  Every thread gets the result.
+template <typename Gen>
+__device__ double serial_sum(int n, Gen gen, double* s_stage, double* s_result) {
+  double acc = 0.0;
+  for (int base = 0; base < n; base += kStage) {
+    const int m = min(kStage, n - base);
+    for (int i = threadIdx.x; i < m; i += blockDim.x) s_stage[i] = gen(base + i);
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int i = 0; i < m; ++i) acc += s_stage[i];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *s_result = acc;
+  __syncthreads();
+  const double r = *s_result;
+  __syncthreads();
+  return r;
+}
+
+// TStatistics::Mean (Statistics.cpp:249-266) from the in-order sum
+__device__ __forceinline__ double mean_of(double sum, int n, double first) {
+  return (n >= 2) ? sum / (double)n : ((n == 1) ? first : 0.0);
+}
+
+// no value inside +-24 frames exceeds x[i] (RT.cpp:362-372, 643-653)
+__device__ __forceinline__ bool window_peak(const double* x, int n, int i) {
+  const double c = x[i];
+  const int lo = max(0, i - 24), hi = min(n - 1, i + 24);
+  bool ok = true;
+  for (int j = lo; j <= hi; ++j) ok = ok && !(x[j] > c);
+  return ok;
+}
+
+__device__ __forceinline__ unsigned long long order_key(double v) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
+}
+__device__ __forceinline__ double key_value(unsigned long long k) {
+  const unsigned long long u = (k >> 63) ? (k & 0x7FFFFFFFFFFFFFFFull) : ~k;
+  return __longlong_as_double((long long)u);
+}
+
+__global__ __launch_bounds__(256) void rhythm_post_kernel(RhythmArgs a) {
+  __shared__ double s_stage[kStage];
+  __shared__ double s_result[2];
+  __shared__ float s_win[512];
+  __shared__ float s_post[257];
+  __shared__ unsigned char s_cand[256];
+  __shared__ unsigned s_hist[256];
+  __shared__ int s_int[4];
+  __shared__ unsigned long long s_key;
+  const RhythmFile f = a.files[blockIdx.x];
+  const int T = f.frames, tid = threadIdx.x;
+  double* out = a.scalars + (int64_t)blockIdx.x * 14;
+  if (T <= 0) {
+    if (tid < 14) out[tid] = 0.0;
+    return;
+  }
+  const int64_t tot = a.total_frames;
+  const int rate = a.sample_rate;
+  double tempo[2] = {0.0, 0.0}, conf[2] = {0.0, 0.0};
+  int last_loud[2] = {0, 0};
+
+  for (int type = 0; type < 2; ++type) {
+    double* raw = a.scratch + (int64_t)(0 + type) * tot + f.frame0;   // TRhythmTracker::Onsets
+    double* S = a.scratch + (int64_t)(2 + type) * tot + f.frame0;     // SharpenedOnsets
+    double* W = a.scratch + (int64_t)(4 + type) * tot + f.frame0;     // convolution, then the autocorrelation, then flags
+    double* AO = a.scratch + (int64_t)(6 + type) * tot + f.frame0;    // comb filterbank output [T / 4]
+    double* o6 = out + 6 * type;
+    const float* odf = a.odf + f.frame0 * 2 + type;
+    const float thresh = a.thresh[type];
+    const int med = a.medspan, mingap = a.mingap[type];
+
+    // ---- DetectOnset (OD.cpp:549-587): median of the last `med` onset-function values removed, then the gap rule ----
+    if (tid == 0) { s_post[256] = 0.f; s_int[0] = 0; s_int[1] = 0; }   // mOdfvalpost = 0, mGapLeft = 0, onset count
+    __syncthreads();
+    for (int c0 = 0; c0 < T; c0 += 256) {
+      const int m = min(256, T - c0);
+      for (int i = tid; i < 256 + med - 1; i += 256) {
+        const int fr = c0 - (med - 1) + i;
+        s_win[i] = (fr >= 0 && fr < T) ? odf[(int64_t)fr * 2] : 0.f;
+      }
+      __syncthreads();
+      float post = 0.f;
+      if (tid < m) {
+        const float* w = s_win + tid;           // w[med-1] is this frame's value, w[0] the oldest in the span
+        const int r_hi = med >> 1, r_lo = (med & 1) ? r_hi : r_hi - 1;   // sorted[(med-1)>>1] for odd spans
+        float v_lo = 0.f, v_hi = 0.f;
+        for (int j = 0; j < med; ++j) {
+          const float c = w[j];
+          int lt = 0, le = 0;
+          for (int k = 0; k < med; ++k) {
+            lt += (w[k] < c) ? 1 : 0;
+            le += (w[k] <= c) ? 1 : 0;
+          }
+          if (lt <= r_lo && r_lo < le) v_lo = c;
+          if (lt <= r_hi && r_hi < le) v_hi = c;
+        }
+        const float median = (med & 1) ? v_hi : ((v_hi + v_lo) * 0.5f);
+        post = w[med - 1] - median;
+        s_post[tid] = post;
+      }
+      const float carried = s_post[256];        // mOdfvalpostprev of the chunk's first frame
+      __syncthreads();
+      if (tid < m) {
+        const float prev = (tid == 0) ? carried : s_post[tid - 1];
+        s_cand[tid] = ((post > thresh) && (prev <= thresh)) ? 1 : 0;
+      }
+      __syncthreads();
+      if (tid == 0) {
+        int gap = s_int[0];
+        for (int i = 0; i < m; ++i) {
+          bool det = false;
+          if (gap != 0) --gap;
+          else if (s_cand[i]) { det = true; gap = mingap; }
+          s_cand[i] = det ? 1 : 0;
+        }
+        s_int[0] = gap;
+        s_post[256] = s_post[m - 1];
+      }
+      __syncthreads();
+      if (tid < m) {
+        const double v = s_cand[tid] ? (double)post : 0.0;     // RT.cpp:109-118
+        raw[c0 + tid] = v;
+        a.onsets[(f.frame0 + c0 + tid) * 2 + type] = v;
+        if (v > (type == 0 ? 0.2 : 0.8)) atomicAdd(&s_int[1], 1);   // OnsetCount, RT.cpp:124-137
+      }
+      __syncthreads();
+    }
+    const int count = s_int[1];
+    __syncthreads();
+
+    // ---- TCannyWindow::Apply (CW.cpp:27-68) ----
+    for (int i = tid; i < T; i += 256) {
+      double sum = 0.0;
+      for (int s = -12; s < 12; ++s)
+        if (i + s >= 0 && i + s < T) sum += raw[i + s] * a.canny[s + 12];
+      W[i] = sum;
+    }
+    __syncthreads();
+    const double w_first = W[0];
+    const double mean = mean_of(serial_sum(T, [&](int i) { return W[i]; }, s_stage, s_result), T, w_first);
+    const double var = (T >= 2) ? serial_sum(T, [&](int i) { return (W[i] - mean) * (W[i] - mean); }, s_stage, s_result) / T : 0.0;
+    {
+      const double sd = sqrt(var);
+      for (int i = tid; i < T; i += 256) {
+        double z = W[i];
+        if (var > 0.0) {
+          z = (z - mean) / sd;
+          z = (0.0 > z) ? 0.0 : z;
+        }
+        S[i] = z;
+      }
+    }
+    if (tid == 0) s_int[2] = 0;
+    __syncthreads();
+
+    // ---- CalculateTempo (RT.cpp:159-234): one aubio_beattracking_do on a fresh tracker (bt.c:132-186, 273-404) ----
+    if (count >= 4) {
+      const unsigned winlen = (unsigned)T, laglen = winlen / 4;
+      for (unsigned i = tid; i < winlen; i += 256) {           // aubio_autocorr, mathutils.c:652-666
+        double t = 0.;
+        const unsigned n = winlen - i;
+        for (unsigned m = 0; m < n; ++m) t += S[m] * S[m + i];
+        W[i] = t / (double)n;
+      }
+      __syncthreads();
+      const double ray = 60. * rate / 120. / kRtHop;           // bt.c:65
+      for (unsigned i = tid; i < laglen; i += 256) {
+        double acc = 0.0;
+        if (i >= 1 && i + 1 < laglen)                          // comb filterbank, bt.c:165-172
+          for (unsigned aa = 1; aa <= 4; ++aa)
+            for (unsigned b = 1; b < 2 * aa; ++b) acc += W[i * aa + b - 1] * 1. / (2. * aa - 1.);
+        const double rw = ((int)i < a.rayleigh_n)                // Rayleigh weight, bt.c:105-108, 174
+                              ? a.rayleigh[i]
+                              : ((double)(i + 1.) / (ray * ray)) * exp((-((i + 1.) * (i + 1.)) / (2. * (ray * ray))));
+        AO[i] = acc * rw;
+      }
+      __syncthreads();
+      // fvec_max_elem (mathutils.c:268-283) starts from 0 and lets later equals win: the last index holding max(0, max)
+      {
+        double best = 0.0;
+        int pos = 0;
+        for (unsigned i = tid; i < laglen; i += 256) {
+          const double d = AO[i];
+          if (!(best > d)) { best = d; pos = (int)i; }
+        }
+        s_stage[tid] = best;
+        s_hist[tid] = (unsigned)pos;
+        __syncthreads();
+        if (tid == 0) {
+          double bv = 0.0;
+          unsigned bp = 0;
+          for (int t = 0; t < 256; ++t) {
+            const double d = s_stage[t];
+            const unsigned p = s_hist[t];
+            if (d > bv || (d == bv && p > bp)) { bv = d; bp = p; }
+          }
+          s_int[3] = (int)bp;
+        }
+        __syncthreads();
+      }
+      const unsigned maxindex = (unsigned)s_int[3];
+      __syncthreads();
+      const double acf_sum = serial_sum((int)laglen, [&](int i) { return AO[i]; }, s_stage, s_result);
+      if (tid == 0) {
+        double rp;
+        if (maxindex > 0 && laglen > 0 && maxindex < laglen - 1) {   // fvec_quadratic_peak_pos, mathutils.c:494-506
+          const double s0 = AO[maxindex - 1], s1 = AO[maxindex], s2 = AO[maxindex + 1];
+          rp = maxindex + .5 * (s0 - s2) / (s0 - 2. * s1 + s2);
+        } else rp = (double)(unsigned)ray;                     // p->rayparam is uint_t, bt.c:46, 82
+        double bp = rp;                                        // checkstate on the fresh state, bt.c:362-379
+        while (0 < bp && bp < 25) bp = bp * 2;
+        double bpm = (bp != 0) ? 60. / (kRtHop * bp / (double)rate) : 0.;
+        double cf = 0.;                                        // bt.c:435-444
+        if (acf_sum != 0.) {                                   // fvec_quadratic_peak_mag, mathutils.c:508-517
+          double mag = 0.;
+          if (!(rp >= laglen || rp < 0.)) {
+            const unsigned index = (unsigned)(rp - .5) + 1;
+            if ((double)index == rp) mag = AO[index];
+            else mag = AO[index] - .25 * (AO[index - 1] - AO[index + 1]) * (rp - index);
+          }
+          cf = mag / acf_sum;
+        }
+        cf = cf * 16.0;
+        cf = (cf < 0.0) ? 0.0 : ((cf > 1.0) ? 1.0 : cf);
+        if (bpm < 20.0 || bpm > 300.0) { cf = 0.0; bpm = 0.0; }
+        else {
+          while (bpm < 80.0) bpm *= 2.0;
+          while (bpm >= 200.0) bpm /= 2.0;
+        }
+        s_result[0] = bpm;
+        s_result[1] = cf;
+      }
+      __syncthreads();
+      tempo[type] = s_result[0];
+      conf[type] = s_result[1];
+      __syncthreads();
+    }
+
+    // ---- peaks of the sharpened onsets (RT.cpp:624-660): W <- 1 where no larger value lies within +-24 frames ----
+    for (int i = tid; i < T; i += 256) {
+      W[i] = window_peak(S, T, i) ? 1.0 : 0.0;
+      if (i >= 1 && !(S[i] < 0.1)) atomicMax(&s_int[2], i);   // last frame that is not below MPeakThreshold, RT.cpp:264-268
+    }
+    if (tid == 0) s_int[1] = 0;
+    __syncthreads();
+    last_loud[type] = s_int[2];
+    for (int i = tid; i < T; i += 256)
+      if (S[i] > 0.1 && W[i] != 0.0) atomicAdd(&s_int[1], 1);
+    __syncthreads();
+    const int n_peaks = s_int[1];
+    const double peak_sum = serial_sum(T, [&](int i) { return (S[i] > 0.1 && W[i] != 0.0) ? S[i] : 0.0; }, s_stage, s_result);
+    const double total_sum = serial_sum(T, [&](int i) { return S[i]; }, s_stage, s_result);
+
+    // ---- CalculateRhythmContrast (RT.cpp:325-412) ----
+    // threshold = sorted[(int)(0.85 (T - 1))]: radix select on the order-preserving bit pattern, 8 bits per pass
+    {
+      int k = (int)(85.0 / 100.0 * (T - 1));
+      unsigned long long prefix = 0;
+      for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        s_hist[tid] = 0;
+        __syncthreads();
+        for (int i = tid; i < T; i += 256) {
+          const unsigned long long key = order_key(S[i]);
+          if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int d = 0;
+          for (; d < 255; ++d) {
+            if (k < (int)s_hist[d]) break;
+            k -= (int)s_hist[d];
+          }
+          s_int[3] = k;
+          s_key = prefix | ((unsigned long long)d << shift);
+        }
+        __syncthreads();
+        k = s_int[3];
+        prefix = s_key;
+        __syncthreads();
+      }
+      const double threshold = key_value(prefix);
+      // serial walk with the running valley (RT.cpp:343-383)
+      if (tid == 0) { s_result[0] = 0.0; s_result[1] = 0.0; s_int[3] = 0; }
+      double valley_value = threshold, valley_at = S[0], psum = 0.0, vsum = 0.0;   // thread 0's copies are the live ones
+      int np = 0;
+      for (int c0 = 0; c0 < T; c0 += kStage) {
+        const int m = min(kStage, T - c0);
+        __syncthreads();
+        for (int i = tid; i < m; i += 256) s_stage[i] = S[c0 + i];
+        // flag: at or above the threshold and a window peak
+        for (int i = tid; i < m; i += 256)
+          reinterpret_cast<unsigned char*>(s_win)[i] = (!(S[c0 + i] < threshold) && W[c0 + i] != 0.0) ? 1 : 0;
+        __syncthreads();
+        if (tid == 0) {
+          const unsigned char* flag = reinterpret_cast<const unsigned char*>(s_win);
+          for (int i = 0; i < m; ++i) {
+            const double xv = s_stage[i];
+            if (xv < valley_value) { valley_at = xv; valley_value = xv; }
+            if (flag[i]) {
+              psum += xv;
+              vsum += valley_at;
+              ++np;
+              valley_value = xv;
+            }
+          }
+        }
+      }
+      if (tid == 0) {
+        const double total_mean = mean_of(total_sum, T, S[0]);
+        // Mean of a single-element list is the element; psum / vsum hold exactly that element then
+        const double peak_mean = mean_of(psum, np, psum);
+        const double valley_mean = mean_of(vsum, np, vsum) + 0.0001;
+        double contrast = 0.0;
+        if (peak_mean != 0.0) contrast = -1.0 * pow(peak_mean / valley_mean, 1.0 / log(total_mean + 0.0001));
+        o6[0] = (double)count;
+        o6[1] = tempo[type];
+        o6[2] = conf[type];
+        o6[3] = (double)n_peaks / (double)T * (double)kRtHop / (double)512;      // RT.cpp:288-289
+        double strength = 0.0;                                                  // RT.cpp:316-318
+        if (n_peaks) {
+          strength = mean_of(peak_sum, n_peaks, peak_sum) / 4.0;
+          strength = (strength < 0.0) ? 0.0 : ((strength > 1.0) ? 1.0 : strength);
+        }
+        o6[4] = strength;
+        o6[5] = contrast;
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- final tempo: CalculateTempoWithHeuristics on the more confident function (SampleAnalyser.cpp:1029-1048, RT.cpp:238-325) ----
+  if (tid == 0) {
+    const int type = (conf[1] > conf[0]) ? 1 : 0;
+    const double* raw = a.scratch + (int64_t)(0 + type) * tot + f.frame0;
+    double t_out = 0.0, c_out = 0.0;
+    if (tempo[type] != 0) {
+      double tp = tempo[type];
+      c_out = conf[type];
+      const double samples_per_beat = 60.0 / tp * (unsigned)rate;
+      const unsigned n_samples = (unsigned)last_loud[type] * (unsigned)kRtHop;
+      if ((double)n_samples < samples_per_beat * 3) {
+        c_out = 0.0;
+        tp = 0.0;
+      } else {
+        // GuessNumberOfBeatsFromDuration(80, 180, duration), RT.cpp:434-486
+        const double duration = f.duration_s, max_beat = 60.0 / 80.0, max_bar = 4.0 * max_beat;
+        double beats = 0.0;
+        if (duration < max_beat) beats = 0.0;
+        else if (duration < max_bar) {
+          beats = 4.0;
+          for (int divider = 2; divider >= 1; divider /= 2) {
+            if (duration < ((double)4 / (double)divider) * max_beat) { beats = 4.0 / (double)divider; break; }
+          }
+        } else {
+          for (int bars = 1; bars <= 8; bars *= 2) {
+            const double nb = 4.0 * bars;
+            if (duration / nb < max_beat) { beats = nb; break; }
+          }
+        }
+        if (beats >= 4 && beats <= 16) {
+          const double guessed = beats / (duration / 60);
+          const double delay = (double)((float)(kRtHop / 2) / ((float)rate / 1000.0f)) / 1000.0;   // SamplesToMs, AudioMath.inl:134-137
+          // OnsetMatchConfidence, RT.cpp:490-540
+          const float ms = (float)((f.offset_s + delay) * 1000);
+          const float fv = (float)rate / 1000.0f * ms;                       // MsToSamples, AudioMath.inl:127-130
+          const int offset_samples = (int)(fv + (signbit(fv) ? -0.5f : 0.5f));
+          const double spb = 60.0 / guessed * (unsigned)rate;
+          const int range = (int)((unsigned)(int)(spb / 32) / (unsigned)kRtHop);
+          const double thr = (type == 0) ? 0.2 : 0.8;
+          double strength = 0;
+          for (int i = 0; i < beats * 2; ++i) {
+            const int st = (int)(i * spb / 2.0) + offset_samples;
+            const int idx = (st + kRtHop / 2) / kRtHop;
+            double peak = 0.0;
+            for (int j = idx - range; j < idx + range; ++j)
+              if (j >= 0 && j < T) peak = (peak > raw[j]) ? peak : raw[j];
+            if (peak >= thr) strength += 1.0;
+          }
+          const double r = strength / (beats * 2) * 2.0;
+          const double g = (1.0 < r) ? 1.0 : r;
+          if ((g > 0.5) || (c_out < 0.1 && g > 0.1) || (c_out < 0.5 && fabs(guessed - tp) < 10)) {
+            tp = guessed;
+            c_out = (0.5 > g) ? 0.5 : g;
+          }
+        }
+      }
+      t_out = tp;
+    }
+    out[12] = t_out;
+    out[13] = c_out;
+  }
+}
+
+}  // namespace
+
+hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream) {
+  if (a.n_files <= 0) return hipSuccess;
+  if (a.total_frames > 0) {
+    if (a.pcm_dtype == 1) hipLaunchKernelGGL(onset_function_kernel<double>, dim3(a.n_files), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(onset_function_kernel<float>, dim3(a.n_files), dim3(256), 0, stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(rhythm_post_kernel, dim3(a.n_files), dim3(256), 0, stream, a);
+  return hipGetLastError();
+}
+
+}  // namespace afx

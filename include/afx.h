@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define AFX_VERSION 2
+#define AFX_VERSION 3
 
 /* ---- status codes (replace TReadableException on this path, SampleAnalyser.cpp:397-408) ---- */
 enum {
@@ -85,6 +85,10 @@ enum {
   AFX_D_EFFECTIVE_LENGTH = 1u << 22,     /* effectve_length_{48,24,12}dB  [n_bufs][3] seconds between the first and the
                                             last sample above -48 / -24 / -12 dB of the whole buffer (not only its
                                             analysed first 20 s) */
+  /* per file, from a second STFT of its own (512-sample frames every 128 samples): the rhythm tracker,
+   * SampleAnalyser.cpp:983-1048 (TRhythmTracker, TOnsetDetector, aubio beat tracking).  Results are fetched with
+   * afx_batch_fetch_rhythm, not through afx_out. */
+  AFX_D_RHYTHM = 1u << 23,
   AFX_D_C2 = AFX_D_MFCC,
   AFX_D_SPECTRAL_STATS = 0x1FEu,     /* bits 1..8 */
   AFX_D_ALL_LOW_LEVEL = 0x1FFFu,     /* the spectral set of SURVEY 8(a), everything except the raw magnitudes */
@@ -286,6 +290,45 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
                               afx_batch** out_batch, afx_load_info* info /* [n_bufs], optional */);
 /* the normalised samples of buffer `buf` (its analysed prefix) for the CPU-resident neighbours */
 int afx_batch_fetch_samples(afx_batch* batch, int32_t buf, double* dst, int64_t n);
+
+/* ---- rhythm tracker (AFX_D_RHYTHM): SampleAnalyser.cpp:983-1048 ---- *
+ * Per file: the two onset series of TRhythmTracker::Onsets (one value per 512/128 frame of the analysed prefix: the
+ * median-removed onset function where an onset was detected, 0 elsewhere), and 14 scalars.  Everything runs on the GPU.
+ * The final tempo's duration heuristics need what TSampleData carries besides the samples (SampleAnalyser.cpp:
+ * 1001-1004): batches made by afx_batch_create_from_raw know it (the file's frames, the plan's rate, the data offset
+ * LoadSample produced); for afx_batch_create the defaults are the buffer's own length, the plan's rate and offset 0 --
+ * afx_batch_set_file_info overrides them (call it before afx_batch_run). */
+#define AFX_NUM_RHYTHM_SCALARS 14
+enum {
+  AFX_R_COMPLEX_ONSET_COUNT = 0,      /* rhythm_complex_onset_count            RhythmTracker.cpp:124-137 */
+  AFX_R_COMPLEX_TEMPO,                /* rhythm_complex_tempo                  :159-234 (aubio beattracking.c) */
+  AFX_R_COMPLEX_TEMPO_CONFIDENCE,     /* rhythm_complex_tempo_confidence                                */
+  AFX_R_COMPLEX_ONSET_FREQUENCY_MEAN, /* rhythm_complex_onset_frequency_mean   :270-296 */
+  AFX_R_COMPLEX_ONSET_STRENGTH,       /* rhythm_complex_onset_strength         :300-325 */
+  AFX_R_COMPLEX_ONSET_CONTRAST,       /* rhythm_complex_onset_contrast         :329-412 */
+  AFX_R_PERCUSSIVE_ONSET_COUNT,       /* the same six for the percussive (power) onset function */
+  AFX_R_PERCUSSIVE_TEMPO,
+  AFX_R_PERCUSSIVE_TEMPO_CONFIDENCE,
+  AFX_R_PERCUSSIVE_ONSET_FREQUENCY_MEAN,
+  AFX_R_PERCUSSIVE_ONSET_STRENGTH,
+  AFX_R_PERCUSSIVE_ONSET_CONTRAST,
+  AFX_R_FINAL_TEMPO,                  /* rhythm_final_tempo             SampleAnalyser.cpp:1029-1048, RhythmTracker.cpp:238-325 */
+  AFX_R_FINAL_TEMPO_CONFIDENCE        /* rhythm_final_tempo_confidence */
+};
+typedef struct {
+  int32_t original_sample_rate; /* TSampleData::mOriginalSampleRate      */
+  int32_t data_offset;          /* TSampleData::mDataOffset              */
+  int64_t original_samples;     /* TSampleData::mOriginalNumberOfSamples */
+} afx_file_info;
+int afx_batch_set_file_info(afx_batch* batch, const afx_file_info* info /* [n_bufs] */);
+/* 512/128 frames of every buffer: offsets[i] .. offsets[i+1]-1 are buffer i's rows of `onsets`; returns the total */
+int64_t afx_batch_rhythm_frames(const afx_batch* batch, int64_t* offsets /* [n_bufs+1] or NULL */);
+/* onsets [total][2] (complex, percussive), scalars [n_bufs][AFX_NUM_RHYTHM_SCALARS], onset_statistics
+ * [n_bufs][2][AFX_NUM_STATISTICS] (needs AFX_D_STATISTICS: the reference's CalcStatistics covers the two onset
+ * series).  Any destination may be NULL. */
+int afx_batch_fetch_rhythm(afx_batch* batch, double* onsets, double* scalars, double* onset_statistics);
+/* the onset functions before median removal, float [total][2]: for the parity tests */
+int afx_batch_fetch_onset_functions(afx_batch* batch, float* odf);
 
 /* Page-locked host memory for PCM and result arrays: transfers from / to such buffers run at the
  * host link's rate (pageable memory is staged by the runtime at a fraction of it). */

@@ -940,6 +940,8 @@ int run_rhythm(afx_batch* b) {
   ra.mingap[0] = (int)((rate * (float)0.06) / (float)128 + 0.5f);                 // OnsetDetector.cpp:272; RhythmTracker.cpp:28, 34
   ra.mingap[1] = (int)((rate * (float)0.12) / (float)128 + 0.5f);
   if (ra.medspan > 256) return fail(AFX_ERR_UNSUPPORTED, "sample rate too high for the onset detector's median span");
+  for (const afx::RhythmFile& rf : b->rt_files)
+    if (rf.frames <= afx::kRhythmLdsFrames) ra.lds_frames = std::max(ra.lds_frames, rf.frames);
   ra.odf = b->d_rt_odf; ra.onsets = b->d_rt_onsets; ra.scratch = b->d_rt_scratch; ra.scalars = b->d_rt_scalars;
   HIP_TRY(afx::launch_rhythm(ra, b->stream));
   if (b->d_rt_stats) {

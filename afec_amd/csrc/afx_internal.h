@@ -212,6 +212,7 @@ struct RhythmFile {
   double duration_s;    // SampleDurationInSeconds (SampleAnalyser.cpp:1001-1002)
   double offset_s;      // OnsetOffsetInSeconds    (SampleAnalyser.cpp:1003-1004)
 };
+constexpr int kRhythmLdsFrames = 8192;   // longest onset series the post kernel stages in LDS (64 KiB; 20 s = 6887 frames)
 constexpr int kRayleighTable = 8192;   // beyond it the Rayleigh weight of the beat tracker has underflowed to 0
 struct RhythmArgs {
   const void* pcm;
@@ -230,6 +231,7 @@ struct RhythmArgs {
   float thresh[2];              // complex, percussive
   int32_t medspan;
   int32_t mingap[2];
+  int32_t lds_frames;           // frames of the longest file that fits kRhythmLdsFrames (0: none)
   float* odf;                   // [total_frames][2]: onset functions before median removal
   double* onsets;               // [total_frames][2]: TRhythmTracker::Onsets (complex, percussive)
   double* scratch;              // [8][total_frames]

@@ -191,16 +191,29 @@ __global__ __launch_bounds__(256) void onset_function_kernel(RhythmArgs a) {
     if (tid < 2 * nf) {
       const int fr = tid >> 1, type = tid & 1;
       float v;
+      // 255 terms added in bin order, 15 at a time in registers so that the LDS reads of a group are in flight together
       if (type == 0) {          // kFunctionRComplex: double sum of the float deviations, OD.cpp:398-458
         const float* row = plane_c + fr * kRow;
         double total = 0.0;
-        for (int i = 0; i < kRtBins; ++i) total += (double)row[i];
+        for (int i0 = 0; i0 < kRtBins; i0 += 15) {
+          float t[15];
+#pragma unroll
+          for (int k = 0; k < 15; ++k) t[k] = row[i0 + k];
+#pragma unroll
+          for (int k = 0; k < 15; ++k) total += (double)t[k];
+        }
         v = (float)total;
         v *= a.norm_complex;
       } else {                  // kFunctionPower: float sum, OD.cpp:380-388 (mNyquist = Im[0] = 0)
         const float* row = plane_p + fr * kRow;
         v = (0.f * 0.f) + row[255];
-        for (int i = 0; i < kRtBins; ++i) v += row[i];
+        for (int i0 = 0; i0 < kRtBins; i0 += 15) {
+          float t[15];
+#pragma unroll
+          for (int k = 0; k < 15; ++k) t[k] = row[i0 + k];
+#pragma unroll
+          for (int k = 0; k < 15; ++k) v += t[k];
+        }
         v *= a.norm_power;
       }
       a.odf[(f.frame0 + t0 + fr) * 2 + type] = v;
@@ -212,6 +225,7 @@ __global__ __launch_bounds__(256) void onset_function_kernel(RhythmArgs a) {
 // ---- post kernel helpers ----------------------------------------------------------------------------------------
 
 constexpr int kStage = 1024;
+constexpr int kMaxLdsFrames = kRhythmLdsFrames;
 
 // sum of gen(0) .. gen(n-1) accumulated in index order (TStatistics::Sum, Statistics.cpp:236-245; fvec_sum): the terms are
 // produced by all threads, one lane adds them.  Every thread gets the result.
@@ -222,8 +236,15 @@ __device__ double serial_sum(int n, Gen gen, double* s_stage, double* s_result) 
     const int m = min(kStage, n - base);
     for (int i = threadIdx.x; i < m; i += blockDim.x) s_stage[i] = gen(base + i);
     __syncthreads();
-    if (threadIdx.x == 0)
-      for (int i = 0; i < m; ++i) acc += s_stage[i];
+    if (threadIdx.x == 0) {
+      int i = 0;
+      for (; i + 8 <= m; i += 8) {       // eight values in flight, added in order
+        const double2 p0 = *reinterpret_cast<const double2*>(s_stage + i), p1 = *reinterpret_cast<const double2*>(s_stage + i + 2),
+                      p2 = *reinterpret_cast<const double2*>(s_stage + i + 4), p3 = *reinterpret_cast<const double2*>(s_stage + i + 6);
+        acc += p0.x; acc += p0.y; acc += p1.x; acc += p1.y; acc += p2.x; acc += p2.y; acc += p3.x; acc += p3.y;
+      }
+      for (; i < m; ++i) acc += s_stage[i];
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) *s_result = acc;
@@ -247,6 +268,39 @@ __device__ __forceinline__ bool window_peak(const double* x, int n, int i) {
   return ok;
 }
 
+// aubio_autocorr (mathutils.c:652-666): acf[i] = (sum_m S[m] S[m+i]) / (T - i), every lag accumulated in the order of m.
+// A thread owns four consecutive lags and slides a four-value register window over S, so that four multiply-adds cost
+// one broadcast read of S[m] and one read of S[m+i+3]; with the series staged in LDS as four planes (S[4q+r] at plane
+// r, slot q) the second read is conflict-free.
+template <bool STAGED>
+__device__ __forceinline__ void autocorrelation(const double* S, const double* lds, int plane, int T, double* acf) {
+  auto at = [&](int j) -> double { return STAGED ? lds[(j & 3) * plane + (j >> 2)] : S[j]; };
+  for (int base = 4 * (int)threadIdx.x; base < T; base += 4 * 256) {
+    double a0 = 0., a1 = 0., a2 = 0., a3 = 0.;
+    const int n3 = T - base - 3;                 // terms of lag base + 3
+    int m = 0;
+    if (n3 > 0) {
+      double x0 = at(base), x1 = at(base + 1), x2 = at(base + 2);
+#pragma unroll 4
+      for (; m < n3; ++m) {
+        const double sm = at(m), x3 = at(m + base + 3);
+        a0 += sm * x0; a1 += sm * x1; a2 += sm * x2; a3 += sm * x3;
+        x0 = x1; x1 = x2; x2 = x3;
+      }
+    }
+    for (; m + base < T; ++m) {                  // the up to three last terms of the shorter lags
+      const double sm = at(m);
+      a0 += sm * at(m + base);
+      if (m + base + 1 < T) a1 += sm * at(m + base + 1);
+      if (m + base + 2 < T) a2 += sm * at(m + base + 2);
+    }
+    acf[base] = a0 / (double)(T - base);
+    if (base + 1 < T) acf[base + 1] = a1 / (double)(T - base - 1);
+    if (base + 2 < T) acf[base + 2] = a2 / (double)(T - base - 2);
+    if (base + 3 < T) acf[base + 3] = a3 / (double)(T - base - 3);
+  }
+}
+
 __device__ __forceinline__ unsigned long long order_key(double v) {
   const unsigned long long u = (unsigned long long)__double_as_longlong(v);
   return (u >> 63) ? ~u : (u | 0x8000000000000000ull);
@@ -257,11 +311,15 @@ __device__ __forceinline__ double key_value(unsigned long long k) {
 }
 
 __global__ __launch_bounds__(256) void rhythm_post_kernel(RhythmArgs a) {
-  __shared__ double s_stage[kStage];
+  __shared__ __align__(16) double s_stage[kStage];
   __shared__ double s_result[2];
-  __shared__ float s_win[512];
+  __shared__ float s_win[520];
+  extern __shared__ double s_series[];     // the sharpened onsets of the file, de-interleaved by 4, when they fit
   __shared__ float s_post[257];
-  __shared__ unsigned char s_cand[256];
+  __shared__ float s_vlo[256], s_vhi[256];
+  __shared__ unsigned long long s_mask[4];
+  __shared__ int s_wsum[4];
+  __shared__ unsigned s_flagbits[kStage / 32];
   __shared__ unsigned s_hist[256];
   __shared__ int s_int[4];
   __shared__ unsigned long long s_key;
@@ -292,51 +350,71 @@ __global__ __launch_bounds__(256) void rhythm_post_kernel(RhythmArgs a) {
     __syncthreads();
     for (int c0 = 0; c0 < T; c0 += 256) {
       const int m = min(256, T - c0);
-      for (int i = tid; i < 256 + med - 1; i += 256) {
+      for (int i = tid; i < 256 + med; i += 256) {
         const int fr = c0 - (med - 1) + i;
         s_win[i] = (fr >= 0 && fr < T) ? odf[(int64_t)fr * 2] : 0.f;
       }
       __syncthreads();
+      // Median of every span by rank: element e of the staged values is the rank-r value of a span when fewer than
+      // r + 1 values of the span lie below it and more than r do not exceed it.  Its rank is counted once for the first
+      // span that holds it and updated by the value that leaves and the one that enters for the next ones.
+      const int r_hi = med >> 1, r_lo = (med & 1) ? r_hi : r_hi - 1;   // sorted[(med-1)>>1] for odd spans
+      for (int e = tid; e < m + med - 1; e += 256) {
+        const float c = s_win[e];
+        const int fi0 = max(0, e - (med - 1)), fi1 = min(m - 1, e);
+        int lt = 0, le = 0;
+        for (int k = 0; k < med; ++k) {
+          const float w = s_win[fi0 + k];
+          lt += (w < c) ? 1 : 0;
+          le += (w <= c) ? 1 : 0;
+        }
+        for (int fi = fi0; fi <= fi1; ++fi) {
+          if (lt <= r_lo && r_lo < le) s_vlo[fi] = c;
+          if (lt <= r_hi && r_hi < le) s_vhi[fi] = c;
+          if (fi < fi1) {
+            const float gone = s_win[fi], come = s_win[fi + med];
+            lt += ((come < c) ? 1 : 0) - ((gone < c) ? 1 : 0);
+            le += ((come <= c) ? 1 : 0) - ((gone <= c) ? 1 : 0);
+          }
+        }
+      }
+      __syncthreads();
       float post = 0.f;
       if (tid < m) {
-        const float* w = s_win + tid;           // w[med-1] is this frame's value, w[0] the oldest in the span
-        const int r_hi = med >> 1, r_lo = (med & 1) ? r_hi : r_hi - 1;   // sorted[(med-1)>>1] for odd spans
-        float v_lo = 0.f, v_hi = 0.f;
-        for (int j = 0; j < med; ++j) {
-          const float c = w[j];
-          int lt = 0, le = 0;
-          for (int k = 0; k < med; ++k) {
-            lt += (w[k] < c) ? 1 : 0;
-            le += (w[k] <= c) ? 1 : 0;
-          }
-          if (lt <= r_lo && r_lo < le) v_lo = c;
-          if (lt <= r_hi && r_hi < le) v_hi = c;
-        }
+        const float v_lo = s_vlo[tid], v_hi = s_vhi[tid];
         const float median = (med & 1) ? v_hi : ((v_hi + v_lo) * 0.5f);
-        post = w[med - 1] - median;
+        post = s_win[tid + med - 1] - median;      // this frame's value is the newest of its span
         s_post[tid] = post;
       }
       const float carried = s_post[256];        // mOdfvalpostprev of the chunk's first frame
       __syncthreads();
-      if (tid < m) {
-        const float prev = (tid == 0) ? carried : s_post[tid - 1];
-        s_cand[tid] = ((post > thresh) && (prev <= thresh)) ? 1 : 0;
+      {
+        // candidates (post > thresh, previous <= thresh) as one 64-bit mask per wave; the gap rule (mGapLeft) walks the
+        // set bits only: after a detection at frame p the next one is allowed from frame p + mingap + 1
+        const float prev = (tid == 0) ? carried : s_post[(tid > 0) ? tid - 1 : 0];
+        const bool cand = (tid < m) && (post > thresh) && (prev <= thresh);
+        const unsigned long long mask = __ballot(cand);
+        if ((tid & 63) == 0) s_mask[tid >> 6] = mask;
       }
       __syncthreads();
       if (tid == 0) {
-        int gap = s_int[0];
-        for (int i = 0; i < m; ++i) {
-          bool det = false;
-          if (gap != 0) --gap;
-          else if (s_cand[i]) { det = true; gap = mingap; }
-          s_cand[i] = det ? 1 : 0;
+        int next_allowed = s_int[0];
+        for (int w = 0; w < 4; ++w) {
+          unsigned long long mk = s_mask[w], det = 0;
+          while (mk) {
+            const int bit = __ffsll((long long)mk) - 1;
+            mk &= mk - 1;
+            const int fr = c0 + 64 * w + bit;
+            if (fr >= next_allowed) { det |= 1ull << bit; next_allowed = fr + mingap + 1; }
+          }
+          s_mask[w] = det;
         }
-        s_int[0] = gap;
+        s_int[0] = next_allowed;
         s_post[256] = s_post[m - 1];
       }
       __syncthreads();
       if (tid < m) {
-        const double v = s_cand[tid] ? (double)post : 0.0;     // RT.cpp:109-118
+        const double v = ((s_mask[tid >> 6] >> (tid & 63)) & 1) ? (double)post : 0.0;     // RT.cpp:109-118
         raw[c0 + tid] = v;
         a.onsets[(f.frame0 + c0 + tid) * 2 + type] = v;
         if (v > (type == 0 ? 0.2 : 0.8)) atomicAdd(&s_int[1], 1);   // OnsetCount, RT.cpp:124-137
@@ -373,13 +451,13 @@ __global__ __launch_bounds__(256) void rhythm_post_kernel(RhythmArgs a) {
 
     // ---- CalculateTempo (RT.cpp:159-234): one aubio_beattracking_do on a fresh tracker (bt.c:132-186, 273-404) ----
     if (count >= 4) {
-      const unsigned winlen = (unsigned)T, laglen = winlen / 4;
-      for (unsigned i = tid; i < winlen; i += 256) {           // aubio_autocorr, mathutils.c:652-666
-        double t = 0.;
-        const unsigned n = winlen - i;
-        for (unsigned m = 0; m < n; ++m) t += S[m] * S[m + i];
-        W[i] = t / (double)n;
-      }
+      const unsigned laglen = (unsigned)T / 4;
+      const int plane = (a.lds_frames + 3) >> 2;
+      if (T <= a.lds_frames) {
+        for (int i = tid; i < T; i += 256) s_series[(i & 3) * plane + (i >> 2)] = S[i];
+        __syncthreads();
+        autocorrelation<true>(S, s_series, plane, T, W);
+      } else autocorrelation<false>(S, s_series, plane, T, W);
       __syncthreads();
       const double ray = 60. * rate / 120. / kRtHop;           // bt.c:65
       for (unsigned i = tid; i < laglen; i += 256) {
@@ -401,13 +479,18 @@ __global__ __launch_bounds__(256) void rhythm_post_kernel(RhythmArgs a) {
           const double d = AO[i];
           if (!(best > d)) { best = d; pos = (int)i; }
         }
-        s_stage[tid] = best;
-        s_hist[tid] = (unsigned)pos;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {       // larger value wins, the later index among equals
+          const double d = __shfl_xor(best, o);
+          const int p = __shfl_xor(pos, o);
+          if (d > best || (d == best && p > pos)) { best = d; pos = p; }
+        }
+        if ((tid & 63) == 0) { s_stage[tid >> 6] = best; s_hist[tid >> 6] = (unsigned)pos; }
         __syncthreads();
         if (tid == 0) {
           double bv = 0.0;
           unsigned bp = 0;
-          for (int t = 0; t < 256; ++t) {
+          for (int t = 0; t < 4; ++t) {
             const double d = s_stage[t];
             const unsigned p = s_hist[t];
             if (d > bv || (d == bv && p > bp)) { bv = d; bp = p; }
@@ -483,14 +566,24 @@ __global__ __launch_bounds__(256) void rhythm_post_kernel(RhythmArgs a) {
           if (pass == 0 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&s_hist[(key >> shift) & 255], 1u);
         }
         __syncthreads();
-        if (tid == 0) {
-          int d = 0;
-          for (; d < 255; ++d) {
-            if (k < (int)s_hist[d]) break;
-            k -= (int)s_hist[d];
+        {
+          // the digit whose bin holds the k-th element: exclusive prefix sum of the 256 bins, one bin per thread
+          const int h = (int)s_hist[tid];
+          int incl = h;
+#pragma unroll
+          for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(incl, o);
+            if ((tid & 63) >= o) incl += t;
           }
-          s_int[3] = k;
-          s_key = prefix | ((unsigned long long)d << shift);
+          if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+          __syncthreads();
+          int before = 0;
+          for (int w = 0; w < (tid >> 6); ++w) before += s_wsum[w];
+          const int excl = before + incl - h;
+          if (h > 0 && excl <= k && k < excl + h) {
+            s_int[3] = k - excl;
+            s_key = prefix | ((unsigned long long)tid << shift);
+          }
         }
         __syncthreads();
         k = s_int[3];
@@ -505,21 +598,35 @@ __global__ __launch_bounds__(256) void rhythm_post_kernel(RhythmArgs a) {
       for (int c0 = 0; c0 < T; c0 += kStage) {
         const int m = min(kStage, T - c0);
         __syncthreads();
-        for (int i = tid; i < m; i += 256) s_stage[i] = S[c0 + i];
-        // flag: at or above the threshold and a window peak
-        for (int i = tid; i < m; i += 256)
-          reinterpret_cast<unsigned char*>(s_win)[i] = (!(S[c0 + i] < threshold) && W[c0 + i] != 0.0) ? 1 : 0;
+        // stage the values and, one bit per frame, "at or above the threshold and a window peak"
+        for (int i = tid; i < kStage; i += 256) {
+          const bool in = i < m;
+          const double sv = in ? S[c0 + i] : 0.0;
+          s_stage[i] = sv;
+          const bool flag = in && !(sv < threshold) && W[c0 + i] != 0.0;
+          const unsigned long long bits = __ballot(flag);
+          if ((tid & 63) == 0) { s_flagbits[i >> 5] = (unsigned)bits; s_flagbits[(i >> 5) + 1] = (unsigned)(bits >> 32); }
+        }
         __syncthreads();
         if (tid == 0) {
-          const unsigned char* flag = reinterpret_cast<const unsigned char*>(s_win);
-          for (int i = 0; i < m; ++i) {
-            const double xv = s_stage[i];
-            if (xv < valley_value) { valley_at = xv; valley_value = xv; }
-            if (flag[i]) {
-              psum += xv;
-              vsum += valley_at;
-              ++np;
-              valley_value = xv;
+          for (int i0 = 0; i0 < m; i0 += 8) {
+            const double2 p0 = *reinterpret_cast<const double2*>(s_stage + i0), p1 = *reinterpret_cast<const double2*>(s_stage + i0 + 2),
+                          p2 = *reinterpret_cast<const double2*>(s_stage + i0 + 4), p3 = *reinterpret_cast<const double2*>(s_stage + i0 + 6);
+            const double xs[8] = {p0.x, p0.y, p1.x, p1.y, p2.x, p2.y, p3.x, p3.y};
+            const unsigned fl = (s_flagbits[i0 >> 5] >> (i0 & 31)) & 0xFFu;
+            const int cnt = min(8, m - i0);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+              if (k < cnt) {
+                const double xv = xs[k];
+                if (xv < valley_value) { valley_at = xv; valley_value = xv; }
+                if ((fl >> k) & 1) {
+                  psum += xv;
+                  vsum += valley_at;
+                  ++np;
+                  valley_value = xv;
+                }
+              }
             }
           }
         }
@@ -620,7 +727,15 @@ hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(rhythm_post_kernel, dim3(a.n_files), dim3(256), 0, stream, a);
+  const size_t lds = (size_t)((a.lds_frames + 3) / 4) * 4 * sizeof(double);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rhythm_post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)(kMaxLdsFrames * sizeof(double)));
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(rhythm_post_kernel, dim3(a.n_files), dim3(256), lds, stream, a);
   return hipGetLastError();
 }
 

@@ -124,8 +124,8 @@ std::vector<TColumnSpec> LowLevelSchema() {
 
 std::vector<TColumn> LowLevelColumns(const TSampleDescriptors& D, const TSampleDataInfo* pInfo, int SampleRate) {
   std::vector<TColumn> Out;
-  // order of TSampleDescriptors::Descriptors(kLowLevelDescriptors), SampleDescriptors.cpp:150-205 (the file_* and
-  // rhythm_* descriptors in between are not produced by this library)
+  // order of TSampleDescriptors::Descriptors(kLowLevelDescriptors), SampleDescriptors.cpp:150-205 (the file_*
+  // descriptors in front come from the container, not from this library)
   Out.push_back(Real("effectve_length_48dB", D.mEffectiveLength48dB));   // [sic], SampleDescriptors.cpp:40-42
   Out.push_back(Real("effectve_length_24dB", D.mEffectiveLength24dB));
   Out.push_back(Real("effectve_length_12dB", D.mEffectiveLength12dB));
@@ -156,6 +156,23 @@ std::vector<TColumn> LowLevelColumns(const TSampleDescriptors& D, const TSampleD
   Append(Out, "tristimulus2", D.mTristimulus2);
   Append(Out, "tristimulus3", D.mTristimulus3);
   Append(Out, "auto_correlation", D.mAutoCorrelation);
+  // rhythm tracker, SampleDescriptors.cpp:180-195
+  Append(Out, "rhythm_complex_onsets", D.mRhythmComplexOnsets);
+  Out.push_back(Real("rhythm_complex_onset_count", D.mRhythmComplexOnsetCount));
+  Out.push_back(Real("rhythm_complex_onset_contrast", D.mRhythmComplexOnsetContrast));
+  Out.push_back(Real("rhythm_complex_onset_frequency_mean", D.mRhythmComplexOnsetFrequencyMean));
+  Out.push_back(Real("rhythm_complex_onset_strength", D.mRhythmComplexOnsetStrength));
+  Out.push_back(Real("rhythm_complex_tempo", D.mRhythmComplexTempo));
+  Out.push_back(Real("rhythm_complex_tempo_confidence", D.mRhythmComplexTempoConfidence));
+  Append(Out, "rhythm_percussive_onsets", D.mRhythmPercussiveOnsets);
+  Out.push_back(Real("rhythm_percussive_onset_count", D.mRhythmPercussiveOnsetCount));
+  Out.push_back(Real("rhythm_percussive_onset_contrast", D.mRhythmPercussiveOnsetContrast));
+  Out.push_back(Real("rhythm_percussive_onset_frequency_mean", D.mRhythmPercussiveOnsetFrequencyMean));
+  Out.push_back(Real("rhythm_percussive_onset_strength", D.mRhythmPercussiveOnsetStrength));
+  Out.push_back(Real("rhythm_percussive_tempo", D.mRhythmPercussiveTempo));
+  Out.push_back(Real("rhythm_percussive_tempo_confidence", D.mRhythmPercussiveTempoConfidence));
+  Out.push_back(Real("rhythm_final_tempo", D.mRhythmFinalTempo));
+  Out.push_back(Real("rhythm_final_tempo_confidence", D.mRhythmFinalTempoConfidence));
   Append(Out, "spectral_rms_bands", D.mSpectralRmsBands);
   Append(Out, "spectral_flatness_bands", D.mSpectralFlatnessBands);
   Append(Out, "spectral_flux_bands", D.mSpectralFluxBands);

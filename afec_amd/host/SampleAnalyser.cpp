@@ -89,6 +89,49 @@ const TVectorSeries<14> kSubBandSeries[] = {
 const TVectorSeries<28> kBandSeries[] = {AFEC_SERIES(spectrum_bands, mSpectrumBands)};
 #undef AFEC_SERIES
 
+// the rhythm tracker's results of file i (afx_batch_fetch_rhythm layout) -> TSampleDescriptors
+void FillRhythm(TSampleDescriptors& R, int i, const int64_t* pOffset, const double* pOnsets, const double* pScalars,
+                const double* pStatistics) {
+  const int64_t t0 = pOffset[i], nt = pOffset[i + 1] - t0;
+  R.mRhythmComplexOnsets.mValues.resize((size_t)nt);
+  R.mRhythmPercussiveOnsets.mValues.resize((size_t)nt);
+  for (int64_t t = 0; t < nt; ++t) {
+    R.mRhythmComplexOnsets.mValues[(size_t)t] = pOnsets[(t0 + t) * 2];
+    R.mRhythmPercussiveOnsets.mValues[(size_t)t] = pOnsets[(t0 + t) * 2 + 1];
+  }
+  FillStatistics(R.mRhythmComplexOnsets, pStatistics + (size_t)i * 2 * AFX_NUM_STATISTICS);
+  FillStatistics(R.mRhythmPercussiveOnsets, pStatistics + ((size_t)i * 2 + 1) * AFX_NUM_STATISTICS);
+  const double* s = pScalars + (size_t)i * AFX_NUM_RHYTHM_SCALARS;
+  R.mRhythmComplexOnsetCount = s[AFX_R_COMPLEX_ONSET_COUNT];
+  R.mRhythmComplexTempo = s[AFX_R_COMPLEX_TEMPO];
+  R.mRhythmComplexTempoConfidence = s[AFX_R_COMPLEX_TEMPO_CONFIDENCE];
+  R.mRhythmComplexOnsetFrequencyMean = s[AFX_R_COMPLEX_ONSET_FREQUENCY_MEAN];
+  R.mRhythmComplexOnsetStrength = s[AFX_R_COMPLEX_ONSET_STRENGTH];
+  R.mRhythmComplexOnsetContrast = s[AFX_R_COMPLEX_ONSET_CONTRAST];
+  R.mRhythmPercussiveOnsetCount = s[AFX_R_PERCUSSIVE_ONSET_COUNT];
+  R.mRhythmPercussiveTempo = s[AFX_R_PERCUSSIVE_TEMPO];
+  R.mRhythmPercussiveTempoConfidence = s[AFX_R_PERCUSSIVE_TEMPO_CONFIDENCE];
+  R.mRhythmPercussiveOnsetFrequencyMean = s[AFX_R_PERCUSSIVE_ONSET_FREQUENCY_MEAN];
+  R.mRhythmPercussiveOnsetStrength = s[AFX_R_PERCUSSIVE_ONSET_STRENGTH];
+  R.mRhythmPercussiveOnsetContrast = s[AFX_R_PERCUSSIVE_ONSET_CONTRAST];
+  R.mRhythmFinalTempo = s[AFX_R_FINAL_TEMPO];
+  R.mRhythmFinalTempoConfidence = s[AFX_R_FINAL_TEMPO_CONFIDENCE];
+}
+
+// TSampleData::mOriginalSampleRate / mOriginalNumberOfSamples of files the caller resampled (SampleAnalyser.cpp:464-467)
+int SetFileInfo(afx_batch* pBatch, const std::vector<TDecodedSample>& Files, const std::vector<afx_load_info>& Info, int PlanRate) {
+  bool Any = false;
+  for (const TDecodedSample& f : Files) Any = Any || f.mOriginalSampleRate > 0 || f.mOriginalNumberOfSamples > 0;
+  if (!Any) return AFX_OK;
+  std::vector<afx_file_info> FileInfo(Files.size());
+  for (size_t i = 0; i < Files.size(); ++i) {
+    FileInfo[i].original_sample_rate = Files[i].mOriginalSampleRate > 0 ? Files[i].mOriginalSampleRate : PlanRate;
+    FileInfo[i].original_samples = Files[i].mOriginalNumberOfSamples > 0 ? Files[i].mOriginalNumberOfSamples : Files[i].mNumberOfSampleFrames;
+    FileInfo[i].data_offset = Info[i].data_offset;
+  }
+  return afx_batch_set_file_info(pBatch, FileInfo.data());
+}
+
 struct TBatchGuard {
   afx_batch* mpBatch = nullptr;
   ~TBatchGuard() { afx_batch_destroy(mpBatch); }
@@ -99,7 +142,7 @@ struct TBatchGuard {
 // (SampleAnalyser.cpp:1065, 2402-2412) runs on the GPU: every per-frame series and its 13 statistics come
 // back from one resident batch.
 namespace {
-constexpr uint32_t kEverything = AFX_D_ALL_PER_FRAME | AFX_D_EFFECTIVE_LENGTH | AFX_D_STATISTICS;
+constexpr uint32_t kEverything = AFX_D_ALL_PER_FRAME | AFX_D_EFFECTIVE_LENGTH | AFX_D_RHYTHM | AFX_D_STATISTICS;
 std::vector<TSampleDescriptors> Collect(TBatchGuard& Batch, int32_t n, std::vector<std::string>* pFailed);
 }  // namespace
 
@@ -129,6 +172,7 @@ std::vector<TSampleDescriptors> TSampleAnalyser::Analyze(const std::vector<TDeco
   std::vector<afx_load_info> Info((size_t)n);
   TBatchGuard Batch;
   int Status = afx_batch_create_from_raw(mpPlan, Raws.data(), n, kEverything, &Batch.mpBatch, Info.data());
+  if (Status == AFX_OK) Status = SetFileInfo(Batch.mpBatch, Files, Info, mSampleRate);
   if (Status == AFX_OK) Status = afx_batch_run(Batch.mpBatch);
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
   if (pInfo) {
@@ -166,6 +210,11 @@ std::vector<TSampleDescriptors> Collect(TBatchGuard& Batch, int32_t n, std::vect
   StatsOut.stats_status = StatsStatus.data();
   Status = afx_batch_fetch(Batch.mpBatch, &Out);
   if (Status == AFX_OK) Status = afx_batch_fetch_statistics(Batch.mpBatch, &StatsOut);
+  std::vector<int64_t> RhythmOffset((size_t)n + 1);
+  const size_t RhythmRows = (size_t)afx_batch_rhythm_frames(Batch.mpBatch, RhythmOffset.data());
+  std::vector<double> Onsets(RhythmRows * 2), RhythmScalars((size_t)n * AFX_NUM_RHYTHM_SCALARS),
+      RhythmStatistics((size_t)n * 2 * AFX_NUM_STATISTICS);
+  if (Status == AFX_OK) Status = afx_batch_fetch_rhythm(Batch.mpBatch, Onsets.data(), RhythmScalars.data(), RhythmStatistics.data());
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
 
   std::vector<TSampleDescriptors> Results((size_t)n);
@@ -193,6 +242,7 @@ std::vector<TSampleDescriptors> Collect(TBatchGuard& Batch, int32_t n, std::vect
       Fill(R.*(S.mpDst), (Out.*(S.mpOut)) + f0 * 28, nf);
       FillStatistics(R.*(S.mpDst), (StatsOut.*(S.mpStat)) + (size_t)i * 28 * AFX_NUM_STATISTICS);
     }
+    FillRhythm(R, i, RhythmOffset.data(), Onsets.data(), RhythmScalars.data(), RhythmStatistics.data());
   }
   return Results;
 }
@@ -244,6 +294,8 @@ TSampleDescriptors TRecordBatch::Descriptors(int i) const {
   Each(kScalarSeries);
   Each(kSubBandSeries);
   Each(kBandSeries);
+  if (!mRhythmOffset.empty())
+    FillRhythm(R, i, mRhythmOffset.data(), mRhythmOnsets.data(), mRhythmScalars.data(), mRhythmStatistics.data());
   return R;
 }
 
@@ -262,13 +314,22 @@ bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files,
   afx_batch_record_layout(Batch.mpBatch, &Result.mStride, Result.mOffsets, Result.mWidths);
   const size_t Frames = (size_t)afx_batch_total_frames(Batch.mpBatch);
   if (Frames * (size_t)Result.mStride > RecordCapacity || Result.mStride > kMaxStride) return false;
-  Status = afx_batch_run(Batch.mpBatch);
+  Status = SetFileInfo(Batch.mpBatch, Files, Info, mSampleRate);
+  if (Status == AFX_OK) Status = afx_batch_run(Batch.mpBatch);
   Result.mFrameOffset.resize((size_t)n + 1);
   Result.mStatus.resize((size_t)n);
   Result.mEffectiveLength.resize((size_t)n * 3);
   if (Status == AFX_OK)
     Status = afx_batch_fetch_records(Batch.mpBatch, pRecords, pStatistics, Result.mFrameOffset.data(), Result.mStatus.data(),
                                      Result.mEffectiveLength.data());
+  Result.mRhythmOffset.resize((size_t)n + 1);
+  const size_t RhythmRows = (size_t)afx_batch_rhythm_frames(Batch.mpBatch, Result.mRhythmOffset.data());
+  Result.mRhythmOnsets.resize(RhythmRows * 2);
+  Result.mRhythmScalars.resize((size_t)n * AFX_NUM_RHYTHM_SCALARS);
+  Result.mRhythmStatistics.resize((size_t)n * 2 * AFX_NUM_STATISTICS);
+  if (Status == AFX_OK)
+    Status = afx_batch_fetch_rhythm(Batch.mpBatch, Result.mRhythmOnsets.data(), Result.mRhythmScalars.data(),
+                                    Result.mRhythmStatistics.data());
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
   Result.mpRecords = pRecords;
   Result.mpStatistics = pStatistics;

@@ -3,9 +3,9 @@
 // low-level part of TSampleDescriptors (Export/SampleDescriptors.h:152-356, 395-465).  Same names,
 // same argument meaning, errors as exceptions (TReadableException there, std::runtime_error here).
 //
-// Only what the GPU path produces is present (every per-frame low-level descriptor and its statistics; the
-// rhythm tracker, SampleAnalyser.cpp:985-1048, is not).  This layer computes nothing itself: values and
-// statistics are the GPU's, fetched through the C-ABI.
+// Only what the GPU path produces is present: every low-level descriptor and its statistics, the rhythm tracker's
+// (SampleAnalyser.cpp:985-1048) included.  This layer computes nothing itself: values and statistics are the GPU's,
+// fetched through the C-ABI.
 #pragma once
 
 #include <array>
@@ -56,6 +56,14 @@ struct TSampleDescriptors {
   TFramedVectorData<kNumberOfSpectrumBands> mSpectrumBands;
   TFramedVectorData<kNumberOfCepstrumCoefficients> mCepstrumBands;
 
+  // rhythm tracker (SampleDescriptors.h:434-452; SampleAnalyser.cpp:1006-1048): one onset value per 512/128 frame
+  TFramedScalarData mRhythmComplexOnsets, mRhythmPercussiveOnsets;
+  double mRhythmComplexOnsetCount = 0, mRhythmComplexOnsetFrequencyMean = 0, mRhythmComplexOnsetStrength = 0,
+         mRhythmComplexOnsetContrast = 0, mRhythmComplexTempo = 0, mRhythmComplexTempoConfidence = 0;
+  double mRhythmPercussiveOnsetCount = 0, mRhythmPercussiveOnsetFrequencyMean = 0, mRhythmPercussiveOnsetStrength = 0,
+         mRhythmPercussiveOnsetContrast = 0, mRhythmPercussiveTempo = 0, mRhythmPercussiveTempoConfidence = 0;
+  double mRhythmFinalTempo = 0, mRhythmFinalTempoConfidence = 0;
+
   // magnitude spectra [frame][1024] for the CPU-resident neighbours (optional)
   std::vector<double> mMagnitudeSpectrum;
 };
@@ -67,6 +75,10 @@ struct TDecodedSample {
   int mNumberOfChannels;    // 1..8
   int mSampleRate;          // 0 = the analyser's rate; other rates must be resampled by the caller
   int64_t mNumberOfSampleFrames;
+  // what the file looked like before the caller resampled it (TSampleData::mOriginalSampleRate / mOriginalNumberOfSamples,
+  // SampleAnalyser.cpp:464-467; the final tempo's duration heuristics use them); 0 = as given above
+  int mOriginalSampleRate = 0;
+  int64_t mOriginalNumberOfSamples = 0;
 };
 // what LoadSample leaves in TSampleData besides the samples (Export/SampleAnalyser.h:75-100)
 struct TSampleDataInfo {
@@ -87,6 +99,11 @@ struct TRecordBatch {
   std::vector<int32_t> mStatus;                     // [files]: AFX_OK or the per-buffer error
   std::vector<double> mEffectiveLength;             // [files][3]
   std::vector<TSampleDataInfo> mInfo;               // [files]
+  // rhythm tracker (afx_batch_fetch_rhythm)
+  std::vector<int64_t> mRhythmOffset;               // [files + 1]: rows of the 512/128 frames
+  std::vector<double> mRhythmOnsets;                // [rows][2]: complex, percussive
+  std::vector<double> mRhythmScalars;               // [files][14], AFX_R_* order
+  std::vector<double> mRhythmStatistics;            // [files][2][13]
   int NumberOfFiles() const { return (int)mStatus.size(); }
   TSampleDescriptors Descriptors(int FileIndex) const;
 };

@@ -55,6 +55,12 @@ static afec::TSampleDescriptors SyntheticDescriptors() {
   for (size_t fr = 0; fr < Frames; ++fr)
     for (size_t b = 0; b < 14; ++b) D.mCepstrumBands.mValues[fr][b] = c[fr * 14 + b];
   for (size_t b = 0; b < 14; ++b) D.mCepstrumBands.mMean[b] = (double)b / 4.0;
+  D.mRhythmComplexOnsets.mValues = ColumnValues(7, 0, 4);
+  D.mRhythmComplexOnsets.mMax = 3.25;
+  D.mRhythmPercussiveOnsetCount = 4.0;
+  D.mRhythmComplexOnsetContrast = -0.125;
+  D.mRhythmFinalTempo = 123.5;
+  D.mRhythmFinalTempoConfidence = 0.75;
   return D;
 }
 
@@ -182,6 +188,28 @@ static int TestAnalyse() {
     afx_oracle_calc_statistics(R.mF0.mValues.data(), (int)nf, s);
     CHECK_EQUAL_EPSILON(R.mF0.mMax, s[1], 0.0);
     CHECK_EQUAL_EPSILON(R.mF0.mMean, s[3], 1e-9 * std::fabs(s[3]) + 1e-12);
+    // the rhythm tracker (SampleAnalyser.cpp:983-1048): onsets of both functions, the 14 scalars, onset statistics
+    {
+      const int64_t nt = afx_oracle_rhythm_frames(o, (int64_t)Inputs[i]->size(), 1);
+      std::vector<double> onsets((size_t)nt * 2);
+      double sc[14];
+      afx_oracle_run_rhythm(o, Inputs[i]->data(), (int64_t)Inputs[i]->size(), 1, 44100, (int64_t)Inputs[i]->size(), 0,
+                            onsets.data(), nullptr, nullptr, sc);
+      CHECK((int64_t)R.mRhythmComplexOnsets.mValues.size() == nt && (int64_t)R.mRhythmPercussiveOnsets.mValues.size() == nt);
+      for (int64_t t = 0; t < nt; ++t) {
+        CHECK_EQUAL_EPSILON(R.mRhythmComplexOnsets.mValues[(size_t)t], onsets[(size_t)t], 1e-5);
+        CHECK_EQUAL_EPSILON(R.mRhythmPercussiveOnsets.mValues[(size_t)t], onsets[(size_t)(nt + t)], 1e-5);
+      }
+      const double got[14] = {R.mRhythmComplexOnsetCount, R.mRhythmComplexTempo, R.mRhythmComplexTempoConfidence,
+                              R.mRhythmComplexOnsetFrequencyMean, R.mRhythmComplexOnsetStrength, R.mRhythmComplexOnsetContrast,
+                              R.mRhythmPercussiveOnsetCount, R.mRhythmPercussiveTempo, R.mRhythmPercussiveTempoConfidence,
+                              R.mRhythmPercussiveOnsetFrequencyMean, R.mRhythmPercussiveOnsetStrength,
+                              R.mRhythmPercussiveOnsetContrast, R.mRhythmFinalTempo, R.mRhythmFinalTempoConfidence};
+      for (int k = 0; k < 14; ++k) CHECK_EQUAL_EPSILON(got[k], sc[k], 1e-5 * std::fabs(sc[k]) + 1e-9);
+      afx_oracle_calc_statistics(R.mRhythmComplexOnsets.mValues.data(), (int)nt, s);
+      CHECK_EQUAL_EPSILON(R.mRhythmComplexOnsets.mMax, s[1], 0.0);
+      CHECK_EQUAL_EPSILON(R.mRhythmComplexOnsets.mMean, s[3], 1e-9 * std::fabs(s[3]) + 1e-12);
+    }
   }
   afx_oracle_destroy(o);
 
@@ -208,6 +236,8 @@ static int TestAnalyse() {
     CHECK(FromFile[0].mSpectralCentroid.mValues == FromBuffer.mSpectralCentroid.mValues);
     CHECK(FromFile[0].mCepstrumBands.mMedian == FromBuffer.mCepstrumBands.mMedian);
     CHECK(FromFile[0].mEffectiveLength24dB == FromBuffer.mEffectiveLength24dB);
+    CHECK(FromFile[0].mRhythmComplexOnsets.mValues == FromBuffer.mRhythmComplexOnsets.mValues);
+    CHECK(FromFile[0].mRhythmPercussiveOnsetContrast == FromBuffer.mRhythmPercussiveOnsetContrast);
   }
 
   // error behaviour: an unsupported geometry throws like the reference's constructor would assert

@@ -98,6 +98,18 @@ def test_crawl_into_the_descriptor_database(tmp_path):
                 assert np.all(np.abs(got_mean - want_mean) <= 1e-4 * np.abs(want_mean) + 1e-7)
         eff = ora.effective_length(mono)
         assert abs(r["effectve_length_48dB_R"] - eff[0]) < 1e-9
+        # the rhythm tracker's columns: onsets and the scalars, with the file's own duration and the
+        # data offset LoadSample produced (SampleAnalyser.cpp:1001-1004)
+        rh = ora.run_rhythm(mono, original_samples=pcm.reshape(-1).size // ch, data_offset=info["data_offset"], cap=True)
+        for t, kind in enumerate(("rhythm_complex", "rhythm_percussive")):
+            got = np.array(msgpack.unpackb(r[kind + "_onsets_VR"]), dtype=np.float64)
+            assert got.shape == rh["onsets"][t].shape
+            assert np.array_equal(np.nonzero(got)[0], np.nonzero(rh["onsets"][t])[0]), (name, kind)
+            assert np.all(np.abs(got - rh["onsets"][t]) <= 1e-5 * np.abs(rh["onsets"][t]) + 1e-6)
+            assert abs(r[kind + "_onsets_mean_R"] - got.mean()) <= 1e-9 * abs(got.mean()) + 1e-12
+        sc = dict(zip(_oracle.RHYTHM_SCALARS, rh["scalars"]))
+        for key, want in sc.items():
+            assert r[key + "_R"] is not None and abs(r[key + "_R"] - want) <= 1e-5 * abs(want) + 1e-9, (name, key, r[key + "_R"], want)
     # the WAV sample types: the normalised buffer's length is what the reference's converters give
     for k in ("u8_mono", "i24_mono", "i32_stereo", "f32_mono", "f64_stereo"):
         r = rows[f"Formats/{k}.wav"]

@@ -47,6 +47,11 @@ def expected_columns():
     names = ["effectve_length_48dB_R", "effectve_length_24dB_R", "effectve_length_12dB_R", "analyzation_offset_R"]
     for n in SCALAR_SERIES:
         names += [n + "_VR"] + [f"{n}_{s}_R" for s in STATS]
+    for kind in ("rhythm_complex", "rhythm_percussive"):      # SampleDescriptors.cpp:180-193
+        names += [kind + "_onsets_VR"] + [f"{kind}_onsets_{s}_R" for s in STATS]
+        names += [kind + s + "_R" for s in ("_onset_count", "_onset_contrast", "_onset_frequency_mean", "_onset_strength",
+                                            "_tempo", "_tempo_confidence")]
+    names += ["rhythm_final_tempo_R", "rhythm_final_tempo_confidence_R"]
     for n in VECTOR_SERIES:
         names += [n + "_VVR"] + [f"{n}_{s}_VR" for s in STATS]
     return names
@@ -110,7 +115,8 @@ def test_column_names_and_msgpack_blobs_match_the_reference(tmp_path):
         order.append(name)
     assert pos == len(raw)
     assert order == expected_columns()
-    assert len(order) == 4 + 22 * 14 + 7 * 14
+    assert len(order) == 4 + 22 * 14 + 2 * (14 + 6) + 2 + 7 * 14        # every low-level column but the six file_* ones
+    assert cols["rhythm_complex_onsets_VR"] == column_values(7, 0, 4).tolist() and cols["rhythm_final_tempo_R"] == 123.5
     assert cols["effectve_length_48dB_R"] == 1.5 and cols["effectve_length_12dB_R"] == 0.5
     # SamplesToMs in float, then / 1000 (SampleAnalyser.cpp:748-749)
     assert cols["analyzation_offset_R"] == float(np.float32(-2205) / (np.float32(44100) / np.float32(1000))) / 1000.0
@@ -173,9 +179,13 @@ def test_descriptor_database_is_the_references_schema(tmp_path):
     assert msgpack.unpackb(ok["spectral_centroid_VR"]) == column_values(5, 0, 1).tolist()
     assert msgpack.unpackb(ok["cepstrum_bands_VVR"]) == column_values(5, 14, 3).tolist()
     assert msgpack.unpackb(ok["cepstrum_bands_mean_VR"]) == [b / 4.0 for b in range(14)]
-    # descriptors this library does not compute (the rhythm tracker): well-formed placeholders, read back the way the
-    # reference reads a "succeeded" row (every BLOB through msgpack, SqliteSampleDescriptorPool.cpp:1004-1014)
-    assert ok["rhythm_final_tempo_R"] == 0.0 and msgpack.unpackb(ok["rhythm_complex_onsets_VR"]) == []
+    # the rhythm tracker's columns (SampleDescriptors.cpp:180-195)
+    assert ok["rhythm_final_tempo_R"] == 123.5 and ok["rhythm_final_tempo_confidence_R"] == 0.75
+    assert msgpack.unpackb(ok["rhythm_complex_onsets_VR"]) == column_values(7, 0, 4).tolist()
+    assert ok["rhythm_complex_onsets_max_R"] == 3.25 and ok["rhythm_percussive_onset_count_R"] == 4.0
+    assert ok["rhythm_complex_onset_contrast_R"] == -0.125 and msgpack.unpackb(ok["rhythm_percussive_onsets_VR"]) == []
+    # every column of a "succeeded" row is well formed, read back the way the reference reads it (every BLOB through
+    # msgpack, SqliteSampleDescriptorPool.cpp:1004-1014)
     for name, kind in full_schema():
         if kind == "BLOB":
             assert isinstance(msgpack.unpackb(ok[name]), list), name

@@ -872,6 +872,9 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     set_rhythm_context(b, nullptr);
     if ((e = ws_reserve(w.rt_files, b->rt_files.size() * sizeof(afx::RhythmFile))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm files)"));
     b->d_rt_files = (afx::RhythmFile*)w.rt_files.p;
+    // (the stream is synchronised below, before the pageable source can change)
+    if ((e = hipMemcpyAsync(b->d_rt_files, b->rt_files.data(), b->rt_files.size() * sizeof(afx::RhythmFile), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(rhythm files)"));
+    b->rt_files_dirty = false;
     if ((e = ws_reserve(w.rt_scalars, (size_t)n_bufs * AFX_NUM_RHYTHM_SCALARS * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm scalars)"));
     b->d_rt_scalars = (double*)w.rt_scalars.p;
     if (rows > 0) {
@@ -920,11 +923,6 @@ void stats_regimes(const afx_batch* b, afx::StatsArgs* sa) { stats_regimes(b->fr
 int run_rhythm(afx_batch* b) {
   if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0) return AFX_OK;
   const afx_plan* plan = b->plan;
-  if (b->rt_files_dirty) {
-    HIP_TRY(hipMemcpyAsync(b->d_rt_files, b->rt_files.data(), b->rt_files.size() * sizeof(afx::RhythmFile), hipMemcpyHostToDevice, b->stream));
-    HIP_TRY(hipStreamSynchronize(b->stream));   // rt_files is pageable host memory that may change again
-    b->rt_files_dirty = false;
-  }
   const float rate = (float)plan->desc.sample_rate;
   afx::RhythmArgs ra{};
   ra.pcm = b->d_pcm; ra.pcm_dtype = b->pcm_dtype; ra.n_files = b->n_bufs; ra.files = b->d_rt_files;
@@ -1371,7 +1369,13 @@ int afx_batch_fetch_records(afx_batch* b, double* records, double* statistics, i
 int afx_batch_set_file_info(afx_batch* b, const afx_file_info* info) {
   if (!b || !info) return fail(AFX_ERR_INVALID_ARG, "null argument");
   if (!(b->mask & AFX_D_RHYTHM)) return fail(AFX_ERR_INVALID_ARG, "AFX_D_RHYTHM was not in the batch mask");
-  if (b->n_bufs > 0) set_rhythm_context(b, info);
+  if (b->n_bufs > 0) {
+    set_rhythm_context(b, info);
+    HIP_TRY(hipSetDevice(b->plan->desc.device));
+    HIP_TRY(hipMemcpyAsync(b->d_rt_files, b->rt_files.data(), b->rt_files.size() * sizeof(afx::RhythmFile), hipMemcpyHostToDevice, b->stream));
+    HIP_TRY(hipStreamSynchronize(b->stream));   // rt_files is pageable host memory that may change again
+    b->rt_files_dirty = false;
+  }
   return AFX_OK;
 }
 

@@ -83,7 +83,7 @@ struct TFinishedBatch {
   std::vector<std::string> mFailed;          // non-empty: the file is a failed sample with this reason
   std::vector<int> mBatchIndex;              // file -> index inside mResults, -1 for files that never reached the GPU
   TRecordBatch mResults;
-  std::unique_ptr<TPinned> mpRecords, mpStatistics;
+  std::unique_ptr<TPinned> mpRecords, mpStatistics, mpRhythm;
 };
 
 class TBoundedQueue {
@@ -212,6 +212,7 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
         int64_t Frames = 0, ResultBytes = 0;
         if (!Decoded.empty()) {
           Done.mpStatistics = Pool.Acquire(Decoded.size() * (size_t)TSampleAnalyser::kMaxStride * 13 * sizeof(double));
+          Done.mpRhythm = Pool.Acquire(TSampleAnalyser::RhythmDoubles(Decoded) * sizeof(double));
           // frames are at most samples / hop + 2 per file (LoadSample pads by up to a frame)
           size_t MaxFrames = 0;
           for (const TDecodedSample& s : Decoded) MaxFrames += (size_t)(s.mNumberOfSampleFrames / Options.mHopFrameSize) + 3;
@@ -220,12 +221,15 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
             if (Done.mpRecords) Done.mpRecords->Reserve(Capacity * sizeof(double));
             else Done.mpRecords = Pool.Acquire(Capacity * sizeof(double));
             if (Analyser.AnalyzeToRecords(Decoded, (double*)Done.mpRecords->mp, Done.mpRecords->mBytes / sizeof(double),
-                                          (double*)Done.mpStatistics->mp, Done.mResults))
+                                          (double*)Done.mpStatistics->mp, (double*)Done.mpRhythm->mp,
+                                          Done.mpRhythm->mBytes / sizeof(double), Done.mResults))
               break;
             Capacity *= 2;
+            Done.mpRhythm->Reserve(2 * Done.mpRhythm->mBytes);
           }
           Frames = Done.mResults.mFrameOffset.back();
-          ResultBytes = (Frames * Done.mResults.mStride + (int64_t)Decoded.size() * Done.mResults.mStride * 13) * 8;
+          ResultBytes = (Frames * Done.mResults.mStride + (int64_t)Decoded.size() * Done.mResults.mStride * 13 +
+                         Done.mResults.mRhythmOffset.back() * 2 + (int64_t)Decoded.size() * 40) * 8;
           for (size_t i = 0; i < n; ++i) {
             const int k = Done.mBatchIndex[i];
             if (k >= 0 && Done.mResults.mStatus[(size_t)k] != AFX_OK)
@@ -276,6 +280,7 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
       }
       Pool.Release(std::move(p->mpRecords));
       Pool.Release(std::move(p->mpStatistics));
+      Pool.Release(std::move(p->mpRhythm));
       std::lock_guard<std::mutex> Lock(StatMutex);
       Total.mFailedFiles += Failed;
       if (pPool) Total.mWriterSeconds += Now() - t0;

@@ -294,13 +294,21 @@ TSampleDescriptors TRecordBatch::Descriptors(int i) const {
   Each(kScalarSeries);
   Each(kSubBandSeries);
   Each(kBandSeries);
-  if (!mRhythmOffset.empty())
-    FillRhythm(R, i, mRhythmOffset.data(), mRhythmOnsets.data(), mRhythmScalars.data(), mRhythmStatistics.data());
+  if (!mRhythmOffset.empty() && mpRhythmScalars)
+    FillRhythm(R, i, mRhythmOffset.data(), mpRhythmOnsets, mpRhythmScalars, mpRhythmStatistics);
   return R;
 }
 
+// onsets [rows][2] + scalars [n][14] + onset statistics [n][2][13]; LoadSample pads a file by at most one 2048-sample
+// frame, so it has at most samples / 128 + 17 rows
+size_t TSampleAnalyser::RhythmDoubles(const std::vector<TDecodedSample>& Files) {
+  size_t Rows = 0;
+  for (const TDecodedSample& f : Files) Rows += (size_t)(f.mNumberOfSampleFrames / 128) + 17;
+  return Rows * 2 + Files.size() * (AFX_NUM_RHYTHM_SCALARS + 2 * AFX_NUM_STATISTICS);
+}
+
 bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files, double* pRecords, size_t RecordCapacity,
-                                       double* pStatistics, TRecordBatch& Result) const {
+                                       double* pStatistics, double* pRhythm, size_t RhythmCapacity, TRecordBatch& Result) const {
   const int32_t n = (int32_t)Files.size();
   std::vector<afx_raw> Raws((size_t)n);
   for (int32_t i = 0; i < n; ++i)
@@ -314,6 +322,9 @@ bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files,
   afx_batch_record_layout(Batch.mpBatch, &Result.mStride, Result.mOffsets, Result.mWidths);
   const size_t Frames = (size_t)afx_batch_total_frames(Batch.mpBatch);
   if (Frames * (size_t)Result.mStride > RecordCapacity || Result.mStride > kMaxStride) return false;
+  Result.mRhythmOffset.resize((size_t)n + 1);
+  const size_t RhythmRows = (size_t)afx_batch_rhythm_frames(Batch.mpBatch, Result.mRhythmOffset.data());
+  if (RhythmRows * 2 + (size_t)n * (AFX_NUM_RHYTHM_SCALARS + 2 * AFX_NUM_STATISTICS) > RhythmCapacity) return false;
   Status = SetFileInfo(Batch.mpBatch, Files, Info, mSampleRate);
   if (Status == AFX_OK) Status = afx_batch_run(Batch.mpBatch);
   Result.mFrameOffset.resize((size_t)n + 1);
@@ -322,14 +333,11 @@ bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files,
   if (Status == AFX_OK)
     Status = afx_batch_fetch_records(Batch.mpBatch, pRecords, pStatistics, Result.mFrameOffset.data(), Result.mStatus.data(),
                                      Result.mEffectiveLength.data());
-  Result.mRhythmOffset.resize((size_t)n + 1);
-  const size_t RhythmRows = (size_t)afx_batch_rhythm_frames(Batch.mpBatch, Result.mRhythmOffset.data());
-  Result.mRhythmOnsets.resize(RhythmRows * 2);
-  Result.mRhythmScalars.resize((size_t)n * AFX_NUM_RHYTHM_SCALARS);
-  Result.mRhythmStatistics.resize((size_t)n * 2 * AFX_NUM_STATISTICS);
-  if (Status == AFX_OK)
-    Status = afx_batch_fetch_rhythm(Batch.mpBatch, Result.mRhythmOnsets.data(), Result.mRhythmScalars.data(),
-                                    Result.mRhythmStatistics.data());
+  double* const pOnsets = pRhythm;
+  double* const pScalars = pOnsets + RhythmRows * 2;
+  double* const pOnsetStatistics = pScalars + (size_t)n * AFX_NUM_RHYTHM_SCALARS;
+  if (Status == AFX_OK) Status = afx_batch_fetch_rhythm(Batch.mpBatch, pOnsets, pScalars, pOnsetStatistics);
+  Result.mpRhythmOnsets = pOnsets; Result.mpRhythmScalars = pScalars; Result.mpRhythmStatistics = pOnsetStatistics;
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
   Result.mpRecords = pRecords;
   Result.mpStatistics = pStatistics;

@@ -99,11 +99,11 @@ struct TRecordBatch {
   std::vector<int32_t> mStatus;                     // [files]: AFX_OK or the per-buffer error
   std::vector<double> mEffectiveLength;             // [files][3]
   std::vector<TSampleDataInfo> mInfo;               // [files]
-  // rhythm tracker (afx_batch_fetch_rhythm)
+  // rhythm tracker (afx_batch_fetch_rhythm), in the caller's rhythm buffer
   std::vector<int64_t> mRhythmOffset;               // [files + 1]: rows of the 512/128 frames
-  std::vector<double> mRhythmOnsets;                // [rows][2]: complex, percussive
-  std::vector<double> mRhythmScalars;               // [files][14], AFX_R_* order
-  std::vector<double> mRhythmStatistics;            // [files][2][13]
+  const double* mpRhythmOnsets = nullptr;           // [rows][2]: complex, percussive
+  const double* mpRhythmScalars = nullptr;          // [files][14], AFX_R_* order
+  const double* mpRhythmStatistics = nullptr;       // [files][2][13]
   int NumberOfFiles() const { return (int)mStatus.size(); }
   TSampleDescriptors Descriptors(int FileIndex) const;
 };
@@ -134,11 +134,13 @@ public:
                                           std::vector<std::string>* pFailed = nullptr) const;
 
   // LoadSample + descriptors + statistics for decoded files, results left as raw records in caller memory:
-  // pRecords must hold RecordCapacity doubles, pStatistics Files.size() * 134 * 13 (kMaxStride columns).  Returns
-  // false (and leaves Batch empty) when the records do not fit RecordCapacity: call again with a larger buffer.
+  // pRecords must hold RecordCapacity doubles, pStatistics Files.size() * 134 * 13 (kMaxStride columns), pRhythm
+  // RhythmCapacity doubles (RhythmDoubles() of the files is always enough).  Returns false (and leaves Batch empty)
+  // when the records do not fit RecordCapacity or the rhythm results RhythmCapacity: call again with larger buffers.
   enum { kMaxStride = 134 };
+  static size_t RhythmDoubles(const std::vector<TDecodedSample>& Files);
   bool AnalyzeToRecords(const std::vector<TDecodedSample>& Files, double* pRecords, size_t RecordCapacity,
-                        double* pStatistics, TRecordBatch& Batch) const;
+                        double* pStatistics, double* pRhythm, size_t RhythmCapacity, TRecordBatch& Batch) const;
 
 private:
   afx_plan* mpPlan;

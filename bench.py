@@ -36,7 +36,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--buffers", type=int, default=64, help="10k-frame buffers per GPU per step")
     ap.add_argument("--precision", choices=["f64"], default="f64", help="the arithmetic the path computes in (the reference's)")
-    ap.add_argument("--mask", default="c2", choices=["c2", "star", "stats", "all", "frame", "neighbours"])
+    ap.add_argument("--mask", default="c2", choices=["c2", "star", "stats", "all", "frame", "neighbours", "everything"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
                     help="c2: --buffers x 10k-frame buffers (headline); c3: 1000 synthetic 2.0 s files, full "
                          "low-level set + per-file statistics (BASELINE.json configs[2]); c4: this rank's share "
@@ -48,8 +48,8 @@ def parse_args():
                     help="with --workload c3|c4: time the streaming host driver instead (WAV images in host memory -> RIFF "
                          "parse -> page-locked staging -> upload -> LoadSample + every descriptor + statistics -> results "
                          "back in host memory); value = frames/s including every transfer")
-    ap.add_argument("--workers", type=int, default=4, help="host threads (batches in flight) per GPU of --end-to-end")
-    ap.add_argument("--files-per-batch", type=int, default=128, help="files per GPU batch of --end-to-end")
+    ap.add_argument("--workers", type=int, default=3, help="host threads (batches in flight) per GPU of --end-to-end")
+    ap.add_argument("--files-per-batch", type=int, default=256, help="files per GPU batch of --end-to-end")
     ap.add_argument("--cpu-frames", type=int, default=30000, help="frames per CPU worker for the baseline")
     return ap.parse_args()
 
@@ -269,13 +269,17 @@ def main():
     star = (afx.D_MFCC | afx.D_SPECTRAL_RMS | afx.D_SPECTRAL_CENTROID | afx.D_SPECTRAL_SPREAD | afx.D_SPECTRAL_ROLLOFF |
             afx.D_SPECTRAL_FLATNESS)
     mask = {"c2": afx.D_C2, "star": star, "stats": afx.D_MFCC | afx.D_SPECTRAL_STATS,
-            "all": afx.D_ALL_LOW_LEVEL, "frame": afx.D_ALL_PER_FRAME, "neighbours": afx.D_NEIGHBOURS}[args.mask]
+            "all": afx.D_ALL_LOW_LEVEL, "frame": afx.D_ALL_PER_FRAME, "neighbours": afx.D_NEIGHBOURS,
+            # every low-level descriptor of the reference: the per-frame ones plus the 512/128 rhythm tracker
+            "everything": afx.D_ALL_PER_FRAME | afx.D_RHYTHM}[args.mask]
     precision = afx.PRECISION_F64
     # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)
     device = int(os.environ.get("AFX_BENCH_DEVICE", local))
     plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0)
     if args.workload in ("c3", "c4"):
-        mask = (afx.D_ALL_PER_FRAME if args.mask in ("frame", "neighbours") else afx.D_ALL_LOW_LEVEL) | afx.D_STATISTICS
+        mask = (afx.D_ALL_PER_FRAME if args.mask in ("frame", "neighbours", "everything") else afx.D_ALL_LOW_LEVEL) | afx.D_STATISTICS
+        if args.mask == "everything":
+            mask |= afx.D_RHYTHM | afx.D_EFFECTIVE_LENGTH
         channels = 1 if args.workload == "c3" else 2
         bufs = make_c3_files(1000, 1234 + rank) if args.workload == "c3" else make_c4_files(args.files, 1234 + rank)
         n_bufs = len(bufs)
@@ -322,12 +326,12 @@ def main():
     e2e = None
     if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
         try:
-            st = end_to_end("c4", 12500, device, 4, 99, repeats=2)
+            st = end_to_end("c4", 12500, device, 3, 99, repeats=2, files_per_batch=256)
             e2e = {"workload": "C4 share: 12 500 stereo 1.0 s 16-bit WAV images in host memory -> RIFF parse -> page-locked staging -> "
-                               "upload -> LoadSample + every per-frame descriptor + statistics -> records back in host memory",
+                               "upload -> LoadSample + every low-level descriptor (per-frame set and rhythm tracker) + statistics -> records back in host memory",
                    "files_per_s": st["files"] / st["seconds"], "frames_per_s": st["frames"] / st["seconds"],
                    "upload_GB_per_s": st["pcm_bytes"] / st["seconds"] / 1e9, "download_GB_per_s": st["result_bytes"] / st["seconds"] / 1e9,
-                   "workers": 4, "files_per_batch": 128}
+                   "workers": 3, "files_per_batch": 256}
         except Exception as e:  # noqa: BLE001  (the headline must not depend on the host library)
             e2e = {"error": str(e)}
 
@@ -356,10 +360,10 @@ def main():
             "dtype": args.precision,
             "data": "synthetic",
             "config": {
-                "workload": (f"C3: {'every per-frame' if args.mask in ('frame', 'neighbours') else 'spectral'} low-level "
+                "workload": (f"C3: {'every' if args.mask == 'everything' else 'every per-frame' if args.mask in ('frame', 'neighbours') else 'spectral'} low-level "
                              f"descriptor set + per-file statistics, {n_bufs} synthetic 2.0 s mono 16-bit files per "
                              f"GPU through the LoadSample front end") if args.workload == "c3" else
-                            (f"C4 share: {'every per-frame' if args.mask in ('frame', 'neighbours') else 'spectral'} low-level "
+                            (f"C4 share: {'every' if args.mask == 'everything' else 'every per-frame' if args.mask in ('frame', 'neighbours') else 'spectral'} low-level "
                              f"descriptor set + per-file statistics, {n_bufs} synthetic 1.0 s stereo 16-bit files per GPU "
                              f"through the LoadSample front end") if args.workload == "c4" else
                             (f"C2 x{args.buffers}: 2048/1024 STFT + 14-coef MFCC, {args.buffers} mono float32 "

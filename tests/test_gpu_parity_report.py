@@ -116,6 +116,46 @@ def _rows_statistics_load_and_lengths():
     return lines
 
 
+def _rows_rhythm():
+    """SURVEY 8(f) row f4, rhythm tracker: observed errors on the golden signals and 24 C3-like files vs the oracle
+    (whose FFT front end and beat-tracking pass are pinned to the reference's objects; the detector, sharpening and
+    heuristics are restated from source: "parity unpinned")."""
+    from tests import _oracle
+    lines = ["", "## Rhythm tracker (f4): 512/128 onset functions, onsets, 14 scalars vs the oracle", ""]
+    gold = np.load(os.path.join(GOLD, "rhythm.npz"))
+    xs = [gold[k].astype(np.float64) / 32768.0 for k in gold.files if k.startswith("pcm_")]
+    xs += [x.astype(np.float64) for x in c3_like_files(24, 321)]
+    plan = afx.Plan()
+    b = plan.batch(xs, afx.D_RHYTHM)
+    b.run()
+    r = b.fetch_rhythm(onset_functions=True)
+    ora = Oracle()
+    frames = int(r["offsets"][-1])
+    eq = np.zeros(2)
+    fn_err, onset_pos_bad, onset_err = 0.0, 0, 0.0
+    sc_err = np.zeros(14)
+    for i, x in enumerate(xs):
+        ref = ora.run_rhythm(x, cap=True)
+        sl = slice(r["offsets"][i], r["offsets"][i + 1])
+        odf, want = r["onset_functions"][sl], ref["odf"].T.astype(np.float32)
+        eq += (odf == want).sum(axis=0)
+        fn_err = max(fn_err, float(np.max(np.abs(odf.astype(np.float64) - want) / (np.abs(want).max(axis=0) + 1e-30))))
+        for t in range(2):
+            onset_pos_bad += int(not np.array_equal(np.nonzero(r["onsets"][sl, t])[0], np.nonzero(ref["onsets"][t])[0]))
+            onset_err = max(onset_err, float(np.max(np.abs(r["onsets"][sl, t] - ref["onsets"][t]))))
+        sc_err = np.maximum(sc_err, np.abs(r["scalars"][i] - ref["scalars"]) / np.maximum(np.abs(ref["scalars"]), 1e-9))
+    b.close()
+    plan.close()
+    lines += [f"{len(xs)} files, {frames} frames of 512 samples.", "", "| quantity | observed |", "|---|---|",
+              f"| complex-domain onset function (float): bit-equal values | {eq[0] / frames:.6f} |",
+              f"| power onset function (float): bit-equal values | {eq[1] / frames:.6f} |",
+              f"| onset functions: max error relative to the file's largest value | {fn_err:.2e} |",
+              f"| series (of {2 * len(xs)}) whose detected onset frames differ | {onset_pos_bad} |",
+              f"| onset values: max abs difference | {onset_err:.2e} |"]
+    lines += [f"| {n}: max rel err | {e:.2e} |" for n, e in zip(_oracle.RHYTHM_SCALARS, sc_err)]
+    return lines, float(sc_err.max()), onset_pos_bad
+
+
 def test_write_parity_report():
     plan, oracle = afx.Plan(max_analysis_ms=0), Oracle()
     acc = {}   # field -> list of (relative errors array, error in units of the tolerance)
@@ -170,6 +210,8 @@ def test_write_parity_report():
         lines.append(f"| {field} | {rel.size} | {rel.max():.2e} | {rel.mean():.2e} | "
                      + ("exact" if rel.max() == 0 else f"{worst:.3g}") + " |")
     lines += _rows_statistics_load_and_lengths()
+    rhythm_lines, rhythm_worst, rhythm_onsets_bad = _rows_rhythm()
+    lines += rhythm_lines
     text = "\n".join(lines) + "\n"
     out_dir = os.path.join(ROOT, "gpurun_out")
     try:
@@ -180,3 +222,4 @@ def test_write_parity_report():
         pass
     print(text)
     assert worst_overall <= 1.0, text
+    assert rhythm_worst <= 1e-4 and rhythm_onsets_bad == 0, text

@@ -156,6 +156,21 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota():
+    """CPUs the container may use at once (cgroup CPU bandwidth limit), None when unlimited / unknown."""
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        pass
+    try:
+        quota = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())             # cgroup v1
+        period = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if quota <= 0 else quota / period
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(frames_per_worker):
     """The reference CPU path timed on this host: oracle/_ref/ref_driver (the reference's own
     objects, kind "reference") when present, else the oracle restatement (kind "port").  One
@@ -166,8 +181,12 @@ def cpu_baseline(frames_per_worker):
         host_cpus_usable = len(os.sched_getaffinity(0))
     except AttributeError:
         host_cpus_usable = host_cpus
-    cores = max(1, min(host_cpus_usable, 256))   # bounded sample: <= 256 worker processes
-    host = {"cpu_model": cpu_model(), "os_cpu_count": host_cpus, "cpus_usable": host_cpus_usable}
+    # worker processes = the CPUs this job can really run on: the affinity mask, cut by the container's CPU bandwidth
+    # quota (on the GPU pool: 256 hardware threads visible, quota 16 CPUs -- more processes than that only contend:
+    # measured 544 k frames/s with 16 processes, 500 k with 64, 320 k with 256)
+    quota = cpu_quota()
+    cores = max(1, min(host_cpus_usable, 256, int(quota + 0.5) if quota else 256))
+    host = {"cpu_model": cpu_model(), "os_cpu_count": host_cpus, "cpus_usable": host_cpus_usable, "cpu_quota": quota}
     ref = os.path.join(ROOT, "oracle", "_ref", "ref_driver")
     if os.path.exists(ref) and os.access(ref, os.X_OK):
         alone = subprocess.run([ref, "time", str(max(2000, frames_per_worker // 4)), "999"], stdout=subprocess.PIPE,

@@ -378,9 +378,10 @@ void ws_free(Workspace* w) {
   delete w;
 }
 
-// pooled workspaces: at most 16 idle ones per plan, none larger than 1 GiB
+// pooled workspaces: at most 16 idle ones per plan, none larger than 4 GiB (a 1024-file batch of one-second files with
+// every descriptor needs ~1 GiB: magnitudes 8 KiB and PCM 8 KiB per frame)
 constexpr size_t kPoolMaxIdle = 16;
-constexpr size_t kPoolMaxBytes = (size_t)1 << 30;
+constexpr size_t kPoolMaxBytes = (size_t)4 << 30;
 
 Workspace* ws_acquire(afx_plan* plan, hipError_t* err) {
   {

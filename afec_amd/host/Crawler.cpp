@@ -143,9 +143,10 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
   TCrawlStatistics Total;
   Total.mFilesPerDevice.assign((size_t)G, 0);
   double PhaseSeconds[2] = {0, 0};   // summed over workers: parse + staging copy, GPU round trip
+  double GpuSeconds[3] = {0, 0, 0};  // of the round trip: upload + LoadSample, kernels enqueue, download + wait
   std::mutex StatMutex;
   TBoundedQueue Queue((size_t)(2 * G * W));
-  TPinnedPool Pool;
+  TPinnedPool Pool, StatisticsPool, RhythmPool;   // one pool per kind of buffer: sizes within a kind are alike, nothing regrows
   std::atomic<bool> Abort(false);
   std::string FirstError;
 
@@ -211,8 +212,8 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
         // GPU: LoadSample + descriptors + statistics; results straight into page-locked buffers
         int64_t Frames = 0, ResultBytes = 0;
         if (!Decoded.empty()) {
-          Done.mpStatistics = Pool.Acquire(Decoded.size() * (size_t)TSampleAnalyser::kMaxStride * 13 * sizeof(double));
-          Done.mpRhythm = Pool.Acquire(TSampleAnalyser::RhythmDoubles(Decoded) * sizeof(double));
+          Done.mpStatistics = StatisticsPool.Acquire(Decoded.size() * (size_t)TSampleAnalyser::kMaxStride * 13 * sizeof(double));
+          Done.mpRhythm = RhythmPool.Acquire(TSampleAnalyser::RhythmDoubles(Decoded) * sizeof(double));
           // frames are at most samples / hop + 2 per file (LoadSample pads by up to a frame)
           size_t MaxFrames = 0;
           for (const TDecodedSample& s : Decoded) MaxFrames += (size_t)(s.mNumberOfSampleFrames / Options.mHopFrameSize) + 3;
@@ -241,6 +242,7 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
           std::lock_guard<std::mutex> Lock(StatMutex);
           PhaseSeconds[0] += tGpu0 - tParse0;
           PhaseSeconds[1] += tGpu1 - tGpu0;
+          for (int k = 0; k < 3; ++k) GpuSeconds[k] += Done.mResults.mSeconds[k];
           Total.mFiles += (int64_t)n;
           Total.mFrames += Frames;
           Total.mPcmBytes += PcmBytes;
@@ -279,8 +281,8 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
         }
       }
       Pool.Release(std::move(p->mpRecords));
-      Pool.Release(std::move(p->mpStatistics));
-      Pool.Release(std::move(p->mpRhythm));
+      StatisticsPool.Release(std::move(p->mpStatistics));
+      RhythmPool.Release(std::move(p->mpRhythm));
       std::lock_guard<std::mutex> Lock(StatMutex);
       Total.mFailedFiles += Failed;
       if (pPool) Total.mWriterSeconds += Now() - t0;
@@ -298,6 +300,9 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
   if (std::getenv("AFEC_CRAWL_TIMING"))
     std::fprintf(stderr, "[afec crawl] %.1f ms wall; worker time summed over %d workers: parse + staging %.1f ms, GPU round trip %.1f ms\n",
                  Total.mSeconds * 1e3, G * W, PhaseSeconds[0] * 1e3, PhaseSeconds[1] * 1e3);
+  if (std::getenv("AFEC_CRAWL_TIMING"))
+    std::fprintf(stderr, "[afec crawl]   round trip = create (upload, LoadSample) %.1f ms + enqueue %.1f ms + fetch (wait, download) %.1f ms\n",
+                 GpuSeconds[0] * 1e3, GpuSeconds[1] * 1e3, GpuSeconds[2] * 1e3);
   if (!FirstError.empty()) throw TReadableException(FirstError);
   return Total;
 }

@@ -2,6 +2,7 @@
 #include "SampleAnalyser.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 
 #include "../../include/afx.h"
@@ -316,8 +317,11 @@ bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files,
                Files[i].mNumberOfSampleFrames};
   std::vector<afx_load_info> Info((size_t)n);
   TBatchGuard Batch;
+  auto Now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t0 = Now();
   int Status = afx_batch_create_from_raw(mpPlan, Raws.data(), n, kEverything, &Batch.mpBatch, Info.data());
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
+  const double t1 = Now();
   Result = TRecordBatch();
   afx_batch_record_layout(Batch.mpBatch, &Result.mStride, Result.mOffsets, Result.mWidths);
   const size_t Frames = (size_t)afx_batch_total_frames(Batch.mpBatch);
@@ -327,6 +331,7 @@ bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files,
   if (RhythmRows * 2 + (size_t)n * (AFX_NUM_RHYTHM_SCALARS + 2 * AFX_NUM_STATISTICS) > RhythmCapacity) return false;
   Status = SetFileInfo(Batch.mpBatch, Files, Info, mSampleRate);
   if (Status == AFX_OK) Status = afx_batch_run(Batch.mpBatch);
+  const double t2 = Now();
   Result.mFrameOffset.resize((size_t)n + 1);
   Result.mStatus.resize((size_t)n);
   Result.mEffectiveLength.resize((size_t)n * 3);
@@ -339,6 +344,7 @@ bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files,
   if (Status == AFX_OK) Status = afx_batch_fetch_rhythm(Batch.mpBatch, pOnsets, pScalars, pOnsetStatistics);
   Result.mpRhythmOnsets = pOnsets; Result.mpRhythmScalars = pScalars; Result.mpRhythmStatistics = pOnsetStatistics;
   if (Status != AFX_OK) Throw("GPU feature extraction failed", Status);
+  Result.mSeconds[0] = t1 - t0; Result.mSeconds[1] = t2 - t1; Result.mSeconds[2] = Now() - t2;
   Result.mpRecords = pRecords;
   Result.mpStatistics = pStatistics;
   Result.mInfo.resize((size_t)n);

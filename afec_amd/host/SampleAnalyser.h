@@ -104,6 +104,7 @@ struct TRecordBatch {
   const double* mpRhythmOnsets = nullptr;           // [rows][2]: complex, percussive
   const double* mpRhythmScalars = nullptr;          // [files][14], AFX_R_* order
   const double* mpRhythmStatistics = nullptr;       // [files][2][13]
+  double mSeconds[3] = {0, 0, 0};                   // wall time of upload + LoadSample, kernels enqueue, download + wait
   int NumberOfFiles() const { return (int)mStatus.size(); }
   TSampleDescriptors Descriptors(int FileIndex) const;
 };

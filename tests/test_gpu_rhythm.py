@@ -165,3 +165,32 @@ def test_rhythm_long_file_hits_the_cap():
     assert abs(r["scalars"][0][7] - 132.0) < 2.0
     b.close()
     plan.close()
+
+
+def test_rhythm_without_the_cap_series_longer_than_the_lds_stage():
+    # 75 s with the 20 s cap disabled: 25 836 onset frames per function -- the autocorrelation reads the series from
+    # global memory (it no longer fits the 8 192-frame LDS stage) and the onset statistics take the long-series kernel
+    sr = 44100
+    rng = np.random.default_rng(19)
+    n = 75 * sr
+    x = np.zeros(n)
+    step = int(60.0 / 104.0 * sr)
+    for k, at in enumerate(range(0, n - 5000, step // 2)):
+        amp = 1.0 if k % 2 == 0 else 0.35
+        x[at:at + 3000] += amp * np.exp(-np.arange(3000) / 350.0) * rng.uniform(-1, 1, 3000)
+    x = (x / np.abs(x).max()).astype(np.float32)
+    plan = afx.Plan(max_analysis_ms=0)
+    b = plan.batch([x, x[:200000]], MASK)
+    b.run()
+    r = b.fetch_rhythm(statistics=True, onset_functions=True)
+    o = _oracle.Oracle()
+    assert np.diff(r["offsets"]).tolist() == [(n - 512) // 128 + 1, (200000 - 512) // 128 + 1]
+    for i, sig in enumerate((x, x[:200000])):
+        ref = o.run_rhythm(sig.astype(np.float64), cap=False)
+        sl = slice(r["offsets"][i], r["offsets"][i + 1])
+        check_file(f"uncapped[{i}]", sig, r["onsets"][sl], r["onset_functions"][sl], r["scalars"][i], ref)
+        for t in range(2):
+            want = _oracle.calc_statistics(r["onsets"][sl, t], np.zeros(13))
+            assert np.all(np.abs(r["onset_statistics"][i, t] - want) <= 1e-8 * np.abs(want) + 1e-12), (i, t)
+    b.close()
+    plan.close()

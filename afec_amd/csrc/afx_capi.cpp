@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -154,6 +155,10 @@ struct Workspace {
   };
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // second stream for the rhythm tracker's kernels, which depend on the PCM only: small batches (a crawler's 256 files)
+  // leave most of the chip idle during any one kernel, so the two kernel chains run side by side
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
   Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff;   // rhythm tracker
@@ -374,6 +379,9 @@ void ws_free(Workspace* w) {
                             &w->rt_onsets, &w->rt_scratch, &w->rt_scalars, &w->rt_stats, &w->rt_foff}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
+  if (w->ev_fork) hipEventDestroy(w->ev_fork);
+  if (w->ev_join) hipEventDestroy(w->ev_join);
+  if (w->side_stream) hipStreamDestroy(w->side_stream);
   if (w->stream) hipStreamDestroy(w->stream);
   delete w;
 }
@@ -397,6 +405,9 @@ Workspace* ws_acquire(afx_plan* plan, hipError_t* err) {
   hipError_t e = hipStreamCreateWithFlags(&w->stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreate(&w->ev0);
   if (e == hipSuccess) e = hipEventCreate(&w->ev1);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->side_stream, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming);
   if (e != hipSuccess) { *err = e; ws_free(w); return nullptr; }
   return w;
 }
@@ -897,6 +908,22 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   return AFX_OK;
 }
 
+// AFX_TIMING=1 in the environment: wall time of the phases of afx_batch_create_from_raw, summed over calls and printed
+// when the process ends (diagnostic for pipelines; three clock reads per call otherwise)
+struct CreateTiming {
+  std::atomic<long long> ns[4]{};   // upload + scan + wait, host placement, build + LoadSample write + wait, calls
+  bool on = std::getenv("AFX_TIMING") != nullptr;
+  ~CreateTiming() {
+    if (on && ns[3].load())
+      std::fprintf(stderr, "[afx timing] create_from_raw x%lld: upload + scan + wait %.1f ms, placement %.1f ms, build + write + wait %.1f ms\n",
+                   ns[3].load(), ns[0].load() * 1e-6, ns[1].load() * 1e-6, ns[2].load() * 1e-6);
+  }
+};
+CreateTiming g_create_timing;
+inline long long now_ns() {
+  return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
 // bytes per sample of the decoded PCM formats (0: unknown format)
 int raw_bytes_per_sample(int format) {
   switch (format) {
@@ -921,7 +948,7 @@ void stats_regimes(const std::vector<int64_t>& offset, afx::StatsArgs* sa) {
 void stats_regimes(const afx_batch* b, afx::StatsArgs* sa) { stats_regimes(b->frame_offset, sa); }
 
 // the rhythm tracker's kernels + the statistics of the two onset series (TSampleAnalyser::CalcStatistics covers them)
-int run_rhythm(afx_batch* b) {
+int run_rhythm(afx_batch* b, hipStream_t stream) {
   if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0) return AFX_OK;
   const afx_plan* plan = b->plan;
   const float rate = (float)plan->desc.sample_rate;
@@ -942,14 +969,31 @@ int run_rhythm(afx_batch* b) {
   for (const afx::RhythmFile& rf : b->rt_files)
     if (rf.frames <= afx::kRhythmLdsFrames) ra.lds_frames = std::max(ra.lds_frames, rf.frames);
   ra.odf = b->d_rt_odf; ra.onsets = b->d_rt_onsets; ra.scratch = b->d_rt_scratch; ra.scalars = b->d_rt_scalars;
-  HIP_TRY(afx::launch_rhythm(ra, b->stream));
+  HIP_TRY(afx::launch_rhythm(ra, stream));
   if (b->d_rt_stats) {
     afx::StatsArgs sa{};
     sa.rec = b->d_rt_onsets; sa.frame_offset = b->d_rt_foff; sa.n_bufs = b->n_bufs; sa.stride = 2;
     sa.stats = b->d_rt_stats;
     stats_regimes(b->rt_offset, &sa);
-    HIP_TRY(afx::launch_stats(sa, b->stream));
+    HIP_TRY(afx::launch_stats(sa, stream));
   }
+  return AFX_OK;
+}
+
+// the rhythm chain on the workspace's side stream, forked here and joined by rhythm_join at the end of the run
+int rhythm_fork(afx_batch* b) {
+  if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0) return AFX_OK;
+  Workspace& w = *b->ws;
+  HIP_TRY(hipEventRecord(w.ev_fork, b->stream));
+  HIP_TRY(hipStreamWaitEvent(w.side_stream, w.ev_fork, 0));
+  const int st = run_rhythm(b, w.side_stream);
+  if (st != AFX_OK) return st;
+  HIP_TRY(hipEventRecord(w.ev_join, w.side_stream));
+  return AFX_OK;
+}
+int rhythm_join(afx_batch* b) {
+  if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0) return AFX_OK;
+  HIP_TRY(hipStreamWaitEvent(b->stream, b->ws->ev_join, 0));
   return AFX_OK;
 }
 
@@ -1038,6 +1082,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     files[i] = afx::LoadFile{raw_bytes, r.n_frames, r.channels, r.format};
     raw_bytes += ((int64_t)r.n_frames * r.channels * bps + 15) & ~(int64_t)15;
   }
+  const long long t_begin = now_ns();
   // device staging of the decoded PCM and the scan results lives in the batch's pooled workspace
   hipError_t e = hipSuccess;
   Workspace* ws = ws_acquire(plan, &e);
@@ -1081,6 +1126,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     if ((e = hipMemcpyAsync(scan.data(), d_scan, scan.size() * sizeof(afx::LoadScan), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(scan)"));
     if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(hip_fail(e, "hipStreamSynchronize"));
   }
+  const long long t_scanned = now_ns();
   // padding rules of SampleAnalyser.cpp:681-701
   const int fft = plan->desc.fft_size;
   std::vector<int64_t> lengths((size_t)n_bufs, 0);
@@ -1126,8 +1172,15 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
       file_samples[(size_t)i] = files[i].n_frames;                                // mOriginalNumberOfSamples, SampleAnalyser.cpp:464
       file_offset[(size_t)i] = (int32_t)(-place[i].lead + place[i].start_pad);    // mDataOffset, SampleAnalyser.cpp:701
     }
-  return build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch, ws, &file_samples,
-                     &file_offset);
+  const long long t_placed = now_ns();
+  const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch, ws, &file_samples,
+                             &file_offset);
+  if (g_create_timing.on) {
+    const long long t_end = now_ns();
+    g_create_timing.ns[0] += t_scanned - t_begin; g_create_timing.ns[1] += t_placed - t_scanned;
+    g_create_timing.ns[2] += t_end - t_placed; g_create_timing.ns[3] += 1;
+  }
+  return st;
 }
 
 int afx_batch_fetch_samples(afx_batch* b, int32_t buf, double* dst, int64_t n) {
@@ -1145,6 +1198,10 @@ int afx_batch_run(afx_batch* b) {
   if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
   HIP_TRY(hipSetDevice(b->plan->desc.device));
   b->ran = true;
+  {
+    const int st = rhythm_fork(b);
+    if (st != AFX_OK) return st;
+  }
   if (b->d_efflen) {
     // DbToLin(-48 / -24 / -12), AudioMath.inl:108-123
     const double k = std::log(10.0) / 20.0;
@@ -1160,7 +1217,7 @@ int afx_batch_run(afx_batch* b) {
       stats_regimes(b, &sa);
       HIP_TRY(afx::launch_stats(sa, b->stream));
     }
-    return run_rhythm(b);
+    return rhythm_join(b);
   }
   const DeviceTables& t = b->plan->dev;
   if (frames_mask(b->mask)) {
@@ -1222,11 +1279,7 @@ int afx_batch_run(afx_batch* b) {
     stats_regimes(b, &sa);
     HIP_TRY(afx::launch_stats(sa, b->stream));
   }
-  {
-    const int st = run_rhythm(b);
-    if (st != AFX_OK) return st;
-  }
-  return AFX_OK;
+  return rhythm_join(b);
 }
 
 int afx_batch_sync(afx_batch* b) {

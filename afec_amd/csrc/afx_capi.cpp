@@ -184,6 +184,9 @@ struct afx_plan {
   // AFX_HALFWAVE in the environment when the plan is created: 0 = 64-lane frame kernels only (A/B timing),
   // 1 = by batch size (default), 2 = half-wave kernel for every batch it supports (tests)
   int halfwave = 1;
+  // AFX_SIDE_STREAM=0 in the environment when the plan is created: the rhythm tracker's kernels are enqueued on the
+  // batch's own stream instead of its side stream (per-kernel durations of a profile are then not inflated by overlap)
+  bool side_stream = true;
 };
 
 struct afx_batch {
@@ -606,6 +609,7 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess) p->cu_count = prop.multiProcessorCount;
   if (const char* hw = std::getenv("AFX_HALFWAVE")) p->halfwave = (hw[0] == '0') ? 0 : (hw[0] == '2' ? 2 : 1);
+  if (const char* ss = std::getenv("AFX_SIDE_STREAM")) p->side_stream = ss[0] != '0';
   const int st = upload_tables(p);
   if (st != AFX_OK) { free_tables(p); delete p; return st; }
   *out_plan = p;
@@ -984,6 +988,7 @@ int run_rhythm(afx_batch* b, hipStream_t stream) {
 int rhythm_fork(afx_batch* b) {
   if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0) return AFX_OK;
   Workspace& w = *b->ws;
+  if (!b->plan->side_stream) return run_rhythm(b, b->stream);
   HIP_TRY(hipEventRecord(w.ev_fork, b->stream));
   HIP_TRY(hipStreamWaitEvent(w.side_stream, w.ev_fork, 0));
   const int st = run_rhythm(b, w.side_stream);
@@ -992,7 +997,7 @@ int rhythm_fork(afx_batch* b) {
   return AFX_OK;
 }
 int rhythm_join(afx_batch* b) {
-  if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0) return AFX_OK;
+  if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0 || !b->plan->side_stream) return AFX_OK;
   HIP_TRY(hipStreamWaitEvent(b->stream, b->ws->ev_join, 0));
   return AFX_OK;
 }

@@ -232,7 +232,7 @@ def kernel_profile(precision, mask_name, workload):
     if not os.path.exists(p):
         return None
     try:
-        key = workload if workload != "c2" else f"{mask_name}_{precision}"
+        key = (f"{workload}_everything" if mask_name == "everything" else workload) if workload != "c2" else f"{mask_name}_{precision}"
         return json.load(open(p)).get(key)
     except Exception:
         return None

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""profiles/kernel_profiles.json (what bench.py's roofline object quotes) from the per-configuration summaries that
+tools/profile_config.py wrote on the GPU box (gpurun_out/<round>/profile_<tag>.json); the summaries and kernel-stats
+files are copied to profiles/<round>/ alongside.
+
+usage: make_kernel_profiles.py [round]      (run from the repo root after a GPU round)"""
+import glob
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+SRC = os.path.join(ROOT, "gpurun_out", ROUND)
+DST = os.path.join(ROOT, "profiles", ROUND)
+CLOCK_GHZ = 1.85   # measured in-kernel (s_memtime / s_memrealtime, stamps build) under the f64 load
+LIMITER = {"c2_f64": "f64 VALU issue (with the CU's LDS at ~70 %)"}
+
+os.makedirs(DST, exist_ok=True)
+out = {"_comment": "Per bench configuration, from rocprofv3 passes on MI355X (tools/profile_config.py; raw summaries "
+                   f"profiles/{ROUND}/profile_<tag>.json): HBM bytes per frame = (2*FETCH_SIZE + WRITE_SIZE)*1024/frames (gfx950 "
+                   "FETCH_SIZE half-count correction, calibrated for 16-B streaming reads only), VALU pipe cycles per frame = "
+                   "4*SQ_ACTIVE_INST_VALU/frames summed over the kernels of one step (rhythm kernels on the batch's own stream: "
+                   "AFX_SIDE_STREAM=0), clock = in-kernel s_memtime/s_memrealtime of the stamps build under this load."}
+for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
+    tag = os.path.basename(f)[len("profile_"):-len(".json")]
+    d = json.load(open(f))
+    kernels = sorted(d["kernels"], key=lambda k: -d["kernels"][k].get("ms_per_step", 0.0))
+    out[tag] = {
+        "bytes_per_frame": d["per_frame"]["hbm_bytes"],
+        "valu_cycles_per_frame": d["per_frame"]["valu_cycles"],
+        "valu_instructions_per_frame": d["per_frame"]["valu_instructions"],
+        "clock_ghz": CLOCK_GHZ,
+        "frames_profiled": d["frames_per_step"],
+        "limiter": LIMITER.get(tag, "f64 VALU issue"),
+        "kernels": kernels,
+        "kernel_ms_per_step": {k: round(d["kernels"][k].get("ms_per_step", 0.0), 4) for k in kernels},
+        "dominant_kernel": kernels[0] if kernels else None,
+        "source": f"profiles/{ROUND}/profile_{tag}.json",
+    }
+    shutil.copy(f, DST)
+for pat in ("*_kernel_stats.csv", "*_pmc_summary.csv", "*_pmc.csv", "rhythm_report.md", "parity_report.md", "ubench_*.txt",
+            "bench_default.json", "pytest_gpu.log"):
+    for f in glob.glob(os.path.join(SRC, pat)):
+        shutil.copy(f, DST)
+json.dump(out, open(os.path.join(ROOT, "profiles", "kernel_profiles.json"), "w"), indent=1)
+print("wrote profiles/kernel_profiles.json:", ", ".join(k for k in out if k != "_comment"))

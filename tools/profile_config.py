@@ -30,7 +30,8 @@ def run_pass(tag, name, prof_args, bench_args):
     cmd = ["rocprofv3"] + prof_args + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3",
                                        os.path.join(ROOT, "bench.py"), "--steps", str(STEPS), "--warmup", str(WARMUP),
                                        "--no-cpu-baseline", "--no-single"] + bench_args
-    env = dict(os.environ, TMPDIR="/tmp")
+    # AFX_SIDE_STREAM=0: the rhythm kernels on the batch's own stream, so that a kernel's duration is its own
+    env = dict(os.environ, TMPDIR="/tmp", AFX_SIDE_STREAM="0")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return d, (json.loads(line[-1]) if line else None), r

@@ -14,7 +14,6 @@ python tools/profile_config.py c3 --workload c3 --mask frame
 python tools/profile_config.py c4 --workload c4 --mask frame
 python tools/profile_config.py c4_everything --workload c4 --mask everything
 bash tools/prof_pmc.sh c2hw frames32 > /dev/null 2>&1
-python tools/rhythm_report.py > /dev/null 2>&1; cp $O/rhythm_report.md /tmp/rr.md
 bash tools/prof_rhythm.sh | grep -v stats_kernel
-cp /tmp/rr.md $O/rhythm_report.md
 bash tools/prof_rhythm_pmc.sh short
+python tools/rhythm_report.py > /dev/null 2>&1      # last: the profiled runs above overwrite the report with partial ones

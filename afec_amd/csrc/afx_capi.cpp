@@ -159,6 +159,7 @@ struct Workspace {
   // leave most of the chip idle during any one kernel, so the two kernel chains run side by side
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_copy = nullptr;   // orders this batch's stream with the plan's upload / download streams
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
   Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff;   // rhythm tracker
@@ -181,6 +182,11 @@ struct afx_plan {
   std::vector<double> mel;     // [14][fft/2]
   DeviceTables dev;
   int cu_count = 256;
+  // The large transfers of every batch of this plan go through ONE upload stream and ONE download stream.  Measured
+  // on the pool (tools/link_rate.py): one stream per direction runs full duplex at 46 + 46 GB/s, three batch streams
+  // that each upload and download collapse to 16 + 16 GB/s (the copy engines are re-assigned back and forth).
+  std::mutex up_mutex, down_mutex;
+  hipStream_t up_stream = nullptr, down_stream = nullptr;
   // AFX_HALFWAVE in the environment when the plan is created: 0 = 64-lane frame kernels only (A/B timing),
   // 1 = by batch size (default), 2 = half-wave kernel for every batch it supports (tests)
   int halfwave = 1;
@@ -384,6 +390,7 @@ void ws_free(Workspace* w) {
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->ev_fork) hipEventDestroy(w->ev_fork);
   if (w->ev_join) hipEventDestroy(w->ev_join);
+  if (w->ev_copy) hipEventDestroy(w->ev_copy);
   if (w->side_stream) hipStreamDestroy(w->side_stream);
   if (w->stream) hipStreamDestroy(w->stream);
   delete w;
@@ -411,6 +418,7 @@ Workspace* ws_acquire(afx_plan* plan, hipError_t* err) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->side_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_copy, hipEventDisableTiming);
   if (e != hipSuccess) { *err = e; ws_free(w); return nullptr; }
   return w;
 }
@@ -612,6 +620,13 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   if (const char* ss = std::getenv("AFX_SIDE_STREAM")) p->side_stream = ss[0] != '0';
   const int st = upload_tables(p);
   if (st != AFX_OK) { free_tables(p); delete p; return st; }
+  if (hipStreamCreateWithFlags(&p->up_stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&p->down_stream, hipStreamNonBlocking) != hipSuccess) {
+    if (p->up_stream) hipStreamDestroy(p->up_stream);
+    free_tables(p);
+    delete p;
+    return fail(AFX_ERR_HIP, "hipStreamCreate(copy streams)");
+  }
   *out_plan = p;
   return AFX_OK;
 }
@@ -621,6 +636,8 @@ static void plan_release(afx_plan* plan) {
   hipSetDevice(plan->desc.device);
   for (Workspace* w : plan->pool) ws_free(w);
   plan->pool.clear();
+  if (plan->up_stream) hipStreamDestroy(plan->up_stream);
+  if (plan->down_stream) hipStreamDestroy(plan->down_stream);
   free_tables(plan);
   delete plan;
 }
@@ -928,6 +945,32 @@ inline long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// One large host-to-device transfer through the plan's upload stream; `stream` (the batch's) continues after it.
+hipError_t upload_through_plan(afx_plan* plan, Workspace* ws, hipStream_t stream, void* dst, const void* src, size_t bytes) {
+  std::lock_guard<std::mutex> lock(plan->up_mutex);
+  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, plan->up_stream);
+  if (e == hipSuccess) e = hipEventRecord(ws->ev_copy, plan->up_stream);
+  if (e == hipSuccess) e = hipStreamWaitEvent(stream, ws->ev_copy, 0);
+  return e;
+}
+// Device-to-host transfers of a batch's results through the plan's download stream, behind everything enqueued on the
+// batch's stream so far; returns when they have landed.
+struct Download { void* dst; const void* src; size_t bytes; };
+hipError_t download_through_plan(afx_batch* b, const Download* items, int n) {
+  afx_plan* plan = b->plan;
+  Workspace* ws = b->ws;
+  {
+    std::lock_guard<std::mutex> lock(plan->down_mutex);
+    hipError_t e = hipEventRecord(ws->ev_copy, b->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(plan->down_stream, ws->ev_copy, 0);
+    for (int i = 0; i < n && e == hipSuccess; ++i)
+      if (items[i].dst && items[i].bytes) e = hipMemcpyAsync(items[i].dst, items[i].src, items[i].bytes, hipMemcpyDeviceToHost, plan->down_stream);
+    if (e == hipSuccess) e = hipEventRecord(ws->ev_copy, plan->down_stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipEventSynchronize(ws->ev_copy);
+}
+
 // bytes per sample of the decoded PCM formats (0: unknown format)
 int raw_bytes_per_sample(int format) {
   switch (format) {
@@ -1115,7 +1158,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
         contiguous = ((const char*)raws[i].data == base + files[i].raw_off);
       }
     if (contiguous && base) {
-      if ((e = hipMemcpyAsync(d_raw, base, (size_t)raw_bytes, hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
+      if ((e = upload_through_plan(plan, ws, s, d_raw, base, (size_t)raw_bytes)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
     } else {
       for (int i = 0; i < n_bufs; ++i)
         if (status[i] == AFX_OK) {
@@ -1411,9 +1454,10 @@ int afx_batch_fetch_records(afx_batch* b, double* records, double* statistics, i
   HIP_TRY(hipSetDevice(b->plan->desc.device));
   const size_t rec_bytes = (size_t)b->total_frames * b->lay.stride * sizeof(double);
   const size_t stat_bytes = (size_t)b->n_bufs * b->lay.stride * 13 * sizeof(double);
-  if (records && rec_bytes) HIP_TRY(hipMemcpyAsync(records, b->d_rec, rec_bytes, hipMemcpyDeviceToHost, b->stream));
-  if (statistics && stat_bytes) HIP_TRY(hipMemcpyAsync(statistics, b->d_stats, stat_bytes, hipMemcpyDeviceToHost, b->stream));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  {
+    const Download items[2] = {{records, b->d_rec, rec_bytes}, {statistics, b->d_stats, stat_bytes}};
+    HIP_TRY(download_through_plan(b, items, 2));
+  }
   if (frame_offset) std::memcpy(frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t));
   if (buf_status) std::memcpy(buf_status, b->buf_status.data(), b->buf_status.size() * sizeof(int32_t));
   if (effective_length) {
@@ -1455,10 +1499,12 @@ int afx_batch_fetch_rhythm(afx_batch* b, double* onsets, double* scalars, double
   if (onset_statistics && !b->d_rt_stats) return fail(AFX_ERR_INVALID_ARG, "AFX_D_STATISTICS was not in the batch mask");
   HIP_TRY(hipSetDevice(b->plan->desc.device));
   const size_t rows = (size_t)b->rt_offset.back();
-  if (onsets && rows) HIP_TRY(hipMemcpyAsync(onsets, b->d_rt_onsets, rows * 2 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  if (scalars) HIP_TRY(hipMemcpyAsync(scalars, b->d_rt_scalars, (size_t)b->n_bufs * AFX_NUM_RHYTHM_SCALARS * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  if (onset_statistics) HIP_TRY(hipMemcpyAsync(onset_statistics, b->d_rt_stats, (size_t)b->n_bufs * 2 * 13 * sizeof(double), hipMemcpyDeviceToHost, b->stream));
-  HIP_TRY(hipStreamSynchronize(b->stream));
+  {
+    const Download items[3] = {{onsets, b->d_rt_onsets, rows * 2 * sizeof(double)},
+                               {scalars, b->d_rt_scalars, (size_t)b->n_bufs * AFX_NUM_RHYTHM_SCALARS * sizeof(double)},
+                               {onset_statistics, b->d_rt_stats, (size_t)b->n_bufs * 2 * 13 * sizeof(double)}};
+    HIP_TRY(download_through_plan(b, items, 3));
+  }
   return AFX_OK;
 }
 

@@ -184,3 +184,63 @@ def test_mixed_pcm_types_in_one_call_flag_the_minority():
     assert res["buf_status"].tolist() == [0, -6, 0]
     assert res["frame_offset"].tolist() == [0, 4, 4, 8]
     plan.close()
+
+
+def test_rhythm_calls_are_validated_and_threads_agree():
+    """Error behaviour of the rhythm entry points, and the rhythm tracker from several threads on one plan (the side
+    stream, the plan's shared transfer streams and the pooled workspaces are shared state)."""
+    from tests import _oracle
+    rng = np.random.default_rng(77)
+    plan = afx.Plan()
+    x = (rng.uniform(-1, 1, 60000) * np.exp(-np.arange(60000) / 20000.0)).astype(np.float32)
+    b = plan.batch([x], afx.D_MFCC)
+    b.run()
+    with pytest.raises(afx.AfxError):          # AFX_D_RHYTHM was not in the mask
+        b.fetch_rhythm()
+    with pytest.raises(afx.AfxError):
+        b.set_file_info([(44100, 0, x.size)])
+    assert b.rhythm_frames().tolist() == [0, 0]
+    b.close()
+    b = plan.batch([x], afx.D_RHYTHM)
+    with pytest.raises(afx.AfxError):          # fetch before run
+        b.fetch_rhythm()
+    b.run()
+    with pytest.raises(afx.AfxError):          # onset statistics need AFX_D_STATISTICS
+        b.fetch_rhythm(statistics=True)
+    want = b.fetch_rhythm(onset_functions=True)
+    b.close()
+
+    files = [[(rng.uniform(-1, 1, 30000 + 4000 * k) * np.exp(-np.arange(30000 + 4000 * k) / 9000.0)).astype(np.float32)
+              for k in range(6)] for _ in range(6)]
+    serial = []
+    for bufs in files:
+        bb = plan.batch(bufs, afx.D_RHYTHM | afx.D_ALL_PER_FRAME | afx.D_STATISTICS)
+        bb.run()
+        serial.append((bb.fetch_rhythm(statistics=True), bb.fetch()))
+        bb.close()
+    out, errs = [None] * len(files), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                bb = plan.batch(files[i], afx.D_RHYTHM | afx.D_ALL_PER_FRAME | afx.D_STATISTICS)
+                bb.run()
+                out[i] = (bb.fetch_rhythm(statistics=True), bb.fetch())
+                bb.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(files))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for (r0, f0), (r1, f1) in zip(serial, out):
+        for k in ("onsets", "scalars", "onset_statistics"):
+            assert np.array_equal(r0[k], r1[k]), k
+        assert np.array_equal(f0["mfcc"], f1["mfcc"]) and np.array_equal(f0["f0"], f1["f0"])
+    # the single-file result did not depend on what ran beside it either
+    ref = _oracle.Oracle().run_rhythm(x.astype(np.float64), cap=True)
+    assert np.array_equal(np.nonzero(want["onsets"][:, 0])[0], np.nonzero(ref["onsets"][0])[0])
+    plan.close()

@@ -60,7 +60,7 @@ def main():
     rng = np.random.default_rng(seed)
     plan, oracle = afx.Plan(max_analysis_ms=0), Oracle()
     t0 = time.time()
-    rounds = frames = bad = skipped = 0
+    rounds = frames = bad = skipped = rhythm_frames = 0
     while time.time() - t0 < seconds:
         bufs = []
         for _ in range(int(rng.integers(1, 7))):
@@ -174,8 +174,38 @@ def main():
                     bad += 1
                     print(f"round {rounds} load front end: file {i} ({data.dtype}, {ch} ch): {infos[i]} vs {winfo}")
             b.close()
+        # the rhythm tracker on the round's buffers (float64 here: the oracle sees the very same samples): onset frames
+        # identical, onset functions to a few float ulps of the file's peak, scalars to 1e-5; a detection that differs
+        # is reported with its margin to the threshold
+        if rng.random() < 0.5 and any(b.size >= 512 for b in bufs):
+            rb = plan.batch(bufs, afx.D_RHYTHM)
+            info = [(44100, int(rng.integers(-3000, 1)), int(b.size * rng.choice([1, 1, 2]))) for b in bufs]
+            rb.set_file_info(info)
+            rb.run()
+            rr = rb.fetch_rhythm(onset_functions=True)
+            rb.close()
+            off = rr["offsets"]
+            for i, b in enumerate(bufs):
+                want = oracle.run_rhythm(b.astype(np.float64), original_samples=info[i][2], data_offset=info[i][1])
+                sl = slice(off[i], off[i + 1])
+                rhythm_frames += int(off[i + 1] - off[i])
+                if off[i + 1] == off[i]:
+                    continue
+                odf, wodf = rr["onset_functions"][sl].astype(np.float64), want["odf"].T.astype(np.float32).astype(np.float64)
+                scale = np.abs(wodf).max(axis=0) + 1e-30
+                ok = np.all(np.abs(odf - wodf) <= 2e-6 * np.abs(wodf) + 2e-7 * scale)
+                for t in range(2):
+                    ok = ok and np.array_equal(np.nonzero(rr["onsets"][sl, t])[0], np.nonzero(want["onsets"][t])[0])
+                finite = np.isfinite(want["scalars"])
+                ok = ok and np.array_equal(np.isfinite(rr["scalars"][i]), finite)
+                ok = ok and np.all(np.abs(rr["scalars"][i][finite] - want["scalars"][finite]) <= 1e-5 * np.abs(want["scalars"][finite]) + 1e-9)
+                if not ok:
+                    bad += 1
+                    dump(rounds, bufs, afx.D_RHYTHM)
+                    print(f"round {rounds} rhythm tracker, buffer {i} ({b.size} samples): scalars {rr['scalars'][i]} vs {want['scalars']}; "
+                          f"max onset-function error {np.max(np.abs(odf - wodf) / scale):.2e}")
         rounds += 1
-    print(f"{rounds} rounds, {frames} frames, {bad} mismatching (round, descriptor) pairs, "
+    print(f"{rounds} rounds, {frames} frames, {rhythm_frames} rhythm frames, {bad} mismatching (round, descriptor) pairs, "
           f"{skipped} ill-conditioned frames left out of the discrete comparisons, seed {seed}")
     return 1 if bad else 0
 

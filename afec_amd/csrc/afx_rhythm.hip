@@ -733,12 +733,14 @@ hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return e;
   }
   const size_t lds = (size_t)((a.lds_frames + 3) / 4) * 4 * sizeof(double);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attribute_set[16] = {};   // per device: raising the dynamic LDS limit once is enough
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attribute_set[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(rhythm_post_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        (int)(kMaxLdsFrames * sizeof(double)));
     if (e != hipSuccess) return e;
-    attr_set = true;
+    if (dev >= 0 && dev < 16) attribute_set[dev] = true;
   }
   hipLaunchKernelGGL(rhythm_post_kernel, dim3(a.n_files), dim3(256), lds, stream, a);
   return hipGetLastError();

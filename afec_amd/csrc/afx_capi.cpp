@@ -236,6 +236,13 @@ struct afx_batch {
   double* d_rt_scalars = nullptr;
   double* d_rt_stats = nullptr;
   int64_t* d_rt_foff = nullptr;
+  // host copies of the tables that are uploaded asynchronously: they live as long as the batch, so creation does not
+  // have to wait for the uploads (afx_batch_destroy synchronises the stream before they go)
+  std::vector<afx::Chunk> h_chunks;
+  std::vector<afx::ChunkRemaining> h_remaining;
+  std::vector<int32_t> h_chunk_first;
+  std::vector<afx::BufSpan> h_spans;
+  std::vector<afx::LoadPlace> h_place;
   bool mag_wanted = false;
   bool ran = false;        // afx_batch_run has been enqueued at least once: the fetches have something to fetch
   bool halfwave = false;   // frames by the half-wave kernel: a wave walks two chunks at a time
@@ -702,7 +709,7 @@ template <typename Fill>
 int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const std::vector<int64_t>& lengths,
                 const std::vector<int32_t>& status, bool zero_arena, Fill fill, afx_batch** out_batch,
                 Workspace* acquired = nullptr, const std::vector<int64_t>* file_samples = nullptr,
-                const std::vector<int32_t>* file_offset = nullptr) {
+                const std::vector<int32_t>* file_offset = nullptr, bool wait_for_uploads = true) {
   const bool want_stats = (mask & AFX_D_STATISTICS) != 0;
   mask &= ~(uint32_t)AFX_D_STATISTICS;   // the kernels see the descriptor bits only
 
@@ -781,9 +788,10 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
       if (cost < best - 1e-9 || (std::fabs(cost - best) <= 1e-9 && k > K)) { best = cost; K = k; }
     }
   }
-  std::vector<afx::Chunk> chunks;
-  std::vector<afx::ChunkRemaining> remaining;
-  std::vector<int32_t> chunk_first((size_t)n_bufs, 0);
+  std::vector<afx::Chunk>& chunks = b->h_chunks;
+  std::vector<afx::ChunkRemaining>& remaining = b->h_remaining;
+  std::vector<int32_t>& chunk_first = b->h_chunk_first;
+  chunk_first.assign((size_t)n_bufs, 0);
   b->chunk_frames = K;
   // When the half-wave frame kernel is the only consumer of the chunk table (it draws chunks from a work queue),
   // the last part of every buffer is cut into short chunks and the table is ordered long chunks first: the waves
@@ -857,12 +865,12 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     b->d_follower = (double*)w.follower.p;
   }
   if (n_bufs > 0 && (mask & AFX_D_EFFECTIVE_LENGTH)) {
-    std::vector<afx::BufSpan> spans((size_t)n_bufs);
+    std::vector<afx::BufSpan>& spans = b->h_spans;
+    spans.resize((size_t)n_bufs);
     for (int i = 0; i < n_bufs; ++i) spans[(size_t)i] = afx::BufSpan{b->arena_off[i], b->used[i]};
     if ((e = ws_reserve(w.spans, spans.size() * sizeof(afx::BufSpan))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(spans)"));
     b->d_spans = (afx::BufSpan*)w.spans.p;
     if ((e = hipMemcpyAsync(b->d_spans, spans.data(), spans.size() * sizeof(afx::BufSpan), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(spans)"));
-    if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
     if ((e = ws_reserve(w.efflen, (size_t)n_bufs * 6 * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(efflen)"));
     b->d_efflen = (int32_t*)w.efflen.p;
   }
@@ -924,7 +932,8 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
       b->d_rt_stats = (double*)w.rt_stats.p;
     }
   }
-  if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
+  // the caller's PCM buffers (afx_batch_create) may go away when this returns; the tables uploaded above are the batch's own
+  if (wait_for_uploads && (e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
   *out_batch = b;
   return AFX_OK;
 }
@@ -1207,9 +1216,9 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     for (int i = 0; i < n_bufs; ++i) place[i].out_off = b->arena_off[i], place[i].out_n = b->used[i];
     if ((e2 = ws_reserve(ws->place, place.size() * sizeof(afx::LoadPlace))) != hipSuccess) return hip_fail(e2, "hipMalloc(place)");
     afx::LoadPlace* d_place = (afx::LoadPlace*)ws->place.p;
-    e2 = hipMemcpyAsync(d_place, place.data(), place.size() * sizeof(afx::LoadPlace), hipMemcpyHostToDevice, b->stream);
+    b->h_place = place;   // the batch's own copy: the upload and the write kernel need not be waited for here
+    e2 = hipMemcpyAsync(d_place, b->h_place.data(), b->h_place.size() * sizeof(afx::LoadPlace), hipMemcpyHostToDevice, b->stream);
     if (e2 == hipSuccess) e2 = afx::launch_load_write(d_raw, d_files, d_place, n_bufs, (double*)b->d_pcm, b->stream);
-    if (e2 == hipSuccess) e2 = hipStreamSynchronize(b->stream);   // `place` is a pageable host vector
     return e2 == hipSuccess ? AFX_OK : hip_fail(e2, "load_write");
   };
   // the workspace (with the staged PCM in it) moves into the batch; build_batch releases it on failure
@@ -1221,8 +1230,9 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
       file_offset[(size_t)i] = (int32_t)(-place[i].lead + place[i].start_pad);    // mDataOffset, SampleAnalyser.cpp:701
     }
   const long long t_placed = now_ns();
+  // the decoded PCM has arrived (the scan was waited for): nothing of the caller's is read after this point
   const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch, ws, &file_samples,
-                             &file_offset);
+                             &file_offset, /*wait_for_uploads=*/false);
   if (g_create_timing.on) {
     const long long t_end = now_ns();
     g_create_timing.ns[0] += t_scanned - t_begin; g_create_timing.ns[1] += t_placed - t_scanned;
@@ -1236,6 +1246,7 @@ int afx_batch_fetch_samples(afx_batch* b, int32_t buf, double* dst, int64_t n) {
   if (b->pcm_dtype != AFX_PCM_F64) return fail(AFX_ERR_INVALID_ARG, "batch does not hold double PCM");
   const int64_t m = std::min<int64_t>(n, b->used[buf]);
   HIP_TRY(hipSetDevice(b->plan->desc.device));
+  HIP_TRY(hipStreamSynchronize(b->stream));   // the LoadSample write kernel is not waited for at creation
   if (m > 0) HIP_TRY(hipMemcpy(dst, (const double*)b->d_pcm + b->arena_off[buf], (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
   return AFX_OK;
 }

@@ -121,16 +121,48 @@ private:
 
 }  // namespace
 
+// What outlives one crawl: the analysers (one plan per device, with its pooled device workspaces) and the page-locked
+// buffers.  Setting these up costs ~65 ms on an MI355X box -- as much as analysing 8 000 one-second files.
+struct TCrawler::TImpl {
+  std::vector<int> mDevices;
+  int mSampleRate, mFftFrameSize, mHopFrameSize;
+  std::vector<std::unique_ptr<TSampleAnalyser>> mAnalysers;
+  TPinnedPool mRecordPool, mStatisticsPool, mRhythmPool, mStagingPool;   // one pool per kind of buffer: nothing regrows
+};
+
+TCrawler::TCrawler(const TCrawlOptions& Options) : mpImpl(new TImpl) {
+  mpImpl->mDevices = Options.mDevices;
+  mpImpl->mSampleRate = Options.mSampleRate; mpImpl->mFftFrameSize = Options.mFftFrameSize; mpImpl->mHopFrameSize = Options.mHopFrameSize;
+  if (Options.mDevices.empty()) { delete mpImpl; throw TReadableException("CrawlWaveFiles: no device given"); }
+  try {
+    // one analyser (plan) per device, shared by that device's workers like the reference's const analyser
+    for (int Device : Options.mDevices)
+      mpImpl->mAnalysers.emplace_back(new TSampleAnalyser(Options.mSampleRate, Options.mFftFrameSize, Options.mHopFrameSize, Device));
+  } catch (...) {
+    delete mpImpl;
+    throw;
+  }
+}
+
+TCrawler::~TCrawler() { delete mpImpl; }
+
 TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCrawlOptions& Options) {
+  TCrawler Crawler(Options);
+  return Crawler.Crawl(Files, Options);
+}
+
+TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCrawlOptions& Options) {
+  if (Options.mDevices != mpImpl->mDevices || Options.mSampleRate != mpImpl->mSampleRate ||
+      Options.mFftFrameSize != mpImpl->mFftFrameSize || Options.mHopFrameSize != mpImpl->mHopFrameSize)
+    throw TReadableException("TCrawler::Crawl: devices / geometry differ from the crawler's");
   const int G = (int)Options.mDevices.size();
-  if (G < 1) throw TReadableException("CrawlWaveFiles: no device given");
   const int W = Options.mWorkersPerDevice < 1 ? 1 : Options.mWorkersPerDevice;
   const int FilesPerBatch = Options.mFilesPerBatch < 1 ? 1 : Options.mFilesPerBatch;
-
-  // one analyser (plan) per device, shared by that device's workers like the reference's const analyser
-  std::vector<std::unique_ptr<TSampleAnalyser>> Analysers;
-  for (int d = 0; d < G; ++d)
-    Analysers.emplace_back(new TSampleAnalyser(Options.mSampleRate, Options.mFftFrameSize, Options.mHopFrameSize, Options.mDevices[d]));
+  std::vector<std::unique_ptr<TSampleAnalyser>>& Analysers = mpImpl->mAnalysers;
+  TPinnedPool& Pool = mpImpl->mRecordPool;
+  TPinnedPool& StatisticsPool = mpImpl->mStatisticsPool;
+  TPinnedPool& RhythmPool = mpImpl->mRhythmPool;
+  TPinnedPool& StagingPool = mpImpl->mStagingPool;
   std::unique_ptr<TSqliteSampleDescriptorPool> pPool;
   if (!Options.mDatabasePath.empty()) pPool.reset(new TSqliteSampleDescriptorPool(Options.mDatabasePath));
 
@@ -146,14 +178,18 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
   double GpuSeconds[3] = {0, 0, 0};  // of the round trip: upload + LoadSample, kernels enqueue, download + wait
   std::mutex StatMutex;
   TBoundedQueue Queue((size_t)(2 * G * W));
-  TPinnedPool Pool, StatisticsPool, RhythmPool;   // one pool per kind of buffer: sizes within a kind are alike, nothing regrows
   std::atomic<bool> Abort(false);
   std::string FirstError;
 
   auto Worker = [&](int d) {
     try {
       const TSampleAnalyser& Analyser = *Analysers[(size_t)d];
-      TPinned Staging;
+      struct TStagingLease {   // the worker's page-locked staging buffer goes back to the crawler when the worker ends
+        TPinnedPool& mPool;
+        std::unique_ptr<TPinned> mp;
+        ~TStagingLease() { mPool.Release(std::move(mp)); }
+      } Lease{StagingPool, StagingPool.Acquire(0)};
+      TPinned& Staging = *Lease.mp;
       std::vector<std::unique_ptr<TWaveFile>> Waves;
       std::vector<std::vector<unsigned char>> Widened;
       for (;;) {
@@ -309,6 +345,18 @@ TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCra
 
 }  // namespace afec
 
+namespace {
+std::mutex gCrawlerMutex, gCrawlMutex;
+std::vector<std::pair<std::string, afec::TCrawler*>> gCrawlers;   // never destroyed at exit: the HIP runtime may be gone by then
+}  // namespace
+
+extern "C" void afec_crawl_release(void) {
+  std::lock_guard<std::mutex> Lock(gCrawlerMutex);
+  std::lock_guard<std::mutex> Lock2(gCrawlMutex);
+  for (auto& Entry : gCrawlers) delete Entry.second;
+  gCrawlers.clear();
+}
+
 extern "C" int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
                                       const int32_t* devices, int32_t n_devices, int32_t workers_per_device,
                                       int32_t files_per_batch, const char* database_path, double* stats, char* error,
@@ -326,7 +374,24 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     if (workers_per_device > 0) Options.mWorkersPerDevice = workers_per_device;
     if (files_per_batch > 0) Options.mFilesPerBatch = files_per_batch;
     if (database_path) Options.mDatabasePath = database_path;
-    const afec::TCrawlStatistics s = afec::CrawlWaveFiles(Files, Options);
+    // one crawler per (devices, geometry), kept between calls
+    afec::TCrawler* pCrawler = nullptr;
+    {
+      std::string Key;
+      for (int d : Options.mDevices) Key += std::to_string(d) + ",";
+      std::lock_guard<std::mutex> Lock(gCrawlerMutex);
+      for (auto& Entry : gCrawlers)
+        if (Entry.first == Key) pCrawler = Entry.second;
+      if (!pCrawler) {
+        pCrawler = new afec::TCrawler(Options);
+        gCrawlers.emplace_back(Key, pCrawler);
+      }
+    }
+    afec::TCrawlStatistics s;
+    {
+      std::lock_guard<std::mutex> Lock(gCrawlMutex);   // one crawl at a time per crawler
+      s = pCrawler->Crawl(Files, Options);
+    }
     if (stats) {
       stats[0] = (double)s.mFiles; stats[1] = (double)s.mFailedFiles; stats[2] = (double)s.mFrames; stats[3] = (double)s.mPcmBytes;
       stats[4] = (double)s.mResultBytes; stats[5] = s.mSeconds; stats[6] = s.mWriterSeconds;

@@ -52,10 +52,27 @@ inline int ShardOfFile(int64_t FileIndex, int NumberOfDevices) { return (int)(Fi
 // that cannot be read or analysed are counted / inserted as failed samples, SampleAnalyser.cpp:397-408)
 TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCrawlOptions& Options);
 
+// The same with the set-up kept between crawls: the analysers (one plan per device and its pooled device workspaces)
+// and the page-locked staging / result buffers.  Options of later crawls must name the same devices and geometry;
+// workers, batch size and database may differ.  One crawl at a time per crawler.
+class TCrawler {
+public:
+  explicit TCrawler(const TCrawlOptions& Options);
+  ~TCrawler();
+  TCrawler(const TCrawler&) = delete;
+  TCrawler& operator=(const TCrawler&) = delete;
+  TCrawlStatistics Crawl(const std::vector<TCrawlFile>& Files, const TCrawlOptions& Options);
+
+private:
+  struct TImpl;
+  TImpl* mpImpl;
+};
+
 }  // namespace afec
 
 extern "C" {
-// C entry point of CrawlWaveFiles for callers without C++ (bench.py, tests): file images in memory.
+// C entry point of CrawlWaveFiles for callers without C++ (bench.py, tests): file images in memory.  The process keeps
+// one TCrawler per (devices, geometry) between calls (afec_crawl_release drops them), so a second crawl starts warm.
 // stats: [files, failed, frames, pcm_bytes, result_bytes, seconds, writer_seconds, files on device 0, 1, ...];
 // returns 0, or -1 with the message in error.
 int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
@@ -67,4 +84,5 @@ int afec_crawl_wave_images(const char* const* names, const void* const* images, 
 int afec_wave_probe(const void* image, int64_t size, int64_t* props /* [7] */, void* payload, int64_t payload_capacity,
                     char* error, int32_t error_size);
 int afec_shard_of_file(int64_t file_index, int32_t n_devices);
+void afec_crawl_release(void);
 }

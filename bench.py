@@ -110,17 +110,21 @@ def wav_image(pcm_i16, channels, rate=44100):
 
 def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=3, files_per_batch=128):
     """The streaming host driver (afec_amd/host/Crawler.cpp) on this rank's share of the crawl: files/s and frames/s
-    with every transfer inside the timed region."""
+    with every transfer inside the timed region.  The crawler (plans, device workspaces, page-locked buffers) persists
+    between the repeats: the first one is the cold crawl ("cold_seconds"), the best one the warm rate."""
     from afec_amd import hostlib
     files = make_c3_files(64, seed) if workload == "c3" else make_c4_files(64, seed)
     channels = 1 if workload == "c3" else 2
     pool = [wav_image(f, channels) for f in files]
     images = [pool[i % len(pool)] for i in range(n_files)]
-    best = None
+    best, cold = None, None
     for _ in range(repeats):
         st = hostlib.crawl(images, devices=(device,), workers=workers, files_per_batch=files_per_batch, database=database)
+        if cold is None:
+            cold = st["seconds"]
         if best is None or st["seconds"] < best["seconds"]:
             best = st
+    best = dict(best, cold_seconds=cold)
     return best
 
 
@@ -276,9 +280,11 @@ def main():
                 "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": seconds * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"{args.workload.upper()} end to end: {n_files} WAV images per GPU in host memory -> streaming host "
-                                       f"driver ({args.workers} workers per GPU, page-locked staging) -> LoadSample + every per-frame "
-                                       f"descriptor + statistics -> records back in host memory; transfers inside the timed region",
+                                       f"driver ({args.workers} workers per GPU, page-locked staging) -> LoadSample + every low-level "
+                                       f"descriptor + statistics -> records back in host memory; transfers inside the timed region; "
+                                       f"best of {max(1, args.steps // 5)} crawls of one process (the crawler persists between them)",
                            "files_per_s": files_all / seconds, "files_per_gpu": n_files,
+                           "cold_files_per_s_per_gpu": st["files"] / st["cold_seconds"],
                            "upload_GB_per_s_per_gpu": st["pcm_bytes"] / st["seconds"] / 1e9,
                            "download_GB_per_s_per_gpu": st["result_bytes"] / st["seconds"] / 1e9,
                            "parallelism": f"replicas x{world} (files sharded i mod N, no collective)"}}))
@@ -348,10 +354,11 @@ def main():
     e2e = None
     if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
         try:
-            st = end_to_end("c4", 12500, device, 3, 99, repeats=2, files_per_batch=256)
+            st = end_to_end("c4", 12500, device, 3, 99, repeats=3, files_per_batch=256)
             e2e = {"workload": "C4 share: 12 500 stereo 1.0 s 16-bit WAV images in host memory -> RIFF parse -> page-locked staging -> "
                                "upload -> LoadSample + every low-level descriptor (per-frame set and rhythm tracker) + statistics -> records back in host memory",
                    "files_per_s": st["files"] / st["seconds"], "frames_per_s": st["frames"] / st["seconds"],
+                   "cold_files_per_s": st["files"] / st["cold_seconds"],   # first crawl of the process: page-locked and device pools empty
                    "upload_GB_per_s": st["pcm_bytes"] / st["seconds"] / 1e9, "download_GB_per_s": st["result_bytes"] / st["seconds"] / 1e9,
                    "workers": 3, "files_per_batch": 256}
         except Exception as e:  # noqa: BLE001  (the headline must not depend on the host library)

@@ -62,3 +62,10 @@ def crawl(images, names=None, devices=(0,), workers=3, files_per_batch=256, data
     out = dict(zip(keys, list(stats)[:7]))
     out["files_per_device"] = [int(v) for v in list(stats)[7:]]
     return out
+
+
+def release():
+    """Drop the crawlers the process keeps between crawl() calls (plans, device workspaces, page-locked buffers)."""
+    L = lib()
+    L.afec_crawl_release.restype = None
+    L.afec_crawl_release()

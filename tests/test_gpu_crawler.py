@@ -131,6 +131,35 @@ def test_crawl_without_a_database_and_small_batches():
     assert a["failed"] == 2 and a["frames"] > 0 and a["writer_seconds"] == 0.0
 
 
+def test_crawler_persists_between_crawls_and_can_be_released(tmp_path):
+    """The process keeps its crawler (plans, device workspaces, page-locked buffers) between crawls: a second crawl and
+    a crawl after afec_crawl_release write the same database rows as the first."""
+    import hashlib
+    images, names, _ = make_crawl(30)
+
+    def rows_of(db):
+        con = sqlite3.connect(db)
+        cols = [r[1] for r in con.execute("PRAGMA table_info(assets)")]
+        out = {}
+        for r in con.execute("SELECT * FROM assets ORDER BY filename"):
+            h = hashlib.sha256()
+            for c, v in zip(cols, r):
+                if c != "modtime":
+                    h.update(repr(v).encode() if not isinstance(v, bytes) else v)
+            out[r[0]] = h.hexdigest()
+        con.close()
+        return out
+
+    dbs = [str(tmp_path / f"crawl{i}.db") for i in range(3)]
+    _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=8, database=dbs[0])
+    _host.crawl(images, names, devices=(0,), workers=3, files_per_batch=16, database=dbs[1])     # warm crawler, other batching
+    from afec_amd import hostlib
+    hostlib.release()
+    _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=64, database=dbs[2])     # a fresh crawler again
+    a, b, c = (rows_of(d) for d in dbs)
+    assert len(a) == len(images) and a == b == c
+
+
 def test_crawl_is_sharded_over_devices():
     import ctypes
     n = ctypes.c_int(0)

@@ -163,10 +163,11 @@ struct Workspace {
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
   Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff;   // rhythm tracker
+  Buf stat_tmp;                                                                 // half-wave statistics class
   size_t bytes() const {
     return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
            efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap + queue.cap + rt_files.cap + rt_odf.cap +
-           rt_onsets.cap + rt_scratch.cap + rt_scalars.cap + rt_stats.cap + rt_foff.cap;
+           rt_onsets.cap + rt_scratch.cap + rt_scalars.cap + rt_stats.cap + rt_foff.cap + stat_tmp.cap;
   }
 };
 
@@ -222,6 +223,7 @@ struct afx_batch {
   int64_t* d_frame_offset = nullptr;
   double* d_stats = nullptr;
   unsigned* d_queue = nullptr;   // work-queue counter of the half-wave frame kernel (lives in the workspace)
+  double* d_stat_tmp = nullptr;  // half-wave statistics class: raw sums per frame
   std::vector<int64_t> arena_off, used;  // per buffer: start and length (samples) of its analysed prefix in d_pcm
   // rhythm tracker (AFX_D_RHYTHM)
   std::vector<int64_t> rt_offset;          // [n_bufs+1]: rows of the 512/128 frames
@@ -392,7 +394,7 @@ void ws_free(Workspace* w) {
   if (!w) return;
   for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
                             &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place, &w->queue, &w->rt_files, &w->rt_odf,
-                            &w->rt_onsets, &w->rt_scratch, &w->rt_scalars, &w->rt_stats, &w->rt_foff}) hipFree(b->p);
+                            &w->rt_onsets, &w->rt_scratch, &w->rt_scalars, &w->rt_stats, &w->rt_foff, &w->stat_tmp}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->ev_fork) hipEventDestroy(w->ev_fork);
@@ -851,6 +853,10 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
       w.queue_count = 0;
     }
     b->d_queue = (unsigned*)w.queue.p;
+    if (fmask != 1u) {   // statistics class: raw sums per frame for its closed-form kernel
+      if ((e = ws_reserve(w.stat_tmp, (size_t)frames * 8 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stat_tmp)"));
+      b->d_stat_tmp = (double*)w.stat_tmp.p;
+    }
   }
   if (b->n_chunks > 0 && (mask & kTimeBits)) {
     if ((e = ws_reserve(w.rem, remaining.size() * sizeof(afx::ChunkRemaining))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(remaining)"));
@@ -1301,7 +1307,8 @@ int afx_batch_run(afx_batch* b) {
       a.queue = b->d_queue;
       a.queue_base = b->ws->queue_count;
       b->ws->queue_count += (unsigned)((b->n_chunks + 1) / 2);
-      HIP_TRY(afx::launch_frames32(a, b->grid_blocks, b->stream));
+      a.stat_tmp = b->d_stat_tmp;
+      HIP_TRY(afx::launch_frames32(a, b->grid_blocks, b->stream, b->total_frames));
     } else HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
   }
   if (b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) {

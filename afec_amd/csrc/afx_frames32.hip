@@ -43,8 +43,8 @@ struct Lds32 {
   static constexpr int tw = 0;                              // [32][32] cx<double>: w1024^(n2 k1)
   static constexpr int post = tw + 32 * 32 * 16;            // [POST_ROWS][32] cx<double>: w2048^(q + 32 r)
   static constexpr int dct = post + POST_ROWS * 32 * 16;    // [14][16] double
-  static constexpr int logc = dct + 14 * 16 * 8;            // 16 doubles: constants of the logarithm (kLogConst)
-  static constexpr int xchg = logc + 16 * 8;                // kWaves32 planes
+  static constexpr int logc = dct + 14 * 16 * 8;            // 32 doubles: constants of the logarithm and of the statistics (kLogConst)
+  static constexpr int xchg = logc + 32 * 8;                // kWaves32 planes
   static constexpr int total = xchg + kWaves32 * kPlane32Bytes;
 };
 
@@ -104,9 +104,16 @@ __device__ __forceinline__ double half_sum16(double (&a)[16], int lane) {
 // Constants of finish_mfcc32's logarithm.  They live in LDS and are read where they are used: as literals the
 // compiler keeps every one of them in a vector register pair for the whole kernel (no 64-bit literals on
 // gfx950's VOP3), which this kernel cannot afford.
-__device__ const double kLogConst[16] = {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0,
+__device__ const double kLogConst[32] = {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0 / 17.0, 1.0 / 15.0, 1.0 / 13.0,
                                          1.0 / 11.0, 1.0 / 9.0,  1.0 / 7.0,  1.0 / 5.0,  1.0 / 3.0,  0.693147180559945309417,
-                                         0.70710678118654752440, 2e-42, 0.0, 0.0};
+                                         0.70710678118654752440, 2e-42,
+                                         // constants of the statistics class (kC* below)
+                                         1e-20, 32.0, 0.38268343236508984, -0.9238795325112867, 1.0 / 738.0,
+                                         (double)(85.0f / 100.0), 43.0, -1.0 / 60.0, (double)1e-12f, 3.0,
+                                         1.44269504088896340736, 20.0 / 2.30258509299404568402, 2.2250738585072014e-308, 1.4916681477317095e-154, 0.0, 0.0, 0.0, 0.0};
+// indices into kLogConst of the statistics class' constants
+constexpr int kCEps = 14, kC32 = 15, kCRotRe = 16, kCRotIm = 17, kCInvN = 18, kCRoll = 19, kCBinHz = 20, kCDb60 = 21,
+              kCTiny = 22, kCThree = 23, kCLog2e = 24, kCDbScale = 25, kCMin = 26, kCSqrtMin = 27;
 
 // natural log of a positive normal double: frexp + atanh series (|s| <= 0.1716), ~1e-16 absolute on log(m)
 __device__ __forceinline__ double log_lds(double x, const double* c) {
@@ -172,8 +179,9 @@ __device__ __forceinline__ void finish_mfcc32(double acc, double*& recp, int& le
 
 template <int FEAT>
 __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs a) {
-  constexpr int MR = kMel32Rows;   // rows of 32 bins whose magnitudes are needed: bins 0..383
-  using Map = Lds32<MR>;
+  // rows of 32 bins whose magnitudes are needed: bins 0..383 for the mel filters, 0..767 for the spectral statistics
+  constexpr int MR = (FEAT == 1) ? 24 : kMel32Rows;
+  using Map = Lds32<kMel32Rows>;   // untangle factors of rows 0..11; rows 12..23 are those times w2048^384
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: SGPR arithmetic
@@ -181,9 +189,9 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 
   // ---- shared tables ----
   copy_lds_table(lds_raw + Map::tw, a.tw32, 32 * 32 * 16, threadIdx.x, kWaves32 * 64);
-  copy_lds_table(lds_raw + Map::post, a.post32, MR * 32 * 16, threadIdx.x, kWaves32 * 64);
+  copy_lds_table(lds_raw + Map::post, a.post32, kMel32Rows * 32 * 16, threadIdx.x, kWaves32 * 64);
   copy_lds_table(lds_raw + Map::dct, a.dct, 14 * 16 * 8, threadIdx.x, kWaves32 * 64);
-  copy_lds_table(lds_raw + Map::logc, kLogConst, 16 * 8, threadIdx.x, kWaves32 * 64);
+  copy_lds_table(lds_raw + Map::logc, kLogConst, 32 * 8, threadIdx.x, kWaves32 * 64);
 #if AFX_STAMPS
   unsigned stamp_acc[16] = {};
   unsigned long long life_core0, life_real0;
@@ -373,20 +381,56 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       cx<double> pp[MR];
       double2 pw2[MR];
       double mwt[kMel32Pairs];
+      // statistics class: per-lane partial sums over this lane's bins of the analysis range (bins 1..738, j = bin - 1):
+      // sum m, m^2, j m, j^2 m, m^3, m^4 and the product of (m + 1e-20) in two halves (24 factors would underflow)
+      double s1 = 0.0, s2 = 0.0, sj = 0.0, sjj = 0.0, s3 = 0.0, s4 = 0.0, prod_a = 1.0, prod_b = 1.0;
+      double jq = 0.0, pa = 0.0;
+      // statistics class: magnitudes of rows 0..11 wait here for the rolloff walk (upper part of the wave's exchange
+      // plane: 384 doubles per half behind the 8 KiB the hop DMA writes)
+      double* const park = reinterpret_cast<double*>(plane_bytes + 8192 + 4352 * h);
+      if (FEAT == 1) {
+        int ql = lane;
+        asm volatile("" : "+v"(ql));
+        jq = (double)((ql & 31) - 1);
+      }
+      // statistics class: one row's contribution to the sums (rows 0..11 after the mel stage, when the registers of
+      // the FFT are free; rows 12..23 as they are produced).  Bins 1..738: row 0 without bin 0, row 23 only bins
+      // 736..738; magnitudes below sqrt(DBL_MIN) are 0 in the reference (TAudioMath::Magnitude runs with DAZ + FZ): a
+      // silent frame has centroid 0, not (n - 1) / 2
+      auto accumulate = [&](int r) {
+        const bool ok = ((r == 0) ? (q != 0) : ((r == 23) ? (q <= 2) : true)) && mag[r] > logc[kCSqrtMin];
+        const double m = ok ? mag[r] : 0.0;
+        const double m2 = m * m;
+        const double jm = jq * m;
+        s1 += m;
+        s2 += m2;
+        sj += jm;
+        sjj = fma(jq, jm, sjj);
+        s3 = fma(m2, m, s3);
+        s4 = fma(m2, m2, s4);
+        const double f = ok ? (mag[r] + logc[kCEps]) : 1.0;
+        if (r < 12) prod_a *= f; else prod_b *= f;
+        jq += logc[kC32];
+      };
       auto fetch = [&](int r) {
         pp[r] = {__shfl(v[31 - r].re, partner), __shfl(v[31 - r].im, partner)};
-        pw2[r] = post[32 * r];
+        pw2[r] = post[32 * (r % kMel32Rows)];
       };
       auto untangle = [&](int r) {
         cx<double> p = pp[r];
         if (q == 0) p = v[(32 - r) & 31];
         const cx<double> z = v[r];
-        const double2 wq = pw2[r];
+        double2 wq = pw2[r];
+        if (r >= kMel32Rows) {   // w2048^(q + 32 r) = w2048^(q + 32 (r - 12)) w2048^384
+          const double cr = logc[kCRotRe], ci = logc[kCRotIm];
+          wq = double2{fma(wq.x, cr, -wq.y * ci), fma(wq.x, ci, wq.y * cr)};
+        }
         const double er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
         const double orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
         const double xr = fma(wq.x, orr, fma(-wq.y, oi, er));
         const double xi = fma(wq.x, oi, fma(wq.y, orr, ei));
         mag[r] = mag_sqrt_mel(xr * xr + xi * xi);
+        if (FEAT == 1 && r >= kMel32Rows) accumulate(r);
       };
 #pragma unroll
       for (int r = 0; r < 4; ++r) fetch(r);
@@ -422,12 +466,123 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
             if (mel32_touches(f, r)) e[f] += mag[r] * mwt[mel32_pair_index(r, f)];
         __builtin_amdgcn_sched_barrier(0);
         AFX_STAMP(7);   // mel rows (waits for the table loads)
-        // the next frame's window pairs, under the reduction and the log / DCT
+        if (FEAT == 1) {
+          // statistics class: the mel sums are reduced first (their registers are needed), then rows 12..23
+          const double tot1 = half_sum16(e, lane);
+          if ((lane & 1) == (fi & 1)) mel_acc = tot1;
 #pragma unroll
-        for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
-        const double tot = half_sum16(e, lane);  // lane L: filter (L & 31) >> 1 of this half's frame
-        if ((lane & 1) == (fi & 1)) mel_acc = tot;
+          for (int r = 0; r < kMel32Rows; ++r) accumulate(r);
+          // rows 0..11 are needed once more (rolloff): their row sums now, the values parked in the part of the
+          // exchange plane that the hop DMA does not use
+          {
+            double ra[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ra[r] = (r < 12) ? ((r == 0 && q == 0) ? 0.0 : mag[r]) : 0.0;
+            pa = half_sum16(ra, lane);               // lane L: row (L & 31) >> 1
+#pragma unroll
+            for (int r = 0; r < 12; ++r) park[32 * r + q] = mag[r];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 12; r < 16; ++r) fetch(r);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 16; r < 20; ++r) fetch(r);
+#pragma unroll
+          for (int r = 12; r < 16; ++r) untangle(r);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 20; r < 24; ++r) fetch(r);
+#pragma unroll
+          for (int r = 16; r < 20; ++r) untangle(r);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 20; r < 24; ++r) untangle(r);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next frame's window pairs, under the reduction and the log / DCT (statistics class: behind its sums,
+        // which need the registers)
+        if (FEAT == 0) {
+#pragma unroll
+          for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
+        }
+        if (FEAT == 0) {
+          const double tot = half_sum16(e, lane);  // lane L: filter (L & 31) >> 1 of this half's frame
+          if ((lane & 1) == (fi & 1)) mel_acc = tot;
+        }
         AFX_STAMP(8);   // window issue + reduction
+        if (FEAT == 1) {
+          // ---- spectral statistics (SA:1808-1933): the sums of this half's frame, reduced over its 32 lanes; the
+          //      closed forms (sqrt, divisions, exp / log of the flatness) are left to stats32_finish_kernel ----
+          int ln = lane;
+          asm volatile("" : "+v"(ln));
+          const int hq = ln & 31;
+          double st[16];
+          st[0] = s1; st[1] = s2; st[2] = sj; st[3] = sjj; st[4] = s3; st[5] = s4;
+          st[6] = log_lds(prod_a, logc) + log_lds(prod_b, logc);
+#pragma unroll
+          for (int i = 7; i < 16; ++i) st[i] = 0.0;
+          const double red = half_sum16(st, ln);    // lane L: st[(L & 31) >> 1]
+          const int64_t row = (int64_t)ch.frame0 + fi;
+          const bool live = fi < nfr;
+          double* const tmp = a.stat_tmp + row * 8;
+          if (live && (hq & 1) == 0 && (hq >> 1) < 7) tmp[hq >> 1] = red;
+          // ---- rolloff (scalar.c:472-492): bins whose running sum stays below 85 % of the total ----
+          const int base_idx = (ln & 32) << 2;       // byte index of lane 32 h for ds_bpermute
+          const double total = __hiloint2double(__builtin_amdgcn_ds_bpermute(base_idx, __double2hiint(red)),
+                                                __builtin_amdgcn_ds_bpermute(base_idx, __double2loint(red)));
+          const double pivot = total * logc[kCRoll];
+          // row sums of rows 12..23 (rows 0..11: pa, taken before they were parked in LDS)
+          double rb[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) rb[r] = (r < 11) ? mag[12 + r] : ((r == 11 && hq <= 2) ? mag[23] : 0.0);
+          double pb = half_sum16(rb, ln);            // lane L: row 12 + ((L & 31) >> 1)
+          // inclusive prefix over the row slots of a half (both lanes of a slot hold the same value)
+#pragma unroll
+          for (int o = 2; o < 32; o <<= 1) {
+            const double ua = __shfl_up(pa, o, 32), ub = __shfl_up(pb, o, 32);
+            if (hq >= o) { pa += ua; pb += ub; }
+          }
+          const int last_idx = base_idx + (22 << 2);   // slot 11
+          const double tot_a = __hiloint2double(__builtin_amdgcn_ds_bpermute(last_idx, __double2hiint(pa)),
+                                                __builtin_amdgcn_ds_bpermute(last_idx, __double2loint(pa)));
+          pb += tot_a;
+          // rows wholly below the pivot (inclusive prefix < pivot)
+          const unsigned long long ma = __ballot((hq & 1) == 0 && (hq >> 1) < 12 && pa < pivot);
+          const unsigned long long mb = __ballot((hq & 1) == 0 && (hq >> 1) < 12 && pb < pivot);
+          const unsigned halfmask_shift = ln & 32;
+          const int rstar = __popc((unsigned)(ma >> halfmask_shift)) + __popc((unsigned)(mb >> halfmask_shift));
+          // running sum before row rstar
+          const int prev = rstar - 1;
+          const int slot = (prev < 12) ? prev : prev - 12;
+          const int idx_a = base_idx + ((2 * (slot & 15)) << 2);
+          const double base_a = __hiloint2double(__builtin_amdgcn_ds_bpermute(idx_a, __double2hiint(pa)),
+                                                 __builtin_amdgcn_ds_bpermute(idx_a, __double2loint(pa)));
+          const double base_b = __hiloint2double(__builtin_amdgcn_ds_bpermute(idx_a, __double2hiint(pb)),
+                                                 __builtin_amdgcn_ds_bpermute(idx_a, __double2loint(pb)));
+          const double before = (rstar == 0) ? 0.0 : ((prev < 12) ? base_a : base_b);
+          // the crossing row's magnitudes, summed along the lanes: rows 0..11 from their LDS parking place
+          double xs = park[32 * (rstar < 12 ? rstar : 0) + hq];
+#pragma unroll
+          for (int r = 12; r < 24; ++r) xs = (rstar == r) ? mag[r] : xs;
+          const bool okq = (rstar == 0) ? (hq != 0) : ((rstar == 23) ? (hq <= 2) : (rstar < 23));
+          xs = okq ? xs : 0.0;
+          double run = xs;
+#pragma unroll
+          for (int o = 1; o < 32; o <<= 1) {
+            const double u = __shfl_up(run, o, 32);
+            if (hq >= o) run += u;
+          }
+          const unsigned long long mrow = __ballot(okq && (before + run) < pivot);
+          const int in_row = __popc((unsigned)(mrow >> halfmask_shift));
+          const int below = 32 * rstar - (rstar > 0 ? 1 : 0) + in_row;
+          int cnt = (pivot > 0.0) ? below + 1 : 0;
+          cnt = cnt > kBinCount ? kBinCount : cnt;
+          if (live && hq == 0) tmp[7] = (double)cnt;
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
+        }
         if (fi & 1) finish_mfcc32(mel_acc, recp, left, stride2, dct, logc, lane);
         AFX_STAMP(9);   // log + DCT + store (every second iteration)
 #if AFX_STAMPS
@@ -453,20 +608,64 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 #endif
 }
 
+// Closed forms of the spectral statistics from the raw sums the statistics-class kernel left per frame
+// (SA:1808-1933; the same formulas as afx_kernels.hip, with the second moments expanded around the centroid):
+// tmp[f] = {sum m, sum m^2, sum j m, sum j^2 m, sum m^3, sum m^4, sum log(m + 1e-20), rolloff count}
+__global__ __launch_bounds__(256) void stats32_finish_kernel(const FrameArgs a, int64_t n_frames) {
+  const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (f >= n_frames) return;
+  const double* t = a.stat_tmp + f * 8;
+  const double s1 = t[0], s2 = t[1], sj = t[2], sjj = t[3], s3 = t[4], s4 = t[5], slog = t[6], cnt = t[7];
+  double* const rec = a.rec + f * a.lay.stride;
+  const double n = (double)kBinCount, inv_n = 1.0 / (double)kBinCount;
+  if (a.mask & (1u << 1)) rec[a.lay.srms] = nan_to_zero(sqrt(s2 * inv_n));
+  if (a.mask & 0x3Cu) {
+    double cen = 0.0, spr = 0.0;
+    if (s1 != 0.0) {
+      cen = sj / s1;
+      spr = (sjj - cen * sj) / s1;      // sum (j - cen)^2 m = sum j^2 m - cen sum j m
+    }
+    if (a.lay.centroid >= 0) rec[a.lay.centroid] = cen;
+    if (a.lay.spread >= 0) rec[a.lay.spread] = spr;
+    if (a.mask & 0x30u) {
+      double sk = 0.0, ku = 0.0;
+      if (fabs(spr) > (double)1e-12f) {
+        const double inv = 1.0 / spr, c2 = cen * cen;
+        // sum (m - cen)^3 and sum (m - cen)^4 over the 738 bins
+        const double m3 = s3 - 3.0 * cen * s2 + 3.0 * c2 * s1 - n * c2 * cen;
+        const double m4 = s4 - 4.0 * cen * s3 + 6.0 * c2 * s2 - 4.0 * c2 * cen * s1 + n * c2 * c2;
+        const double i2 = inv * inv;
+        sk = m3 * i2 * inv * inv_n;
+        ku = m4 * i2 * i2 * inv_n - 3.0;
+      }
+      if (a.lay.skew >= 0) rec[a.lay.skew] = sk;
+      if (a.lay.kurt >= 0) rec[a.lay.kurt] = ku;
+    }
+  }
+  if (a.mask & (1u << 7)) {
+    const double gm = fast_exp(slog * inv_n);
+    const double am = s1 * inv_n;
+    const double fl = (am == 0.0) ? 0.0 : gm / am;
+    const double d = lin_to_db(fl) * (-1.0 / 60.0);
+    rec[a.lay.flatness] = nan_to_zero(d < 1.0 ? d : 1.0);
+  }
+  if (a.mask & (1u << 6)) rec[a.lay.rolloff] = cnt * (double)(kSampleRate / (kFft / 2));
+}
+
 }  // namespace
 
 int frames32_waves_per_block() { return kWaves32; }
 
-// which (descriptor mask, arithmetic, PCM type) combinations the half-wave kernels serve
+// which (descriptor mask, arithmetic, PCM type) combinations the half-wave kernels serve: MFCC alone, or MFCC with any
+// of the spectral statistics rms / centroid / spread / skewness / kurtosis / rolloff / flatness (bits 1..7)
 bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype) {
-  return mask == 1u && precision == 0 && pcm_dtype == 0;
+  return (mask & 1u) && !(mask & ~0xFFu) && precision == 0 && pcm_dtype == 0;
 }
 
-// MFCC-only class, f64 arithmetic, f32 PCM
-hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream) {
-  if (a.n_chunks <= 0) return hipSuccess;
+template <int FEAT>
+static hipError_t launch_frames32_class(const FrameArgs& a, int grid_blocks, hipStream_t stream) {
   constexpr int lds = Lds32<kMel32Rows>::total;
-  auto k = frames32_kernel<0>;
+  auto k = frames32_kernel<FEAT>;
   static bool attribute_set[16] = {};   // per device: raising the dynamic LDS limit once is enough
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -476,6 +675,17 @@ hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stre
     if (dev >= 0 && dev < 16) attribute_set[dev] = true;
   }
   hipLaunchKernelGGL(k, dim3(grid_blocks), dim3(kWaves32 * 64), lds, stream, a);
+  return hipGetLastError();
+}
+
+// f64 arithmetic, f32 PCM: the MFCC-only class, or the statistics class (a.mask has bits 1..7, a.stat_tmp holds
+// total_frames x 8 doubles) followed by its closed-form kernel
+hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames) {
+  if (a.n_chunks <= 0) return hipSuccess;
+  if (a.mask == 1u) return launch_frames32_class<0>(a, grid_blocks, stream);
+  hipError_t e = launch_frames32_class<1>(a, grid_blocks, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(stats32_finish_kernel, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, stream, a, total_frames);
   return hipGetLastError();
 }
 

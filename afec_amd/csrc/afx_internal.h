@@ -121,7 +121,8 @@ struct FrameArgs {
   const void* melw32;  // [kMel32Pairs][32] packed mel rows
   unsigned* queue;     // work-queue counter of the half-wave kernels: advances by ceil(n_chunks / 2) per launch
   unsigned queue_base; // its value when this launch starts
-  unsigned long long* stamps;   // diagnostic builds (AFX_STAMPS): 16 per-stage cycle counters, else nullptr
+  unsigned long long* stamps;
+  double* stat_tmp;             // half-wave statistics class: [F][8] raw sums per frame (afx_frames32.hip)   // diagnostic builds (AFX_STAMPS): 16 per-stage cycle counters, else nullptr
 };
 
 // launchers (afx_kernels.hip).  precision: 0 = f64, 1 = f32; pcm_dtype: AFX_PCM_*
@@ -130,7 +131,7 @@ hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int g
 int frames_waves_per_block(uint32_t mask);    // waves (of 64 lanes) per workgroup
 // half-wave kernels (afx_frames32.hip): a wave walks two chunks at a time, one per 32-lane half
 bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype);
-hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream);
+hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames);
 int frames32_waves_per_block();
 int frames_feature_class(uint32_t mask);     // 0 = MFCC only, 1 = + statistics, 2 = everything
 

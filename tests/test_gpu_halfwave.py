@@ -121,3 +121,68 @@ def test_default_plan_picks_the_half_wave_kernel_for_large_batches(forced, oracl
     a, b = FIELDS["mfcc"]
     o = oracle.run(bufs[3][:2048 + 1024 * 40].astype(np.float64))
     _tol.check("mfcc", got[3 * 3000:3 * 3000 + 41], o[:, a:b], *_tol.GPU_TOL["mfcc"], what="large batch ")
+
+
+# ---- the statistics class of the half-wave kernel: MFCC + spectral rms / centroid / spread / skewness / kurtosis /
+#      rolloff / flatness (bins 0..767, sums reduced per half, closed forms in stats32_finish_kernel) ----
+STAT_FIELDS = ["mfcc", "spectral_rms", "spectral_centroid", "spectral_spread", "spectral_skewness", "spectral_kurtosis",
+               "spectral_rolloff", "spectral_flatness"]
+STAT_MASK = afx.D_MFCC | afx.D_SPECTRAL_STATS & ~afx.D_SPECTRAL_FLUX
+
+
+def check_stats(got, ref_rows, what):
+    for field in STAT_FIELDS:
+        if field not in got:
+            continue
+        a, b = FIELDS[field]
+        _tol.check(field, got[field].reshape(ref_rows.shape[0], -1), ref_rows[:, a:b], *_tol.GPU_TOL[field], what=what)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_statistics_class(forced, name):
+    z = np.load(os.path.join(GOLD, "frames.npz"))
+    x, ref = z["in_" + name], z["ref_" + name]
+    x32 = x.astype(np.float32)
+    if not np.array_equal(x32.astype(np.float64), x):
+        ref = Oracle().run(x32.astype(np.float64))
+    check_stats(forced.extract([x32], STAT_MASK), ref, name + " ")
+
+
+def test_statistics_class_ragged_batch_and_partial_masks(forced, lanes64, oracle):
+    rng = np.random.default_rng(15)
+    lens = [0, 2048, 3072, 2048 + 1024 * 5, 2048 + 1024 * 33, 2048 + 1024 * 64, 2047, 2048 + 1024 * 31, 2048 + 1024 * 70]
+    bufs = [rng.uniform(-1, 1, n).astype(np.float32) for n in lens]
+    t = np.arange(lens[4])
+    bufs[4] = (0.5 * np.sin(2 * np.pi * 1000.0 * t / 44100) + 0.2 * np.sin(2 * np.pi * 7000.0 * t / 44100)).astype(np.float32)
+    bufs[5][:] = 0.0                                      # silence: every sum is 0, flatness / rolloff special cases
+    bufs[8] = (rng.standard_normal(lens[8]) * np.exp(-np.arange(lens[8]) / 9000.0)).astype(np.float32)
+    star = afx.D_MFCC | afx.D_SPECTRAL_RMS | afx.D_SPECTRAL_CENTROID | afx.D_SPECTRAL_SPREAD | afx.D_SPECTRAL_ROLLOFF | afx.D_SPECTRAL_FLATNESS
+    for mask in (STAT_MASK, star, afx.D_MFCC | afx.D_SPECTRAL_KURTOSIS, afx.D_MFCC | afx.D_SPECTRAL_ROLLOFF):
+        got = forced.extract(bufs, mask)
+        ref64 = lanes64.extract(bufs, mask)
+        assert got["frame_offset"].tolist() == ref64["frame_offset"].tolist()
+        off = got["frame_offset"]
+        for i, x in enumerate(bufs):
+            if off[i + 1] == off[i]:
+                continue
+            o = oracle.run(x.astype(np.float64))
+            check_stats({k: v[off[i]:off[i + 1]] for k, v in got.items() if k in STAT_FIELDS}, o, f"mask {mask:#x} buffer {i} ")
+        # the two layouts agree far inside the tolerance (rolloff exactly)
+        if "spectral_rolloff" in got:
+            assert np.array_equal(got["spectral_rolloff"], ref64["spectral_rolloff"])
+        if "spectral_centroid" in got:
+            _tol.check("spectral_centroid", got["spectral_centroid"], ref64["spectral_centroid"], 1e-9, 1e-9, what="half-wave vs 64-lane ")
+
+
+def test_statistics_class_repeated_launches(forced):
+    rng = np.random.default_rng(29)
+    a = [rng.uniform(-1, 1, 2048 + 1024 * 150).astype(np.float32) for _ in range(5)]
+    first = forced.extract(a, STAT_MASK)
+    batch = forced.batch(a, STAT_MASK)
+    for _ in range(3):
+        batch.run()
+    batch.sync()
+    again = batch.fetch()
+    batch.close()
+    for f in STAT_FIELDS:
+        np.testing.assert_array_equal(again[f], first[f])

@@ -60,7 +60,7 @@ def main():
     rng = np.random.default_rng(seed)
     plan, oracle = afx.Plan(max_analysis_ms=0), Oracle()
     t0 = time.time()
-    rounds = frames = bad = skipped = rhythm_frames = 0
+    rounds = frames = bad = skipped = rhythm_frames = rhythm_gate_flips = 0
     while time.time() - t0 < seconds:
         bufs = []
         for _ in range(int(rng.integers(1, 7))):
@@ -72,6 +72,11 @@ def main():
         mask = int(rng.integers(1, 1 << 22)) & afx.D_ALL_PER_FRAME
         if mask == 0:
             mask = afx.D_ALL_PER_FRAME
+        if os.environ.get("AFX_FUZZ_STATS"):
+            # the statistics class of the half-wave kernel (run with AFX_HALFWAVE=2): MFCC + a random subset of
+            # spectral rms / centroid / spread / skewness / kurtosis / rolloff / flatness, float32 PCM
+            mask = afx.D_MFCC | (int(rng.integers(0, 128)) << 1)
+            bufs = [b.astype(np.float32) for b in bufs]
         res = plan.extract(bufs, mask)
         ref = np.concatenate([oracle.run(b.astype(np.float64)) for b in bufs]) if bufs else None
         nref = np.concatenate([oracle.run_neighbours(b.astype(np.float64)) for b in bufs])
@@ -193,7 +198,16 @@ def main():
                     continue
                 odf, wodf = rr["onset_functions"][sl].astype(np.float64), want["odf"].T.astype(np.float32).astype(np.float64)
                 scale = np.abs(wodf).max(axis=0) + 1e-30
-                ok = np.all(np.abs(odf - wodf) <= 2e-6 * np.abs(wodf) + 2e-7 * scale)
+                # The rectified complex-domain function sums a bin's deviation only when its whitened magnitude did not
+                # fall (OnsetDetector.cpp:419): a bin that sits exactly at its follower's maximum has the float value
+                # 1.0 in one FFT implementation and 1 - 2^-24 in another (the reference's IPP / vDSP / Ooura builds
+                # differ the same way), so a single term may enter or leave a frame's sum.  Such frames (at most 0.2 %)
+                # may deviate by a few terms' worth; everything else to a few float ulps.
+                dev_frames = np.abs(odf - wodf) > 2e-6 * np.abs(wodf) + 2e-7 * scale
+                flips = int(dev_frames[:, 0].sum())
+                ok = (not dev_frames[:, 1].any() and flips <= max(1, int(0.002 * odf.shape[0])) and
+                      np.all(np.abs(odf[:, 0] - wodf[:, 0]) <= 0.1))
+                rhythm_gate_flips += flips
                 for t in range(2):
                     ok = ok and np.array_equal(np.nonzero(rr["onsets"][sl, t])[0], np.nonzero(want["onsets"][t])[0])
                 finite = np.isfinite(want["scalars"])
@@ -205,7 +219,8 @@ def main():
                     print(f"round {rounds} rhythm tracker, buffer {i} ({b.size} samples): scalars {rr['scalars'][i]} vs {want['scalars']}; "
                           f"max onset-function error {np.max(np.abs(odf - wodf) / scale):.2e}")
         rounds += 1
-    print(f"{rounds} rounds, {frames} frames, {rhythm_frames} rhythm frames, {bad} mismatching (round, descriptor) pairs, "
+    print(f"{rounds} rounds, {frames} frames, {rhythm_frames} rhythm frames ({rhythm_gate_flips} with a rectification-gate flip), "
+          f"{bad} mismatching (round, descriptor) pairs, "
           f"{skipped} ill-conditioned frames left out of the discrete comparisons, seed {seed}")
     return 1 if bad else 0
 

@@ -344,11 +344,11 @@ def main():
         single = FRAMES_PER_BUFFER / (one.run_timed(50) / 50 * 1e-3)
         one.close()
 
-    # the descriptor set north_star names and the full spectral set as secondary numbers (16 buffers each)
+    # the descriptor set north_star names and the full spectral set as secondary numbers (32 buffers = 320 000 frames each)
     star_rate = all_rate = None
     if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
-        star_rate = secondary_rate(plan, star, 16)
-        all_rate = secondary_rate(plan, afx.D_ALL_LOW_LEVEL, 16)
+        star_rate = secondary_rate(plan, star, 32)
+        all_rate = secondary_rate(plan, afx.D_ALL_LOW_LEVEL, 32)
 
     # the streaming host driver on C4's per-GPU share, every transfer inside the timed region (secondary number)
     e2e = None

@@ -114,8 +114,14 @@ typedef struct {
                               0 disables the cap (synthetic benchmarks)                       */
 } afx_plan_desc;
 
-/* Environment read by afx_plan_create: AFX_HALFWAVE = 0 | 1 | 2 selects the frame kernel of the MFCC-only class
- * (0: 64-lane kernel, 1: by batch size (default), 2: half-wave kernel for every batch; results agree to rounding). */
+/* Environment read by afx_plan_create:
+ * AFX_HALFWAVE = 0 | 1 | 2 selects the frame kernel of the masks the half-wave layout serves (float PCM; AFX_D_MFCC alone
+ * or with any of AFX_D_SPECTRAL_RMS .. AFX_D_SPECTRAL_FLATNESS, bits 1..7): 0 = 64-lane kernel, 1 = by batch size
+ * (default), 2 = half-wave kernel for every batch; results agree to rounding.
+ * AFX_SIDE_STREAM = 0: the rhythm tracker's kernels run on the batch's own stream instead of beside the per-frame kernels
+ * (for profiles: per-kernel durations are then not inflated by overlap; results are identical).
+ * AFX_TIMING (any value, read when the library is loaded): wall time of the phases of afx_batch_create_from_raw, summed
+ * over calls, printed to stderr when the process ends -- a diagnostic for pipelines, no effect on results. */
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan);
 void afx_plan_destroy(afx_plan* plan);
 

@@ -447,11 +447,17 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       __builtin_amdgcn_sched_barrier(0);
       // the packed mel rows come from global memory (L1/L2-resident): issued here, when two thirds of the FFT
       // registers are dead
+      if (FEAT == 0) {
 #pragma unroll
-      for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
+        for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
+      }
 #pragma unroll
       for (int r = 8; r < 12; ++r) untangle(r);
       __builtin_amdgcn_sched_barrier(0);
+      if (FEAT == 1) {   // statistics class: behind the last rows (62 registers in flight that it cannot spare earlier)
+#pragma unroll
+        for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
+      }
       AFX_STAMP(6);   // untangle
 
       // ---- MFCC: sparse mel rows now; log + DCT once per two iterations (vector.c:350-391) ----

@@ -493,14 +493,16 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           for (int r = 12; r < 16; ++r) fetch(r);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int r = 16; r < 20; ++r) fetch(r);
-#pragma unroll
           for (int r = 12; r < 16; ++r) untangle(r);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int r = 20; r < 24; ++r) fetch(r);
+          for (int r = 16; r < 20; ++r) fetch(r);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 16; r < 20; ++r) untangle(r);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int r = 20; r < 24; ++r) fetch(r);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 20; r < 24; ++r) untangle(r);

@@ -956,28 +956,45 @@ struct CreateTiming {
   }
 };
 CreateTiming g_create_timing;
+
+// HIP multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and the packets of streams
+// that share a queue execute in order.  A pipeline keeps 2 streams per batch in flight plus the plan's two copy streams:
+// on 4 queues six to eight batches in flight serialise (205 k one-second files/s on one MI355X), on 16 they do not
+// (268 k).  Not more than 16: once a process has created more queues than the device has hardware slots for (between
+// 18 and 24 on this system) they are time-sliced, and the same crawl drops to 175 k files/s.  The variable is read
+// when the HIP runtime initialises, so it is set when this library is loaded, and only when the process has not
+// chosen a value itself.
+struct HwQueueDefault {
+  HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
+} g_hw_queue_default;
 inline long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-// One large host-to-device transfer through the plan's upload stream; `stream` (the batch's) continues after it.
-hipError_t upload_through_plan(afx_plan* plan, Workspace* ws, hipStream_t stream, void* dst, const void* src, size_t bytes) {
-  std::lock_guard<std::mutex> lock(plan->up_mutex);
-  hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, plan->up_stream);
-  if (e == hipSuccess) e = hipEventRecord(ws->ev_copy, plan->up_stream);
-  if (e == hipSuccess) e = hipStreamWaitEvent(stream, ws->ev_copy, 0);
-  return e;
+// One large host-to-device transfer through the plan's upload stream; returns when it has landed.  The wait is the
+// host's, not a hipStreamWaitEvent of the batch's stream: HIP multiplexes its streams onto a few hardware queues
+// (GPU_MAX_HW_QUEUES, 4 by default), and a barrier packet that waits for a 1.6 ms upload stalls every other stream
+// that shares the queue -- with six batches in flight the kernels of one batch and the uploads of the next then
+// exclude each other (measured: kernels busy 0.55, copies busy 0.59, either busy 0.85 of a crawl).
+hipError_t upload_through_plan(afx_plan* plan, Workspace* ws, void* dst, const void* src, size_t bytes) {
+  {
+    std::lock_guard<std::mutex> lock(plan->up_mutex);
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, plan->up_stream);
+    if (e == hipSuccess) e = hipEventRecord(ws->ev_copy, plan->up_stream);
+    if (e != hipSuccess) return e;
+  }
+  return hipEventSynchronize(ws->ev_copy);
 }
 // Device-to-host transfers of a batch's results through the plan's download stream, behind everything enqueued on the
-// batch's stream so far; returns when they have landed.
+// batch's stream so far (waited for on the host, for the same reason as above); returns when they have landed.
 struct Download { void* dst; const void* src; size_t bytes; };
 hipError_t download_through_plan(afx_batch* b, const Download* items, int n) {
   afx_plan* plan = b->plan;
   Workspace* ws = b->ws;
+  hipError_t e = hipStreamSynchronize(b->stream);
+  if (e != hipSuccess) return e;
   {
     std::lock_guard<std::mutex> lock(plan->down_mutex);
-    hipError_t e = hipEventRecord(ws->ev_copy, b->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(plan->down_stream, ws->ev_copy, 0);
     for (int i = 0; i < n && e == hipSuccess; ++i)
       if (items[i].dst && items[i].bytes) e = hipMemcpyAsync(items[i].dst, items[i].src, items[i].bytes, hipMemcpyDeviceToHost, plan->down_stream);
     if (e == hipSuccess) e = hipEventRecord(ws->ev_copy, plan->down_stream);
@@ -1173,7 +1190,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
         contiguous = ((const char*)raws[i].data == base + files[i].raw_off);
       }
     if (contiguous && base) {
-      if ((e = upload_through_plan(plan, ws, s, d_raw, base, (size_t)raw_bytes)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
+      if ((e = upload_through_plan(plan, ws, d_raw, base, (size_t)raw_bytes)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
     } else {
       for (int i = 0; i < n_bufs; ++i)
         if (status[i] == AFX_OK) {

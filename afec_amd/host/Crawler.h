@@ -30,8 +30,8 @@ struct TCrawlFile {
 
 struct TCrawlOptions {
   std::vector<int> mDevices = {0};  // HIP device ordinals
-  int mWorkersPerDevice = 3;        // host threads (= batches in flight) per device
-  int mFilesPerBatch = 256;         // measured best on one MI355X for 1 s stereo files (profiles/r02/README.md)
+  int mWorkersPerDevice = 8;        // host threads (= batches in flight) per device
+  int mFilesPerBatch = 512;         // measured best on one MI355X for 1 s stereo files (profiles/r02/README.md)
   std::string mDatabasePath;        // empty: results are counted, not stored
   int mSampleRate = 44100, mFftFrameSize = 2048, mHopFrameSize = 1024;
 };

@@ -42,7 +42,7 @@ def wave_probe(image):
     return d, payload[:d["payload_bytes"]].tobytes()
 
 
-def crawl(images, names=None, devices=(0,), workers=3, files_per_batch=256, database=None):
+def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, database=None):
     """images: list of bytes (WAV file images).  -> dict of statistics."""
     L = lib()
     n = len(images)

@@ -51,8 +51,8 @@ def parse_args():
                     help="with --workload c3|c4: time the streaming host driver instead (WAV images in host memory -> RIFF "
                          "parse -> page-locked staging -> upload -> LoadSample + every descriptor + statistics -> results "
                          "back in host memory); value = frames/s including every transfer")
-    ap.add_argument("--workers", type=int, default=3, help="host threads (batches in flight) per GPU of --end-to-end")
-    ap.add_argument("--files-per-batch", type=int, default=256, help="files per GPU batch of --end-to-end")
+    ap.add_argument("--workers", type=int, default=8, help="host threads (batches in flight) per GPU of --end-to-end")
+    ap.add_argument("--files-per-batch", type=int, default=512, help="files per GPU batch of --end-to-end")
     ap.add_argument("--cpu-frames", type=int, default=30000, help="frames per CPU worker for the baseline")
     return ap.parse_args()
 
@@ -108,7 +108,7 @@ def wav_image(pcm_i16, channels, rate=44100):
     return b"RIFF" + struct.pack("<I", len(body)) + body
 
 
-def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=3, files_per_batch=128):
+def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=3, files_per_batch=512):
     """The streaming host driver (afec_amd/host/Crawler.cpp) on this rank's share of the crawl: files/s and frames/s
     with every transfer inside the timed region.  The crawler (plans, device workspaces, page-locked buffers) persists
     between the repeats: the first one is the cold crawl ("cold_seconds"), the best one the warm rate."""
@@ -354,13 +354,15 @@ def main():
     e2e = None
     if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
         try:
-            st = end_to_end("c4", 12500, device, 3, 99, repeats=3, files_per_batch=256)
+            st = end_to_end("c4", 12500, device, 8, 99, repeats=3, files_per_batch=512)
             e2e = {"workload": "C4 share: 12 500 stereo 1.0 s 16-bit WAV images in host memory -> RIFF parse -> page-locked staging -> "
                                "upload -> LoadSample + every low-level descriptor (per-frame set and rhythm tracker) + statistics -> records back in host memory",
                    "files_per_s": st["files"] / st["seconds"], "frames_per_s": st["frames"] / st["seconds"],
                    "cold_files_per_s": st["files"] / st["cold_seconds"],   # first crawl of the process: page-locked and device pools empty
                    "upload_GB_per_s": st["pcm_bytes"] / st["seconds"] / 1e9, "download_GB_per_s": st["result_bytes"] / st["seconds"] / 1e9,
-                   "workers": 3, "files_per_batch": 256}
+                   # 55 GB/s: one page-locked upload stream on this host link (tools/link_rate.py, profiles/r02/README.md)
+                   "upload_frac_of_host_link": st["pcm_bytes"] / st["seconds"] / 55e9,
+                   "workers": 8, "files_per_batch": 512}
         except Exception as e:  # noqa: BLE001  (the headline must not depend on the host library)
             e2e = {"error": str(e)}
 

@@ -121,7 +121,11 @@ typedef struct {
  * AFX_SIDE_STREAM = 0: the rhythm tracker's kernels run on the batch's own stream instead of beside the per-frame kernels
  * (for profiles: per-kernel durations are then not inflated by overlap; results are identical).
  * AFX_TIMING (any value, read when the library is loaded): wall time of the phases of afx_batch_create_from_raw, summed
- * over calls, printed to stderr when the process ends -- a diagnostic for pipelines, no effect on results. */
+ * over calls, printed to stderr when the process ends -- a diagnostic for pipelines, no effect on results.
+ * GPU_MAX_HW_QUEUES (the HIP runtime's own variable: hardware queues its streams are multiplexed onto, 4 by default):
+ * when it is unset the library sets it to 16 as it is loaded, so that the streams of six to eight batches in flight do
+ * not serialise on shared queues (more than the device's hardware queue slots, about 20, would be time-sliced); this
+ * takes effect when the library is loaded before the process' first HIP call. */
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan);
 void afx_plan_destroy(afx_plan* plan);
 

@@ -2,7 +2,7 @@
 # GPU timeline of the streaming host driver: union of kernel intervals and of copy intervals vs the wall time of the crawl
 set -u
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/ctl
-AFEC_CRAWL_TIMING=1 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/ctl -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload c4 --end-to-end --files ${1:-50000} --workers ${2:-3} 2>&1 | grep "afec crawl" | tail -2
+AFEC_CRAWL_TIMING=1 rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d /tmp/ctl -o p -- python3 $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --workload c4 --end-to-end --files ${1:-50000} --workers ${2:-3} --files-per-batch ${3:-256} 2>&1 | grep "afec crawl" | tail -2
 python3 - <<'PY'
 import csv, glob
 def union(iv):
@@ -26,7 +26,18 @@ print(f"window {span / 1e6:.1f} ms: kernels busy (union) {union(kk) / 1e6:.1f} m
       f"copies busy (union) {union(cc) / 1e6:.1f} ms, {len(kk)} kernels, {len(cc)} copies")
 import collections
 d = collections.Counter(); n = collections.Counter()
+import re
+def short(name):
+    while True:
+        t = re.sub(r"<[^<>]*>", "", name)
+        if t == name: break
+        name = t
+    return name.replace("(anonymous namespace)::", "").split("(")[0].split("::")[-1].split(" ")[-1]
 for a, b, name in k:
-    if a >= lo: d[name.split("(")[0][-40:]] += b - a; n[name.split("(")[0][-40:]] += 1
-for name, t in d.most_common(8): print(f"   {name:42s} {t / 1e6:8.1f} ms in {n[name]} launches")
+    if a >= lo: d[short(name)] += b - a; n[short(name)] += 1
+for name, t in d.most_common(40): print(f"   {name:42s} {t / 1e6:8.2f} ms in {n[name]} launches, {t / n[name] / 1e3:7.1f} us each")
+both = kk + cc
+print(f"kernels or copies busy (union) {union(both) / 1e6:.1f} ms")
 PY
+
+if [ -n "${KEEP_TRACE:-}" ]; then mkdir -p $GRAFT_REPO_ROOT/gpurun_out/ctl; cp $(find /tmp/ctl -name "*kernel_trace.csv") $GRAFT_REPO_ROOT/gpurun_out/ctl/kernel_trace.csv; cp $(find /tmp/ctl -name "*memory_copy_trace.csv") $GRAFT_REPO_ROOT/gpurun_out/ctl/memory_copy_trace.csv; fi

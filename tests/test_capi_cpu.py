@@ -82,3 +82,17 @@ def test_unsupported_geometry_is_rejected_before_touching_the_device(lib):
     with pytest.raises(afec_amd.AfxError) as ei:
         afec_amd.Plan(fft_size=1000)
     assert ei.value.status == -1
+
+
+def test_library_raises_the_hardware_queue_limit_only_when_the_process_has_not_chosen():
+    """libafx_hip.so sets GPU_MAX_HW_QUEUES=16 as it is loaded (include/afx.h, environment notes) unless the variable is
+    already set -- checked in fresh processes through libc's getenv (os.environ does not see setenv from C)."""
+    import subprocess
+    import sys
+    so = os.path.join(os.path.dirname(afec_amd.__file__), "lib", "libafx_hip.so")
+    code = ("import ctypes, sys; ctypes.CDLL(sys.argv[1]); c = ctypes.CDLL(None); c.getenv.restype = ctypes.c_char_p; "
+            "print(c.getenv(b'GPU_MAX_HW_QUEUES').decode())")
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.check_output([sys.executable, "-c", code, so], env=env).decode().strip() == "16"
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    assert subprocess.check_output([sys.executable, "-c", code, so], env=env).decode().strip() == "4"

@@ -12,6 +12,8 @@
 #include <mutex>
 #include <thread>
 
+#include <sys/stat.h>
+
 #include "../../include/afx.h"
 #include "SqlitePool.h"
 #include "WaveFile.h"
@@ -169,8 +171,14 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   // shards: file i -> device i mod G, in crawl order
   std::vector<std::vector<const TCrawlFile*>> Shard((size_t)G);
   for (size_t i = 0; i < Files.size(); ++i) Shard[(size_t)ShardOfFile((int64_t)i, G)].push_back(&Files[i]);
-  std::vector<std::atomic<size_t>> Cursor((size_t)G);
-  for (auto& c : Cursor) c = 0;
+  std::vector<size_t> Cursor((size_t)G, 0);
+  std::vector<std::mutex> CursorMutex((size_t)G);
+  const int64_t BytesPerBatch = Options.mBytesPerBatch < 1 ? 1 : Options.mBytesPerBatch;
+  auto FileBytes = [](const TCrawlFile& f) -> int64_t {
+    if (f.mpImage) return (int64_t)f.mImageSize;
+    struct stat St;
+    return ::stat(f.mFileName.c_str(), &St) == 0 ? (int64_t)St.st_size : 0;   // a file that is not there fails when it is opened
+  };
 
   TCrawlStatistics Total;
   Total.mFilesPerDevice.assign((size_t)G, 0);
@@ -194,9 +202,23 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
       std::vector<std::vector<unsigned char>> Widened;
       for (;;) {
         if (Abort) return;
-        const size_t Begin = Cursor[(size_t)d].fetch_add((size_t)FilesPerBatch);
-        if (Begin >= Shard[(size_t)d].size()) return;
-        const size_t End = std::min(Begin + (size_t)FilesPerBatch, Shard[(size_t)d].size());
+        // the next FilesPerBatch files of the shard, or fewer when their bytes reach the batch's budget (long files:
+        // the staging buffer, the device workspace and the result buffers all scale with the PCM of a batch)
+        size_t Begin, End;
+        {
+          std::lock_guard<std::mutex> Lock(CursorMutex[(size_t)d]);
+          const std::vector<const TCrawlFile*>& Mine = Shard[(size_t)d];
+          Begin = End = Cursor[(size_t)d];
+          if (Begin >= Mine.size()) return;
+          int64_t BatchBytes = 0;
+          while (End < Mine.size() && End - Begin < (size_t)FilesPerBatch) {
+            const int64_t Size = FileBytes(*Mine[End]);
+            if (End > Begin && BatchBytes + Size > BytesPerBatch) break;
+            BatchBytes += Size;
+            ++End;
+          }
+          Cursor[(size_t)d] = End;
+        }
         std::unique_ptr<TFinishedBatch> pDone(new TFinishedBatch);
         TFinishedBatch& Done = *pDone;
         const size_t n = End - Begin;
@@ -280,6 +302,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
           PhaseSeconds[1] += tGpu1 - tGpu0;
           for (int k = 0; k < 3; ++k) GpuSeconds[k] += Done.mResults.mSeconds[k];
           Total.mFiles += (int64_t)n;
+          Total.mBatches += 1;
           Total.mFrames += Frames;
           Total.mPcmBytes += PcmBytes;
           Total.mResultBytes += ResultBytes;
@@ -347,6 +370,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
 
 namespace {
 std::mutex gCrawlerMutex, gCrawlMutex;
+std::atomic<int64_t> gBytesPerBatch(0);   // afec_crawl_set_bytes_per_batch: 0 = TCrawlOptions' default
 std::vector<std::pair<std::string, afec::TCrawler*>> gCrawlers;   // never destroyed at exit: the HIP runtime may be gone by then
 }  // namespace
 
@@ -356,6 +380,8 @@ extern "C" void afec_crawl_release(void) {
   for (auto& Entry : gCrawlers) delete Entry.second;
   gCrawlers.clear();
 }
+
+extern "C" void afec_crawl_set_bytes_per_batch(int64_t bytes) { gBytesPerBatch = bytes; }
 
 extern "C" int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
                                       const int32_t* devices, int32_t n_devices, int32_t workers_per_device,
@@ -374,6 +400,7 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     if (workers_per_device > 0) Options.mWorkersPerDevice = workers_per_device;
     if (files_per_batch > 0) Options.mFilesPerBatch = files_per_batch;
     if (database_path) Options.mDatabasePath = database_path;
+    if (gBytesPerBatch > 0) Options.mBytesPerBatch = gBytesPerBatch;
     // one crawler per (devices, geometry), kept between calls
     afec::TCrawler* pCrawler = nullptr;
     {
@@ -395,7 +422,8 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     if (stats) {
       stats[0] = (double)s.mFiles; stats[1] = (double)s.mFailedFiles; stats[2] = (double)s.mFrames; stats[3] = (double)s.mPcmBytes;
       stats[4] = (double)s.mResultBytes; stats[5] = s.mSeconds; stats[6] = s.mWriterSeconds;
-      for (int32_t d = 0; d < n_devices; ++d) stats[7 + d] = (double)s.mFilesPerDevice[(size_t)d];
+      stats[7] = (double)s.mBatches;
+      for (int32_t d = 0; d < n_devices; ++d) stats[8 + d] = (double)s.mFilesPerDevice[(size_t)d];
     }
     return 0;
   } catch (const std::exception& e) {

@@ -32,12 +32,14 @@ struct TCrawlOptions {
   std::vector<int> mDevices = {0};  // HIP device ordinals
   int mWorkersPerDevice = 8;        // host threads (= batches in flight) per device
   int mFilesPerBatch = 512;         // measured best on one MI355X for 1 s stereo files (profiles/r02/README.md)
+  int64_t mBytesPerBatch = 128 << 20;  // a batch also ends before the file that takes it over this many file bytes (a
+                                    // 16-bit mono file needs ~10 x its size in device memory: PCM as doubles, spectra)
   std::string mDatabasePath;        // empty: results are counted, not stored
   int mSampleRate = 44100, mFftFrameSize = 2048, mHopFrameSize = 1024;
 };
 
 struct TCrawlStatistics {
-  int64_t mFiles = 0, mFailedFiles = 0, mFrames = 0;
+  int64_t mFiles = 0, mFailedFiles = 0, mFrames = 0, mBatches = 0;
   int64_t mPcmBytes = 0;            // bytes of PCM uploaded
   int64_t mResultBytes = 0;         // bytes of records + statistics downloaded
   double mSeconds = 0;              // first file read .. last result delivered to the writer
@@ -73,7 +75,7 @@ private:
 extern "C" {
 // C entry point of CrawlWaveFiles for callers without C++ (bench.py, tests): file images in memory.  The process keeps
 // one TCrawler per (devices, geometry) between calls (afec_crawl_release drops them), so a second crawl starts warm.
-// stats: [files, failed, frames, pcm_bytes, result_bytes, seconds, writer_seconds, files on device 0, 1, ...];
+// stats: [files, failed, frames, pcm_bytes, result_bytes, seconds, writer_seconds, batches, files on device 0, 1, ...];
 // returns 0, or -1 with the message in error.
 int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
                            const int32_t* devices, int32_t n_devices, int32_t workers_per_device, int32_t files_per_batch,
@@ -85,4 +87,6 @@ int afec_wave_probe(const void* image, int64_t size, int64_t* props /* [7] */, v
                     char* error, int32_t error_size);
 int afec_shard_of_file(int64_t file_index, int32_t n_devices);
 void afec_crawl_release(void);
+// TCrawlOptions::mBytesPerBatch of the crawls that follow (0: the default)
+void afec_crawl_set_bytes_per_batch(int64_t bytes);
 }

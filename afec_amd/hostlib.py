@@ -52,15 +52,15 @@ def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, data
     c_images = (ctypes.c_void_p * n)(*[k.ctypes.data for k in keep])
     c_sizes = (ctypes.c_int64 * n)(*[len(b) for b in images])
     c_dev = (ctypes.c_int32 * len(devices))(*devices)
-    stats = (ctypes.c_double * (7 + len(devices)))()
+    stats = (ctypes.c_double * (8 + len(devices)))()
     err = ctypes.create_string_buffer(512)
     rc = L.afec_crawl_wave_images(c_names, c_images, c_sizes, n, c_dev, len(devices), workers, files_per_batch,
                                   database.encode() if database else None, stats, err, 512)
     if rc != 0:
         raise RuntimeError(err.value.decode())
-    keys = ["files", "failed", "frames", "pcm_bytes", "result_bytes", "seconds", "writer_seconds"]
-    out = dict(zip(keys, list(stats)[:7]))
-    out["files_per_device"] = [int(v) for v in list(stats)[7:]]
+    keys = ["files", "failed", "frames", "pcm_bytes", "result_bytes", "seconds", "writer_seconds", "batches"]
+    out = dict(zip(keys, list(stats)[:8]))
+    out["files_per_device"] = [int(v) for v in list(stats)[8:]]
     return out
 
 
@@ -69,3 +69,11 @@ def release():
     L = lib()
     L.afec_crawl_release.restype = None
     L.afec_crawl_release()
+
+
+def set_bytes_per_batch(n_bytes):
+    """TCrawlOptions::mBytesPerBatch of the crawls that follow (0: the default, 128 MiB of file bytes)."""
+    L = lib()
+    L.afec_crawl_set_bytes_per_batch.restype = None
+    L.afec_crawl_set_bytes_per_batch.argtypes = [ctypes.c_int64]
+    L.afec_crawl_set_bytes_per_batch(int(n_bytes))

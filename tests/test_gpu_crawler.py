@@ -131,6 +131,26 @@ def test_crawl_without_a_database_and_small_batches():
     assert a["failed"] == 2 and a["frames"] > 0 and a["writer_seconds"] == 0.0
 
 
+def test_batches_end_at_the_byte_budget():
+    """TCrawlOptions::mBytesPerBatch: a batch ends before the file that would take it over the budget (long files must not
+    grow the staging buffer and the device workspace without bound); the results do not depend on it."""
+    from afec_amd import hostlib
+    images, names, _ = make_crawl(40)
+    whole = _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=1000)
+    assert whole["batches"] == 1
+    largest = max(len(b) for b in images)
+    try:
+        hostlib.set_bytes_per_batch(2 * largest)
+        cut = _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=1000)
+        hostlib.set_bytes_per_batch(1)                 # one file per batch: a batch always takes at least one
+        single = _host.crawl(images, names, devices=(0,), workers=3, files_per_batch=1000)
+    finally:
+        hostlib.set_bytes_per_batch(0)
+    assert 5 < cut["batches"] < len(images) and single["batches"] == len(images)
+    for k in ("files", "failed", "frames", "pcm_bytes", "result_bytes"):
+        assert whole[k] == cut[k] == single[k], k
+
+
 def test_crawler_persists_between_crawls_and_can_be_released(tmp_path):
     """The process keeps its crawler (plans, device workspaces, page-locked buffers) between crawls: a second crawl and
     a crawl after afec_crawl_release write the same database rows as the first."""

@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -159,7 +160,8 @@ struct Workspace {
   // leave most of the chip idle during any one kernel, so the two kernel chains run side by side
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  hipEvent_t ev_copy = nullptr;   // orders this batch's stream with the plan's upload / download streams
+  hipEvent_t ev_copy = nullptr;   // the host's waits for the plan's upload / download streams (and, when blocking, for this batch's stream)
+  bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_set_blocking_wait)
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
   Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff;   // rhythm tracker
@@ -405,6 +407,8 @@ void ws_free(Workspace* w) {
   delete w;
 }
 
+std::atomic<bool> g_blocking_wait(false);   // afx_set_blocking_wait: copy events of workspaces created from now on block too
+
 // pooled workspaces: at most 16 idle ones per plan, none larger than 4 GiB (a 1024-file batch of one-second files with
 // every descriptor needs ~1 GiB: magnitudes 8 KiB and PCM 8 KiB per frame)
 constexpr size_t kPoolMaxIdle = 16;
@@ -427,6 +431,7 @@ Workspace* ws_acquire(afx_plan* plan, hipError_t* err) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->side_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming);
+  w->blocking = g_blocking_wait.load();
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_copy, hipEventDisableTiming);
   if (e != hipSuccess) { *err = e; ws_free(w); return nullptr; }
   return w;
@@ -971,6 +976,25 @@ inline long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
+// The host's waits.  hipStreamSynchronize / hipEventSynchronize spin (one busy CPU per waiting thread); with
+// afx_set_blocking_wait the thread polls the workspace's copy event and sleeps in between.  The runtime's own
+// alternatives did not serve: hipEventBlockingSync alone changes nothing here (the eight workers of a crawl still keep
+// 6.6 CPUs busy), and hipDeviceScheduleBlockingSync, set on a device that is already active, left a later
+// hipStreamSynchronize hanging.
+hipError_t wait_for_event(Workspace* ws, hipEvent_t ev) {
+  if (!ws->blocking) return hipEventSynchronize(ev);
+  for (;;) {
+    const hipError_t e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+    std::this_thread::sleep_for(std::chrono::microseconds(20));
+  }
+}
+hipError_t wait_for_stream(Workspace* ws, hipStream_t stream) {
+  if (!ws || !ws->blocking) return hipStreamSynchronize(stream);
+  hipError_t e = hipEventRecord(ws->ev_copy, stream);
+  return e == hipSuccess ? wait_for_event(ws, ws->ev_copy) : e;
+}
+
 // One large host-to-device transfer through the plan's upload stream; returns when it has landed.  The wait is the
 // host's, not a hipStreamWaitEvent of the batch's stream: HIP multiplexes its streams onto a few hardware queues
 // (GPU_MAX_HW_QUEUES, 4 by default), and a barrier packet that waits for a 1.6 ms upload stalls every other stream
@@ -983,7 +1007,7 @@ hipError_t upload_through_plan(afx_plan* plan, Workspace* ws, void* dst, const v
     if (e == hipSuccess) e = hipEventRecord(ws->ev_copy, plan->up_stream);
     if (e != hipSuccess) return e;
   }
-  return hipEventSynchronize(ws->ev_copy);
+  return wait_for_event(ws, ws->ev_copy);
 }
 // Device-to-host transfers of a batch's results through the plan's download stream, behind everything enqueued on the
 // batch's stream so far (waited for on the host, for the same reason as above); returns when they have landed.
@@ -991,7 +1015,7 @@ struct Download { void* dst; const void* src; size_t bytes; };
 hipError_t download_through_plan(afx_batch* b, const Download* items, int n) {
   afx_plan* plan = b->plan;
   Workspace* ws = b->ws;
-  hipError_t e = hipStreamSynchronize(b->stream);
+  hipError_t e = wait_for_stream(ws, b->stream);
   if (e != hipSuccess) return e;
   {
     std::lock_guard<std::mutex> lock(plan->down_mutex);
@@ -1000,7 +1024,7 @@ hipError_t download_through_plan(afx_batch* b, const Download* items, int n) {
     if (e == hipSuccess) e = hipEventRecord(ws->ev_copy, plan->down_stream);
     if (e != hipSuccess) return e;
   }
-  return hipEventSynchronize(ws->ev_copy);
+  return wait_for_event(ws, ws->ev_copy);
 }
 
 // bytes per sample of the decoded PCM formats (0: unknown format)
@@ -1204,7 +1228,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     const double silence_floor = 32768.0 * std::exp(-48.0 * (std::log(10.0) / 20.0));
     if ((e = afx::launch_load_scan(d_raw, d_files, n_bufs, silence_floor, ws->partial.p, d_scan, s)) != hipSuccess) return bail(hip_fail(e, "load_scan"));
     if ((e = hipMemcpyAsync(scan.data(), d_scan, scan.size() * sizeof(afx::LoadScan), hipMemcpyDeviceToHost, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(scan)"));
-    if ((e = hipStreamSynchronize(s)) != hipSuccess) return bail(hip_fail(e, "hipStreamSynchronize"));
+    if ((e = wait_for_stream(ws, s)) != hipSuccess) return bail(hip_fail(e, "hipStreamSynchronize"));
   }
   const long long t_scanned = now_ns();
   // padding rules of SampleAnalyser.cpp:681-701
@@ -1601,6 +1625,8 @@ void afx_batch_destroy(afx_batch* b) {
   ws_release(b->plan, b->ws);
   delete b;
 }
+
+void afx_set_blocking_wait(int32_t blocking) { g_blocking_wait = blocking != 0; }
 
 void* afx_host_alloc(int64_t bytes) {
   void* p = nullptr;

@@ -137,7 +137,10 @@ TCrawler::TCrawler(const TCrawlOptions& Options) : mpImpl(new TImpl) {
   mpImpl->mSampleRate = Options.mSampleRate; mpImpl->mFftFrameSize = Options.mFftFrameSize; mpImpl->mHopFrameSize = Options.mHopFrameSize;
   if (Options.mDevices.empty()) { delete mpImpl; throw TReadableException("CrawlWaveFiles: no device given"); }
   try {
-    // one analyser (plan) per device, shared by that device's workers like the reference's const analyser
+    // one analyser (plan) per device, shared by that device's workers like the reference's const analyser; the
+    // workers' waits for the device sleep instead of spinning (eight spinning threads per GPU would need eight CPUs
+    // per GPU for the same throughput)
+    afx_set_blocking_wait(1);
     for (int Device : Options.mDevices)
       mpImpl->mAnalysers.emplace_back(new TSampleAnalyser(Options.mSampleRate, Options.mFftFrameSize, Options.mHopFrameSize, Device));
   } catch (...) {

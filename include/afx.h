@@ -345,6 +345,13 @@ int afx_batch_fetch_onset_functions(afx_batch* batch, float* odf);
 void* afx_host_alloc(int64_t bytes);
 void afx_host_free(void* p);
 
+/* How host threads wait for the device in afx_batch_create_from_raw, afx_batch_fetch_records and afx_batch_fetch_rhythm:
+ * spinning (the HIP runtime's default: lowest latency, one busy CPU per waiting thread) or, with blocking != 0, sleeping
+ * between polls of an event (20 us naps).  A pipeline with several batches in flight per device wants the latter:
+ * the streaming driver of afec_amd/host keeps eight worker threads per GPU and reaches the same 270 k files/s with about
+ * 3 instead of 7 busy CPUs.  Process-wide; applies to the batch workspaces created after the call. */
+void afx_set_blocking_wait(int32_t blocking);
+
 /* static facts for roofline accounting (bytes the algorithm must move per frame for `mask`) */
 int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int32_t pcm_dtype);
 

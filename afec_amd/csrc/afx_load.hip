@@ -5,8 +5,8 @@
 // and zero padding.  Byte / integer work and two reductions per file: HBM-bound by construction
 // (2..4 bytes in, 8 bytes out per sample).
 //
-//   load_scan   max |x| and sum (x/32768)^2 of the mono mix, then first and last sample whose normalised
-//               magnitude exceeds the silence floor (three small kernels, several workgroups per file)
+//   load_scan   max |x| and sum (x/32768)^2 of the mono mix (several workgroups per file), then first and last sample
+//               whose normalised magnitude exceeds the silence floor (one workgroup per file, from both ends)
 //   load_write  writes scaling * x[lead + n] as doubles behind start_pad zeros (the arena is pre-zeroed)
 
 #include <hip/hip_runtime.h>
@@ -43,6 +43,28 @@ __device__ __forceinline__ float mono_sample(const unsigned char* raw, int forma
   return d;
 }
 
+// the mono mix of frames n4 .. n4 + 3 (n4 a multiple of 4; frames at or behind n_frames come back as 0).  16-bit files
+// -- the common case -- take one 8- or 16-byte load (a file's payload starts on a 16-byte boundary of the staging
+// arena, afx_capi.cpp); every other format and channel count goes sample by sample.  The arithmetic is mono_sample's.
+__device__ __forceinline__ void mono4(const unsigned char* raw, int format, int channels, int64_t n4, int64_t n_frames, float (&out)[4]) {
+  if (format == 0 && channels <= 2 && n4 + 4 <= n_frames) {
+    if (channels == 1) {
+      const uint2 w = *reinterpret_cast<const uint2*>(raw + 2 * n4);
+      out[0] = (float)(short)(w.x & 0xFFFFu); out[1] = (float)(short)(w.x >> 16);
+      out[2] = (float)(short)(w.y & 0xFFFFu); out[3] = (float)(short)(w.y >> 16);
+    } else {
+      const uint4 w = *reinterpret_cast<const uint4*>(raw + 4 * n4);
+      const unsigned v[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        out[k] = __fmul_rn(__fadd_rn((float)(short)(v[k] & 0xFFFFu), (float)(short)(v[k] >> 16)), 1.0f / 2.0f);
+    }
+    return;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) out[k] = (n4 + k < n_frames) ? mono_sample(raw, format, channels, n4 + k) : 0.0f;
+}
+
 constexpr int kLoadThreads = 256;
 
 template <typename T, typename Op>
@@ -60,7 +82,7 @@ __device__ __forceinline__ T block_reduce(T v, T* scratch, Op op) {
 // A file is scanned by gridDim.y workgroups (many when the batch has few files, one when it has thousands).
 // Stage 1: per-workgroup partial sum of squares and maximum; stage 2 (one workgroup per file) adds the
 // partials in index order -- the result does not depend on timing -- and derives the amplification;
-// stage 3: first / last sample above the silence floor, merged with atomicMin / atomicMax.
+// stage 3: first / last sample above the silence floor (load_scan3_kernel).
 struct LoadPartial {
   double sum_sq;
   float max_amp;
@@ -76,11 +98,15 @@ __global__ __launch_bounds__(kLoadThreads) void load_scan1_kernel(const unsigned
   // rms and peak (SampleAnalyser.cpp:612-637)
   double sum_sq = 0.0;
   float mx = 0.0f;
-  for (int64_t n = (int64_t)blockIdx.y * kLoadThreads + threadIdx.x; n < f.n_frames; n += (int64_t)gridDim.y * kLoadThreads) {
-    const float x = mono_sample(src, f.format, f.channels, n);
-    const double t = (double)(x / 32768.0f);
-    sum_sq += t * t;
-    mx = fmaxf(mx, fabsf(x));
+  for (int64_t n = 4 * ((int64_t)blockIdx.y * kLoadThreads + threadIdx.x); n < f.n_frames; n += 4 * (int64_t)gridDim.y * kLoadThreads) {
+    float x[4];
+    mono4(src, f.format, f.channels, n, f.n_frames, x);   // frames behind the end are 0: they change neither result
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const double t = (double)(x[k] / 32768.0f);
+      sum_sq += t * t;
+      mx = fmaxf(mx, fabsf(x[k]));
+    }
   }
   sum_sq = block_reduce(sum_sq, sd, [](double a, double b) { return a + b; });
   mx = block_reduce(mx, sf, [](float a, float b) { return fmaxf(a, b); });
@@ -109,24 +135,47 @@ __global__ void load_scan2_kernel(const LoadFile* files, const LoadPartial* part
 
 __global__ __launch_bounds__(kLoadThreads) void load_scan3_kernel(const unsigned char* raw, const LoadFile* files,
                                                                   double silence_floor, LoadScan* scan) {
+  // silent leading / trailing samples (SampleAnalyser.cpp:651-669): one workgroup per file walks blocks of 1024 frames
+  // from the front until one holds a sample above the floor, then from the back -- like the reference's two loops it
+  // reads the silence and little else (a file without silence: 8 KiB of it)
   __shared__ long long sl[kLoadThreads / 64];
   const LoadFile f = files[blockIdx.x];
+  if (f.n_frames <= 0) return;
   const unsigned char* src = raw + f.raw_off;
   const double amplification = scan[blockIdx.x].amplification;
-  // silent leading / trailing samples (SampleAnalyser.cpp:651-669)
-  long long first = 0x7FFFFFFF, last = -1;
-  for (int64_t n = (int64_t)blockIdx.y * kLoadThreads + threadIdx.x; n < f.n_frames; n += (int64_t)gridDim.y * kLoadThreads) {
-    const float x = mono_sample(src, f.format, f.channels, n);
-    if (fabs(amplification * (double)x) > silence_floor) {
-      first = n < first ? n : first;
-      last = n > last ? n : last;
+  constexpr int64_t kBlock = 4 * kLoadThreads;
+  const int64_t n_blocks = (f.n_frames + kBlock - 1) / kBlock;
+  auto block_hits = [&](int64_t b, long long& first, long long& last) {
+    float x[4];
+    const int64_t n4 = b * kBlock + 4 * (int64_t)threadIdx.x;
+    first = 0x7FFFFFFF; last = -1;
+    if (n4 < f.n_frames) {
+      mono4(src, f.format, f.channels, n4, f.n_frames, x);
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (n4 + k < f.n_frames && fabs(amplification * (double)x[k]) > silence_floor) {
+          first = first < n4 + k ? first : n4 + k;
+          last = n4 + k;
+        }
     }
-  }
-  first = block_reduce(first, sl, [](long long a, long long b) { return a < b ? a : b; });
-  last = block_reduce(last, sl, [](long long a, long long b) { return a > b ? a : b; });
-  if (threadIdx.x == 0 && last >= 0) {
-    atomicMin(&scan[blockIdx.x].lead, (int32_t)first);
-    atomicMax(&scan[blockIdx.x].trail, (int32_t)last);
+    return __syncthreads_or(last >= 0) != 0;
+  };
+  long long first = 0x7FFFFFFF, last = -1, lo, hi;
+  int64_t b = 0;
+  for (; b < n_blocks; ++b)
+    if (block_hits(b, lo, hi)) {
+      first = block_reduce(lo, sl, [](long long p, long long q) { return p < q ? p : q; });
+      break;
+    }
+  if (b == n_blocks) return;                 // nothing above the floor: lead / trail keep their initial values
+  for (int64_t e = n_blocks - 1; e >= b; --e)
+    if (block_hits(e, lo, hi)) {
+      last = block_reduce(hi, sl, [](long long p, long long q) { return p > q ? p : q; });
+      break;
+    }
+  if (threadIdx.x == 0) {
+    scan[blockIdx.x].lead = (int32_t)first;
+    scan[blockIdx.x].trail = (int32_t)last;
   }
 }
 
@@ -139,8 +188,17 @@ __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned
   double* dst = arena + p.out_off;
   // only the analysed prefix is kept; zeros of the start / end pads are already there
   const int64_t n_copy = (p.audible < p.out_n - p.start_pad) ? p.audible : (p.out_n - p.start_pad);
-  for (int64_t n = (int64_t)blockIdx.y * kLoadThreads + threadIdx.x; n < n_copy; n += (int64_t)gridDim.y * kLoadThreads)
-    dst[p.start_pad + n] = (double)mono_sample(src, f.format, f.channels, p.lead + n) * p.scaling;  // SA:712-718
+  // groups of four source frames on the source's alignment (vector loads); frames before `lead` and behind the copied
+  // range are skipped
+  const int64_t s_end = p.lead + n_copy;
+  for (int64_t s4 = (p.lead & ~(int64_t)3) + 4 * ((int64_t)blockIdx.y * kLoadThreads + threadIdx.x); s4 < s_end;
+       s4 += 4 * (int64_t)gridDim.y * kLoadThreads) {
+    float x[4];
+    mono4(src, f.format, f.channels, s4, f.n_frames, x);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (s4 + k >= p.lead && s4 + k < s_end) dst[p.start_pad + (s4 + k - p.lead)] = (double)x[k] * p.scaling;  // SA:712-718
+  }
 }
 
 // CalcEffectiveLength (SampleAnalyser.cpp:1715-1755) on the normalised buffer: for each of three floors the
@@ -179,14 +237,82 @@ __global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TI
   }
 }
 
+// The same for batches of many buffers: one workgroup per buffer walks blocks of 1024 samples from the front until
+// the highest floor has been crossed, then from the back -- typical audio is read only at its ends.
+template <typename TIn>
+__global__ __launch_bounds__(kLoadThreads) void effective_length_ends_kernel(const TIn* pcm, const BufSpan* spans, double f0,
+                                                                             double f1, double f2, int32_t* out) {
+  __shared__ long long sl[kLoadThreads / 64];
+  const BufSpan sp = spans[blockIdx.x];
+  const TIn* const x = pcm + sp.off;
+  const double floors[3] = {f0, f1, f2};   // ascending (-48, -24, -12 dB)
+  constexpr int64_t kBlock = 4 * kLoadThreads;
+  const int64_t n_blocks = (sp.n + kBlock - 1) / kBlock;
+  long long first[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, last[3] = {-1, -1, -1};
+  // forward: a block's hits per floor; stop behind the block in which the highest floor was crossed
+  for (int64_t b = 0; b < n_blocks; ++b) {
+    long long lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int64_t n = b * kBlock + (int64_t)k * kLoadThreads + threadIdx.x;
+      const double v = n < sp.n ? fabs((double)x[n]) : 0.0;
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        if (v > floors[j] && n < lo[j]) lo[j] = n;
+    }
+    if (!__syncthreads_or(lo[0] != 0x7FFFFFFF)) continue;   // nothing above the lowest floor in this block
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const long long a = block_reduce(lo[j], sl, [](long long p, long long q) { return p < q ? p : q; });
+      if (first[j] == 0x7FFFFFFF) first[j] = a;
+    }
+    if (first[2] != 0x7FFFFFFF) break;
+  }
+  if (first[0] != 0x7FFFFFFF)
+    for (int64_t b = n_blocks - 1; b >= 0; --b) {
+      long long hi[3] = {-1, -1, -1};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int64_t n = b * kBlock + (int64_t)k * kLoadThreads + threadIdx.x;
+        const double v = n < sp.n ? fabs((double)x[n]) : 0.0;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+          if (v > floors[j] && n > hi[j]) hi[j] = n;
+      }
+      if (!__syncthreads_or(hi[0] >= 0)) continue;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const long long a = block_reduce(hi[j], sl, [](long long p, long long q) { return p > q ? p : q; });
+        if (last[j] < 0) last[j] = a;
+      }
+      // a floor that was never crossed from the front is not crossed from the back either
+      if ((last[2] >= 0 || first[2] == 0x7FFFFFFF) && (last[1] >= 0 || first[1] == 0x7FFFFFFF)) break;
+    }
+  if (threadIdx.x == 0)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      out[6 * blockIdx.x + 2 * j] = (int32_t)first[j];
+      out[6 * blockIdx.x + 2 * j + 1] = (int32_t)last[j];
+    }
+}
+
 }  // namespace
 
 hipError_t launch_effective_length(const void* pcm, int pcm_dtype, const BufSpan* spans, int n_bufs, double floor48,
                                    double floor24, double floor12, int32_t* out, hipStream_t stream) {
   if (n_bufs <= 0) return hipSuccess;
+  if (n_bufs >= 64) {   // many buffers: one workgroup each, from both ends (writes every output itself)
+    if (pcm_dtype == 0)
+      hipLaunchKernelGGL(effective_length_ends_kernel<float>, dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+                         reinterpret_cast<const float*>(pcm), spans, floor48, floor24, floor12, out);
+    else
+      hipLaunchKernelGGL(effective_length_ends_kernel<double>, dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+                         reinterpret_cast<const double*>(pcm), spans, floor48, floor24, floor12, out);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL(effective_length_init_kernel, dim3((6 * n_bufs + 255) / 256), dim3(256), 0, stream, out, 6 * n_bufs);
   // few buffers: many workgroups per buffer; many buffers: one each
-  const int per_buffer = n_bufs >= 1024 ? 1 : (n_bufs >= 64 ? 8 : 128);
+  const int per_buffer = 128;
   if (pcm_dtype == 0)
     hipLaunchKernelGGL(effective_length_kernel<float>, dim3(n_bufs, per_buffer), dim3(kLoadThreads), 0, stream,
                        reinterpret_cast<const float*>(pcm), spans, floor48, floor24, floor12, out);
@@ -205,7 +331,7 @@ hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int
   LoadPartial* partial = reinterpret_cast<LoadPartial*>(partial_scratch);
   hipLaunchKernelGGL(load_scan1_kernel, dim3(n_files, per_file), dim3(kLoadThreads), 0, stream, raw, files, partial);
   hipLaunchKernelGGL(load_scan2_kernel, dim3((n_files + 255) / 256), dim3(256), 0, stream, files, partial, per_file, n_files, scan);
-  hipLaunchKernelGGL(load_scan3_kernel, dim3(n_files, per_file), dim3(kLoadThreads), 0, stream, raw, files, silence_floor, scan);
+  hipLaunchKernelGGL(load_scan3_kernel, dim3(n_files), dim3(kLoadThreads), 0, stream, raw, files, silence_floor, scan);
   return hipGetLastError();
 }
 

@@ -264,6 +264,39 @@ def test_effective_length_golden_and_beyond_the_cap(oracle):
     capped.close()
 
 
+def test_effective_length_of_many_buffers(oracle):
+    """batches of 64 and more buffers take the kernel that searches from both ends (afx_load.hip): decays that end above
+    one floor and below the next, floors that are never crossed, silence, one-sample bursts at either end, lengths around
+    the 1024-sample blocks"""
+    rng = np.random.default_rng(57)
+    bufs = []
+    for i in range(90):
+        n = int(rng.choice([1, 5, 1023, 1024, 1025, 4096, 30000, 70001]))
+        kind = i % 6
+        if kind == 0:
+            x = rng.uniform(-1, 1, n) * np.exp(-np.arange(n) / max(1.0, n / rng.uniform(2, 30)))
+        elif kind == 1:
+            x = rng.uniform(-1, 1, n) * rng.choice([0.003, 0.02, 0.1])          # below some or all of the floors
+        elif kind == 2:
+            x = np.zeros(n)
+        elif kind == 3:
+            x = np.zeros(n); x[0] = 0.9; x[-1] = rng.choice([0.9, 0.05, 0.005])
+        elif kind == 4:
+            x = np.zeros(n); x[n // 2] = 0.3                                       # one sample in the middle
+        else:
+            x = np.concatenate([np.zeros(n // 3), rng.uniform(-1, 1, n - n // 3) * np.linspace(0, 1, n - n // 3) ** 4])
+        bufs.append(x)
+    p = afx.Plan(max_analysis_ms=0)
+    for dt in (np.float32, np.float64):
+        typed = [b.astype(dt) for b in bufs]
+        got = p.extract(typed, afx.D_EFFECTIVE_LENGTH)["effective_length"]
+        want = np.stack([oracle.effective_length(b.astype(np.float64)) for b in typed])
+        np.testing.assert_array_equal(got, want)
+        few = p.extract(typed[:40], afx.D_EFFECTIVE_LENGTH)["effective_length"]     # the kernel for few buffers
+        np.testing.assert_array_equal(few, want[:40])
+    p.close()
+
+
 def test_chunking_invariance_bitwise(plan):
     """the same buffer alone (short chunks, one round) and inside a large batch (long chunks): carried state --
     the whitening follower, the pitch kernel's first-half transform -- must not depend on where chunks start"""

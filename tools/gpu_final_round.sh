@@ -3,7 +3,7 @@
 # (tools/profile_config.py: kernel trace + separate PMC passes), rhythm kernel stats / PMC, parity report.
 set -u
 O=gpurun_out/${AFX_ROUND:-r02}; mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+timeout 1200 python -m pytest tests -m gpu -q --timeout 150 --timeout-method thread > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 cp gpurun_out/parity_report.md $O/parity_report.md 2>/dev/null
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo
 python tools/profile_config.py c2_f64

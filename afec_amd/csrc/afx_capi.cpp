@@ -1278,7 +1278,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     }
   const long long t_placed = now_ns();
   // the decoded PCM has arrived (the scan was waited for): nothing of the caller's is read after this point
-  const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/true, fill, out_batch, ws, &file_samples,
+  const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/false, fill, out_batch, ws, &file_samples,
                              &file_offset, /*wait_for_uploads=*/false);
   if (g_create_timing.on) {
     const long long t_end = now_ns();

@@ -7,7 +7,7 @@
 //
 //   load_scan   max |x| and sum (x/32768)^2 of the mono mix (several workgroups per file), then first and last sample
 //               whose normalised magnitude exceeds the silence floor (one workgroup per file, from both ends)
-//   load_write  writes scaling * x[lead + n] as doubles behind start_pad zeros (the arena is pre-zeroed)
+//   load_write  writes scaling * x[lead + n] as doubles behind start_pad zeros, and the zeros of the pads
 
 #include <hip/hip_runtime.h>
 
@@ -186,8 +186,16 @@ __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned
   if (f.n_frames <= 0 || p.out_n <= 0) return;
   const unsigned char* src = raw + f.raw_off;
   double* dst = arena + p.out_off;
-  // only the analysed prefix is kept; zeros of the start / end pads are already there
-  const int64_t n_copy = (p.audible < p.out_n - p.start_pad) ? p.audible : (p.out_n - p.start_pad);
+  // only the analysed prefix is kept
+  int64_t n_copy = (p.audible < p.out_n - p.start_pad) ? p.audible : (p.out_n - p.start_pad);
+  if (n_copy < 0) n_copy = 0;
+  // the start pad, the end pad and the slack up to the buffer's 4-sample slot (afx_capi.cpp, build_batch) are zeros:
+  // written here, by the first workgroup of the file, so that the arena needs no memset (it is written exactly once)
+  if (blockIdx.y == 0) {
+    const int64_t slot = (p.out_n + 3) & ~(int64_t)3, tail = p.start_pad + n_copy;
+    for (int64_t n = threadIdx.x; n < p.start_pad; n += kLoadThreads) dst[n] = 0.0;
+    for (int64_t n = tail + threadIdx.x; n < slot; n += kLoadThreads) dst[n] = 0.0;
+  }
   // groups of four source frames on the source's alignment (vector loads); frames before `lead` and behind the copied
   // range are skipped
   const int64_t s_end = p.lead + n_copy;

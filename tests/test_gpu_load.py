@@ -103,3 +103,46 @@ def test_load_front_end_rejects_bad_files_individually():
     np.testing.assert_array_equal(res["mfcc"][:4], res["mfcc"][4:])
     batch.close()
     plan.close()
+
+
+def test_pads_are_zero_in_a_reused_workspace():
+    """The analysis arena is not cleared between batches (pooled workspaces): load_write_kernel itself writes the zeros of
+    the start pad, the end pad and the slot's slack.  A batch of loud files first fills the arena, then batches of short /
+    silent / heavily trimmed files reuse it: samples (pads included) and descriptors must equal the oracle's."""
+    rng = np.random.default_rng(77)
+    plan = afx.Plan()
+    mask = afx.D_MFCC | afx.D_AMPLITUDE_PEAK | afx.D_AUTO_CORRELATION | afx.D_EFFECTIVE_LENGTH | afx.D_RHYTHM
+    loud = [((rng.uniform(-1, 1, 50000) * 30000).astype(np.int16), 1) for _ in range(12)]
+    ora = Oracle()
+    for round_ in range(3):
+        b0, _ = plan.batch_from_raw(loud, mask)
+        b0.run(); b0.fetch(); b0.close()
+        files = []
+        for k in range(12):
+            n = int(rng.choice([300, 700, 1500, 2047, 2049, 3000, 5000, 9000]))
+            x = np.zeros(n)
+            kind = (k + round_) % 4
+            if kind == 0:
+                x[n // 3:n // 3 + 40] = rng.uniform(-0.8, 0.8, 40)                      # a click in silence: long pads
+            elif kind == 1:
+                x[:] = 0.5 * np.sin(2 * np.pi * 300 * np.arange(n) / 44100)
+            elif kind == 2:
+                x[-5:] = 0.4                                                             # audible only at the very end
+            files.append(((x * 32767).astype(np.int16), 1))                              # kind 3: digital silence
+        batch, infos = plan.batch_from_raw(files, mask)
+        batch.run()
+        res = batch.fetch()
+        row = 0
+        for i, (data, ch) in enumerate(files):
+            want, _ = _oracle.load_sample(data, ch)
+            got = batch.fetch_samples(i, len(want))
+            np.testing.assert_array_equal(got, want[:len(got)], err_msg=f"round {round_} file {i}")
+            nf = plan.num_frames(len(want))
+            ref = ora.run(want, cap=True)
+            a, b = FIELDS["amplitude_peak"]
+            np.testing.assert_array_equal(res["amplitude_peak"][row:row + nf], ref[:, a])
+            a, b = FIELDS["mfcc"]
+            _tol.check("mfcc", res["mfcc"][row:row + nf], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"round {round_} file {i} ")
+            row += nf
+        batch.close()
+    plan.close()

@@ -112,8 +112,9 @@ __device__ const double kLogConst[32] = {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0
                                          (double)(85.0f / 100.0), 43.0, -1.0 / 60.0, (double)1e-12f, 3.0,
                                          1.44269504088896340736, 20.0 / 2.30258509299404568402, 2.2250738585072014e-308, 1.4916681477317095e-154, 0.0, 0.0, 0.0, 0.0};
 // indices into kLogConst of the statistics class' constants
-constexpr int kCEps = 14, kC32 = 15, kCRotRe = 16, kCRotIm = 17, kCInvN = 18, kCRoll = 19, kCBinHz = 20, kCDb60 = 21,
-              kCTiny = 22, kCThree = 23, kCLog2e = 24, kCDbScale = 25, kCMin = 26, kCSqrtMin = 27;
+constexpr int kCEps = 14, kC32 = 15, kCRotRe = 16, kCRotIm = 17, kCRoll = 19, kCSqrtMin = 27;
+// (entries 18, 20..26 -- 1/738, 43, -1/60, 1e-12f, 3, log2 e, 20/ln 10, DBL_MIN -- served the closed forms while they
+// lived in this kernel; they are stats32_finish_kernel's literals now)
 
 // natural log of a positive normal double: frexp + atanh series (|s| <= 0.1716), ~1e-16 absolute on log(m)
 __device__ __forceinline__ double log_lds(double x, const double* c) {

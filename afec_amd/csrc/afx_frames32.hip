@@ -110,9 +110,9 @@ __device__ const double kLogConst[32] = {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0
                                          // constants of the statistics class (kC* below)
                                          1e-20, 32.0, 0.38268343236508984, -0.9238795325112867, 1.0 / 738.0,
                                          (double)(85.0f / 100.0), 43.0, -1.0 / 60.0, (double)1e-12f, 3.0,
-                                         1.44269504088896340736, 20.0 / 2.30258509299404568402, 2.2250738585072014e-308, 1.4916681477317095e-154, 0.0, 0.0, 0.0, 0.0};
+                                         1.44269504088896340736, 20.0 / 2.30258509299404568402, 2.2250738585072014e-308, 1.4916681477317095e-154, 511.0, 0.0, 0.0, 0.0};
 // indices into kLogConst of the statistics class' constants
-constexpr int kCEps = 14, kC32 = 15, kCRotRe = 16, kCRotIm = 17, kCRoll = 19, kCSqrtMin = 27;
+constexpr int kCEps = 14, kC32 = 15, kCRotRe = 16, kCRotIm = 17, kCRoll = 19, kCSqrtMin = 27, kC511 = 28;
 // (entries 18, 20..26 -- 1/738, 43, -1/60, 1e-12f, 3, log2 e, 20/ln 10, DBL_MIN -- served the closed forms while they
 // lived in this kernel; they are stats32_finish_kernel's literals now)
 
@@ -178,11 +178,19 @@ __device__ __forceinline__ void finish_mfcc32(double acc, double*& recp, int& le
 #define AFX_STAMP(i)
 #endif
 
+// Statistics class: untangle the bins in PAIRS.  X[k] and X[1024 - k] come from the same (Z[k], Z[1024 - k]):
+// X[k] = E + w O, |X[1024 - k]| = |E - w O|, so row r (bins 32 r + q) also yields the "mirrored block" M_r = bins
+// 32 (31 - r) + 1 .. 32 (32 - r) -- in reversed lane order (lane q holds bin 1024 - 32 r - q; lane 0 the block's last
+// bin) -- for ten more operations instead of a second fetch + untangle.  Rows 0..15, bin 512 (lane 0 of row 16, its own
+// partner) and M_15..M_8 cover the analysis range 1..738: 16 untangle steps instead of 24.
+
 template <int FEAT>
 __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs a) {
-  // rows of 32 bins whose magnitudes are needed: bins 0..383 for the mel filters, 0..767 for the spectral statistics
-  constexpr int MR = (FEAT == 1) ? 24 : kMel32Rows;
-  using Map = Lds32<kMel32Rows>;   // untangle factors of rows 0..11; rows 12..23 are those times w2048^384
+  constexpr bool PAIRS = (FEAT == 1);
+  // rows of 32 bins that are untangled directly: bins 0..383 for the mel filters, 0..511 (+ their mirrored blocks) for
+  // the spectral statistics
+  constexpr int MR = (FEAT == 1) ? 16 : kMel32Rows;
+  using Map = Lds32<kMel32Rows>;   // untangle factors of rows 0..11; rows 12..15 are rows 0..3 times w2048^384
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably wave-uniform: SGPR arithmetic
@@ -386,6 +394,8 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       // sum m, m^2, j m, j^2 m, m^3, m^4 and the product of (m + 1e-20) in two halves (24 factors would underflow)
       double s1 = 0.0, s2 = 0.0, sj = 0.0, sjj = 0.0, s3 = 0.0, s4 = 0.0, prod_a = 1.0, prod_b = 1.0;
       double jq = 0.0, pa = 0.0;
+      double jmir = 0.0;   // pairs: j of this lane's bin in the next mirrored block: 1023 - q - 32 r, r = 8, 9, ..
+      double mir[4] = {0.0, 0.0, 0.0, 0.0}, cmid = 0.0;   // pairs: M_12..M_15 (index r - 12) and bin 512 (lane 0)
       // statistics class: magnitudes of rows 0..11 wait here for the rolloff walk (upper part of the wave's exchange
       // plane: 384 doubles per half behind the 8 KiB the hop DMA writes)
       double* const park = reinterpret_cast<double*>(plane_bytes + 8192 + 4352 * h);
@@ -393,13 +403,29 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         int ql = lane;
         asm volatile("" : "+v"(ql));
         jq = (double)((ql & 31) - 1);
+        if (PAIRS) jmir = (double)(767 - (ql & 31));   // M_8: bin 1024 - 256 - q
       }
-      // statistics class: one row's contribution to the sums (rows 0..11 after the mel stage, when the registers of
-      // the FFT are free; rows 12..23 as they are produced).  Bins 1..738: row 0 without bin 0, row 23 only bins
-      // 736..738; magnitudes below sqrt(DBL_MIN) are 0 in the reference (TAudioMath::Magnitude runs with DAZ + FZ): a
-      // silent frame has centroid 0, not (n - 1) / 2
+      // statistics class: one value's contribution to the sums over bins 1..738 (j = bin - 1): the direct rows 0..15
+      // (row 0 without bin 0; rows 0..11 after the mel stage, when the registers of the FFT are free, rows 12..15 as
+      // they are produced), bin 512, and the mirrored blocks M_15..M_8 (of M_8 = bins 737..768 only two bins).
+      // Magnitudes below sqrt(DBL_MIN) are 0 in the reference (TAudioMath::Magnitude runs with DAZ + FZ): a silent
+      // frame has centroid 0, not (n - 1) / 2.
+      // accumulate_at: a value that is not one of the direct rows (mirrored block, bin 512)
+      auto accumulate_at = [&](double value, double j, bool in_range) {
+        const bool ok = in_range && value > logc[kCSqrtMin];
+        const double m = ok ? value : 0.0;
+        const double m2 = m * m;
+        const double jm = j * m;
+        s1 += m;
+        s2 += m2;
+        sj += jm;
+        sjj = fma(j, jm, sjj);
+        s3 = fma(m2, m, s3);
+        s4 = fma(m2, m2, s4);
+        prod_b *= ok ? (value + logc[kCEps]) : 1.0;
+      };
       auto accumulate = [&](int r) {
-        const bool ok = ((r == 0) ? (q != 0) : ((r == 23) ? (q <= 2) : true)) && mag[r] > logc[kCSqrtMin];
+        const bool ok = ((r == 0) ? (q != 0) : true) && mag[r] > logc[kCSqrtMin];
         const double m = ok ? mag[r] : 0.0;
         const double m2 = m * m;
         const double jm = jq * m;
@@ -428,9 +454,22 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         }
         const double er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
         const double orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
-        const double xr = fma(wq.x, orr, fma(-wq.y, oi, er));
-        const double xi = fma(wq.x, oi, fma(wq.y, orr, ei));
-        mag[r] = mag_sqrt_mel(xr * xr + xi * xi);
+        if (PAIRS && r >= 8) {
+          const double tr = fma(wq.x, orr, -wq.y * oi), ti = fma(wq.x, oi, wq.y * orr);   // w O
+          const double xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
+          mag[r] = mag_sqrt_mel(xr * xr + xi * xi);
+          const double mv = mag_sqrt_mel(yr * yr + yi * yi);                              // |X[1024 - k]|
+          if (r < kMel32Rows) park[32 * (r + 4) + q] = mv;    // M_8..M_11 wait in LDS (slots 12..15) for the registers of the FFT
+          else {
+            mir[r - kMel32Rows] = mv;
+            accumulate_at(mv, jmir, true);
+            jmir -= logc[kC32];
+          }
+        } else {
+          const double xr = fma(wq.x, orr, fma(-wq.y, oi, er));
+          const double xi = fma(wq.x, oi, fma(wq.y, orr, ei));
+          mag[r] = mag_sqrt_mel(xr * xr + xi * xi);
+        }
         if (FEAT == 1 && r >= kMel32Rows) accumulate(r);
       };
 #pragma unroll
@@ -474,7 +513,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         __builtin_amdgcn_sched_barrier(0);
         AFX_STAMP(7);   // mel rows (waits for the table loads)
         if (FEAT == 1) {
-          // statistics class: the mel sums are reduced first (their registers are needed), then rows 12..23
+          // statistics class: the mel sums are reduced first (their registers are needed), then rows 12..15 and their mirrors
           const double tot1 = half_sum16(e, lane);
           if ((lane & 1) == (fi & 1)) mel_acc = tot1;
 #pragma unroll
@@ -492,22 +531,23 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 12; r < 16; ++r) fetch(r);
+          if constexpr (PAIRS) {   // the mirrored blocks of rows 8..11, parked by the untangle stage: bins 737..768 (two of them in range) .. 641..672
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              accumulate_at(park[32 * (12 + i) + q], jmir, (i == 0) ? (q >= 30) : true);
+              jmir -= logc[kC32];
+            }
+          }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 12; r < 16; ++r) untangle(r);
           __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r = 16; r < 20; ++r) fetch(r);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r = 16; r < 20; ++r) untangle(r);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r = 20; r < 24; ++r) fetch(r);
-          __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-          for (int r = 20; r < 24; ++r) untangle(r);
-          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (PAIRS) {
+            // bin 512 = lane 0 of row 16 is its own partner: E = 2 Re Z, w O = -2i Im Z (the window carries the 1/2)
+            const double er = v[16].re + v[16].re, orr = v[16].im + v[16].im;
+            cmid = (q == 0) ? mag_sqrt_mel(er * er + orr * orr) : 0.0;
+            accumulate_at(cmid, logc[kC511], q == 0);
+          }
         }
         // the next frame's window pairs, under the reduction and the log / DCT (statistics class: behind its sums,
         // which need the registers)
@@ -541,11 +581,20 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           const double total = __hiloint2double(__builtin_amdgcn_ds_bpermute(base_idx, __double2hiint(red)),
                                                 __builtin_amdgcn_ds_bpermute(base_idx, __double2loint(red)));
           const double pivot = total * logc[kCRoll];
-          // row sums of rows 12..23 (rows 0..11: pa, taken before they were parked in LDS)
+          // block sums (rows 0..11: pa, taken before they were parked in LDS); the blocks behind
+          // row 11 in bin order are rows 12..15, bin 512, M_15..M_12 (registers), M_11..M_8 (parked): 13 slots
           double rb[16];
+          if constexpr (PAIRS) {
 #pragma unroll
-          for (int r = 0; r < 16; ++r) rb[r] = (r < 11) ? mag[12 + r] : ((r == 11 && hq <= 2) ? mag[23] : 0.0);
-          double pb = half_sum16(rb, ln);            // lane L: row 12 + ((L & 31) >> 1)
+            for (int r = 0; r < 4; ++r) rb[r] = mag[12 + r];
+            rb[4] = cmid;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[5 + i] = mir[3 - i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[9 + i] = (i == 3 && hq < 30) ? 0.0 : park[32 * (15 - i) + hq];
+            rb[13] = rb[14] = rb[15] = 0.0;
+          }
+          double pb = half_sum16(rb, ln);            // lane L: slot (L & 31) >> 1
           // inclusive prefix over the row slots of a half (both lanes of a slot hold the same value)
 #pragma unroll
           for (int o = 2; o < 32; o <<= 1) {
@@ -558,7 +607,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           pb += tot_a;
           // rows wholly below the pivot (inclusive prefix < pivot)
           const unsigned long long ma = __ballot((hq & 1) == 0 && (hq >> 1) < 12 && pa < pivot);
-          const unsigned long long mb = __ballot((hq & 1) == 0 && (hq >> 1) < 12 && pb < pivot);
+          const unsigned long long mb = __ballot((hq & 1) == 0 && (hq >> 1) < 13 && pb < pivot);
           const unsigned halfmask_shift = ln & 32;
           const int rstar = __popc((unsigned)(ma >> halfmask_shift)) + __popc((unsigned)(mb >> halfmask_shift));
           // running sum before row rstar
@@ -571,10 +620,28 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
                                                  __builtin_amdgcn_ds_bpermute(idx_a, __double2loint(pb)));
           const double before = (rstar == 0) ? 0.0 : ((prev < 12) ? base_a : base_b);
           // the crossing row's magnitudes, summed along the lanes: rows 0..11 from their LDS parking place
-          double xs = park[32 * (rstar < 12 ? rstar : 0) + hq];
+          double xs;
+          bool okq;
+          int bins_before;
+          if constexpr (PAIRS) {
+            // block rstar in bin order: 0..15 rows, 16 bin 512, 17..20 M_15..M_12 (registers), 21..24 M_11..M_8 (parked);
+            // a mirrored block holds its bins in reversed lane order
+            const bool parked_m = rstar >= 21;
+            const int prow = (rstar < 12) ? rstar : (parked_m ? 36 - rstar : 0);
+            xs = park[32 * prow + (parked_m ? 31 - hq : hq)];
 #pragma unroll
-          for (int r = 12; r < 24; ++r) xs = (rstar == r) ? mag[r] : xs;
-          const bool okq = (rstar == 0) ? (hq != 0) : ((rstar == 23) ? (hq <= 2) : (rstar < 23));
+            for (int r = 12; r < 16; ++r) xs = (rstar == r) ? mag[r] : xs;
+            xs = (rstar == 16) ? cmid : xs;
+            double xm = mir[0];
+#pragma unroll
+            for (int i = 1; i < 4; ++i) xm = (rstar == 20 - i) ? mir[i] : xm;
+            const int ridx = base_idx + ((31 - hq) << 2);
+            const double xrev = __hiloint2double(__builtin_amdgcn_ds_bpermute(ridx, __double2hiint(xm)),
+                                                 __builtin_amdgcn_ds_bpermute(ridx, __double2loint(xm)));
+            xs = (rstar >= 17 && rstar <= 20) ? xrev : xs;
+            okq = (rstar == 0) ? (hq != 0) : ((rstar == 16) ? (hq == 0) : ((rstar == 24) ? (hq <= 1) : (rstar < 24)));
+            bins_before = (rstar < 16) ? 32 * rstar - (rstar > 0 ? 1 : 0) : ((rstar == 16) ? 511 : 512 + 32 * (rstar - 17));
+          }
           xs = okq ? xs : 0.0;
           double run = xs;
 #pragma unroll
@@ -584,7 +651,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           }
           const unsigned long long mrow = __ballot(okq && (before + run) < pivot);
           const int in_row = __popc((unsigned)(mrow >> halfmask_shift));
-          const int below = 32 * rstar - (rstar > 0 ? 1 : 0) + in_row;
+          const int below = bins_before + in_row;
           int cnt = (pivot > 0.0) ? below + 1 : 0;
           cnt = cnt > kBinCount ? kBinCount : cnt;
           if (live && hq == 0) tmp[7] = (double)cnt;

@@ -19,9 +19,8 @@
 //
 // Float semantics: the reference keeps the polar spectrum, the whitened magnitudes and both onset functions in `float`;
 // every expression below has the type of its counterpart and the file is compiled without FMA contraction.  The only
-// operations that are not the reference's bit for bit are libm calls: cosf (here: double cos rounded to float, equal
-// to glibc's cosf for ~98.7 % of arguments, 1 ulp otherwise), atan2 / sqrt of FFT outputs that differ in the last
-// bits, pow / log of the contrast.
+// operations that are not the reference's bit for bit are libm calls: atan2 / sqrt of FFT outputs that differ in the
+// last bits, pow / log of the contrast (cosf is glibc's algorithm, cosf_glibc below).
 #include "afx_internal.h"
 
 #include "afx_device.h"
@@ -48,6 +47,31 @@ __device__ __forceinline__ float phase_rewrap(float p) {   // SPhaseRewrap, OD.c
   constexpr float pi = (float)3.1415926535897932384626433832795, two_pi = (float)6.2831853071795864769252867665590,
                   inv = (float)0.15915494309189533576888376337251;
   return (p > -pi && p < pi) ? p : p + two_pi * (1.f + floorf((-pi - p) * inv));
+}
+
+// cosf as glibc (>= 2.28) computes it, the libm the reference calls on Linux (::cosf, OD.cpp:441): double-precision
+// reduction by pi/2 and the sincosf polynomials of sysdeps/ieee754/flt-32/s_sincosf.h (coefficients of its
+// __sincosf_table; the ARM optimized-routines algorithm), rounded to float once.  Valid for |y| < 120 -- the argument is
+// a rewrapped phase.  With the products fused as below it equals this container's cosf on 10^8 arguments of [-pi, pi]
+// (a CPU restatement, fused and unfused, against libm: 0 differences).
+__device__ __forceinline__ float cosf_glibc(float y) {
+  const unsigned top = (__float_as_uint(y) >> 20) & 0x7ffu;
+  double x = (double)y;
+  int n = 0;
+  if (top >= 0x3f4u) {                                             // |y| >= pi/4
+    const double r = x * 0x1.45F306DC9C883p+23;                    // 2/pi * 2^24
+    n = ((int)r + 0x800000) >> 24;
+    x = __builtin_fma(-(double)n, 0x1.921FB54442D18p0, x);
+  }
+  const double x2 = x * x;
+  const double xs = (((n + 1) & 2) != 0) ? -x : x;                 // sign[n & 3] = {1, -1, -1, 1}
+  const double x3 = xs * x2, t1 = __builtin_fma(x2, -0x1.994eb3774cf24p-13, 0x1.1107605230bc4p-7), x7 = x3 * x2;
+  const double sp = __builtin_fma(x7, t1, __builtin_fma(x3, -0x1.555545995a603p-3, xs));
+  const double x4 = x2 * x2, d2 = __builtin_fma(x2, 0x1.99343027bf8c3p-16, -0x1.6c087e89a359dp-10);
+  const double d1 = __builtin_fma(x2, -0x1.ffffffd0c621cp-2, 1.0), x6 = x4 * x2;
+  const double cp = __builtin_fma(x6, d2, __builtin_fma(x4, 0x1.55553e1068f19p-5, d1));
+  const double res = (n & 1) ? sp : ((n & 2) ? -cp : cp);          // quadrant n: cos, -sin, -cos, sin of the reduced angle
+  return (top < 0x398u) ? 1.0f : (float)res;                       // |y| < 2^-12
 }
 
 __device__ __forceinline__ void load2(const float* p, double& a, double& b) {
@@ -175,7 +199,7 @@ __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel
             const float pred_phase = yester_phase + yester_diff;
             float d = pred_phase - ph;
             d = phase_rewrap(d);
-            const float cs = (float)cos((double)d);
+            const float cs = cosf_glibc(d);
             dev = sqrtf(pred_mag * pred_mag + cur * cur - pred_mag * cur * cs);
           }
         }

@@ -6,8 +6,10 @@
 //   * file i of a crawl belongs to device i mod G (ShardOfFile): no exchange between devices, no collective;
 //   * every device is fed by W worker threads; a worker owns one page-locked staging buffer, fills it with the data
 //     chunks of its next batch of WAV files (TWaveFile), and runs LoadSample + every per-frame descriptor + the
-//     statistics on the GPU (afx_batch_create_from_raw / run); the C-ABI gives every batch its own stream and
-//     workspace, so the upload of one worker's batch overlaps the kernels of another's and the download of a third;
+//     statistics on the GPU (afx_batch_create_from_raw / run); the C-ABI gives every batch its own streams and
+//     workspace and sends the large transfers of a plan through one upload and one download stream, so the upload of
+//     one worker's batch overlaps the kernels of another's and the download of a third (the library raises the HIP
+//     runtime's hardware-queue limit to 16 for that; the workers' waits sleep: afx_set_blocking_wait);
 //   * results come back as the raw per-frame records and statistics (one transfer each, afx_batch_fetch_records)
 //     and go through a bounded queue to ONE writer, which materialises TSampleDescriptors per file and inserts them
 //     into the reference's `assets` table (TSqliteSampleDescriptorPool) -- or just counts them.

@@ -216,9 +216,11 @@ __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel
       }
     }
     __syncthreads();
-    // ---- one lane per (frame, function): the sums in the reference's order ----
-    if (tid < 2 * nf) {
-      const int fr = tid >> 1, type = tid & 1;
+    // ---- one lane per (frame, function): the sums in the reference's order; the two functions in different waves, so
+    //      that their dependent-add chains (255 double adds, 255 float adds) run side by side instead of as the two
+    //      sides of a divergent branch ----
+    if ((tid & 63) < nf && tid < 128) {
+      const int fr = tid & 63, type = tid >> 6;
       float v;
       // 255 terms added in bin order, 15 at a time in registers so that the LDS reads of a group are in flight together
       if (type == 0) {          // kFunctionRComplex: double sum of the float deviations, OD.cpp:398-458

@@ -5,7 +5,7 @@
 //   TCannyWindow                         Source/Crawler/FeatureExtraction/Source/CannyWindow.cpp     ("CW.cpp")
 //   aubio beat tracking                  3rdParty/Aubio/Dist/src/tempo/beattracking.c ("bt.c"), mathutils.c
 //
-// Two kernels, one workgroup (256 threads) per file:
+// Kernels (256 threads per workgroup; one workgroup per file, the post kernel one per file and onset function):
 //   onset_function_kernel  rounds of 16 frames: (1) one 16-lane group per frame computes the 512-point real FFT as a
 //                          256-point complex FFT (16 x 16 in registers, one LDS exchange) + untangle, magnitude and phase
 //                          of bins 0..254 as float; (2) thread = bin walks the 16 frames in order: adaptive-max whitening
@@ -354,11 +354,14 @@ __global__ __launch_bounds__(256, kPostWavesPerSimd) void rhythm_post_kernel(Rhy
   __shared__ unsigned s_hist[256];
   __shared__ int s_int[4];
   __shared__ unsigned long long s_key;
-  const RhythmFile f = a.files[blockIdx.x];
+  // one workgroup per (file, onset function): the two chains of a file are independent up to the final tempo, which
+  // rhythm_final_kernel derives from both (a lone long file is latency-bound: two workgroups halve its time)
+  const RhythmFile f = a.files[blockIdx.x >> 1];
   const int T = f.frames, tid = threadIdx.x;
-  double* out = a.scalars + (int64_t)blockIdx.x * 14;
+  double* out = a.scalars + (int64_t)(blockIdx.x >> 1) * 14;
   if (T <= 0) {
-    if (tid < 14) out[tid] = 0.0;
+    if (tid < 6) out[6 * (blockIdx.x & 1) + tid] = 0.0;
+    if (tid == 0) out[12 + (blockIdx.x & 1)] = 0.0;
     return;
   }
   const int64_t tot = a.total_frames;
@@ -366,7 +369,8 @@ __global__ __launch_bounds__(256, kPostWavesPerSimd) void rhythm_post_kernel(Rhy
   double tempo[2] = {0.0, 0.0}, conf[2] = {0.0, 0.0};
   int last_loud[2] = {0, 0};
 
-  for (int type = 0; type < 2; ++type) {
+  {
+    const int type = blockIdx.x & 1;
     double* raw = a.scratch + (int64_t)(0 + type) * tot + f.frame0;   // TRhythmTracker::Onsets
     double* S = a.scratch + (int64_t)(2 + type) * tot + f.frame0;     // SharpenedOnsets
     double* W = a.scratch + (int64_t)(4 + type) * tot + f.frame0;     // convolution, then the autocorrelation, then flags
@@ -685,8 +689,24 @@ __global__ __launch_bounds__(256, kPostWavesPerSimd) void rhythm_post_kernel(Rhy
     }
   }
 
-  // ---- final tempo: CalculateTempoWithHeuristics on the more confident function (SampleAnalyser.cpp:1029-1048, RT.cpp:238-325) ----
-  if (tid == 0) {
+  // the last analysed frame above the threshold travels to rhythm_final_kernel in the slot of the final results
+  if (tid == 0) out[12 + (blockIdx.x & 1)] = (double)last_loud[blockIdx.x & 1];
+}
+
+// ---- final tempo: CalculateTempoWithHeuristics on the more confident function (SampleAnalyser.cpp:1029-1048, RT.cpp:238-325);
+//      one thread per file, after both chains of the file ----
+__global__ __launch_bounds__(256) void rhythm_final_kernel(RhythmArgs a) {
+  const int file = blockIdx.x * blockDim.x + threadIdx.x;
+  if (file >= a.n_files) return;
+  const RhythmFile f = a.files[file];
+  const int T = f.frames;
+  double* out = a.scalars + (int64_t)file * 14;
+  if (T <= 0) { out[12] = 0.0; out[13] = 0.0; return; }
+  const int64_t tot = a.total_frames;
+  const int rate = a.sample_rate;
+  const double tempo[2] = {out[1], out[7]}, conf[2] = {out[2], out[8]};
+  const int last_loud[2] = {(int)out[12], (int)out[13]};
+  {
     const int type = (conf[1] > conf[0]) ? 1 : 0;
     const double* raw = a.scratch + (int64_t)(0 + type) * tot + f.frame0;
     double t_out = 0.0, c_out = 0.0;
@@ -768,7 +788,8 @@ hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) attribute_set[dev] = true;
   }
-  hipLaunchKernelGGL(rhythm_post_kernel, dim3(a.n_files), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(rhythm_post_kernel, dim3(2 * a.n_files), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(rhythm_final_kernel, dim3((a.n_files + 255) / 256), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

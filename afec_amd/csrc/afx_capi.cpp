@@ -1653,7 +1653,8 @@ void* afx_host_alloc(int64_t bytes) {
       if (tail) munmap(base + len, tail);
       madvise(base, len, MADV_HUGEPAGE);
       for (size_t off = 0; off < len; off += 4096) base[off] = 0;   // fault the pages in before they are locked
-      if (hipHostRegister(base, len, hipHostRegisterDefault) == hipSuccess) {
+      // portable: the streaming driver's pools hand a buffer to workers of any device
+      if (hipHostRegister(base, len, hipHostRegisterPortable) == hipSuccess) {
         std::lock_guard<std::mutex> lock(g_host_mutex);
         g_host_mapped.emplace_back(base, len);
         return base;

@@ -244,3 +244,28 @@ def test_rhythm_calls_are_validated_and_threads_agree():
     ref = _oracle.Oracle().run_rhythm(x.astype(np.float64), cap=True)
     assert np.array_equal(np.nonzero(want["onsets"][:, 0])[0], np.nonzero(ref["onsets"][0])[0])
     plan.close()
+
+
+def test_page_locked_blocks_of_every_size_class():
+    """afx_host_alloc: blocks of 8 MiB and more are huge-page mappings registered with the runtime, smaller ones come
+    from hipHostMalloc; both are plain memory to the host and sources of direct transfers to the device."""
+    from afec_amd import capi
+    rng = np.random.default_rng(5)
+    owners = []
+    for n_bytes in (1, 4096, (8 << 20) - 1, 8 << 20, (8 << 20) + 12345, 24 << 20):
+        arr, owner = capi.pinned_array((n_bytes,), np.uint8)
+        arr[:] = 0x5A
+        arr[-1] = 0xA5
+        assert int(arr[-1]) == 0xA5 and arr.size == n_bytes and (n_bytes == 1 or int(arr[0]) == 0x5A)
+        owners.append((arr, owner))
+    del owners                                   # freed in any order
+    x = (0.5 * rng.standard_normal(2048 + 1024 * 4999)).astype(np.float32)      # 20 MiB of PCM
+    pinned, owner = capi.pinned_array(x.shape, np.float32)
+    pinned[:] = x
+    p = afx.Plan()
+    a = p.extract([x], afx.D_MFCC | afx.D_SPECTRAL_CENTROID)
+    b = p.extract([pinned], afx.D_MFCC | afx.D_SPECTRAL_CENTROID)
+    np.testing.assert_array_equal(a["mfcc"], b["mfcc"])
+    np.testing.assert_array_equal(a["spectral_centroid"], b["spectral_centroid"])
+    p.close()
+    del pinned, owner

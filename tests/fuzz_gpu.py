@@ -141,8 +141,14 @@ def main():
                             continue
                         want = _oracle.calc_statistics(v)
                         tiny = abs(v.sum()) < 1e-3 * np.abs(v).sum() or not np.abs(v).sum() > 0   # sum by cancellation: centroid, spread, ... are ill-conditioned
+                        # a series that is constant to 1e-9 of its level: the rounding of the mean is a visible part of
+                        # the standard deviation, which skewness and kurtosis divide by to the 3rd / 4th power (observed:
+                        # 4.60e35 vs 4.57e35)
+                        flatline = float(np.std(v)) <= 1e-9 * float(np.abs(v).max())
                         for j, sn in enumerate(afx.STAT_NAMES):
                             if tiny and sn in ("centroid", "spread", "skewness", "kurtosis", "flatness"):
+                                continue
+                            if flatline and sn in ("skewness", "kurtosis"):
                                 continue
                             if not abs(got[w, j] - want[j]) <= 1e-8 * abs(want[j]) + 1e-11:
                                 bad += 1

@@ -302,8 +302,9 @@ int upload_halfwave_tables(afx_plan* p) {
   for (int r = 0; r < 32; ++r)
     for (int q = 0; q < 32; ++q) {
       const int n = q + 32 * r;
-      // 1/fft: kDivFwdByN (Fourier.cpp:265-270); 1/2: even/odd untangle of the half-size FFT
-      win[32 * r + q] = {p->window[2 * n] / (2.0 * fft), p->window[2 * n + 1] / (2.0 * fft)};
+      // 1/fft: kDivFwdByN (Fourier.cpp:265-270); 1/2: even/odd untangle of the half-size FFT; another 1/2: the
+      // magnitude's Newton step returns twice the square root (mag_sqrt_mel, afx_frames32.hip)
+      win[32 * r + q] = {p->window[2 * n] / (4.0 * fft), p->window[2 * n + 1] / (4.0 * fft)};
       tw[32 * r + q] = twiddle<double>((long long)r * q, 1024);   // [n2 = r][k1 = q]
       post[32 * r + q] = twiddle<double>(n, 2048);
     }

@@ -62,15 +62,49 @@ __device__ __forceinline__ double table_load1(__amdgpu_buffer_rsrc_t rs, int lan
   return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, lane_off, row_off, 0));
 }
 
-// Magnitude for the mel sums: v_rsq_f64 seed (~2^-23) + one Goldschmidt step (~2e-14 relative).  Sums of squares
-// below the smallest normal double come out as sqrt(DBL_MIN) ~ 1.5e-154 instead of the reference's flushed 0
-// (TAudioMath::Magnitude runs with DAZ + FZ, AudioMath.cpp:25-35): every mel sum of such bins stays below the
-// 2e-42 floor of the logarithm, so the MFCCs are the same and the select is saved.
-__device__ __forceinline__ double mag_sqrt_mel(double x) {
-  const double xs = fmax(x, 2.2250738585072014e-308);
-  const double r = __builtin_amdgcn_rsq(xs);
-  const double g = xs * r, h = 0.5 * r;
-  return fma(g, fma(-h, g, 0.5), g);
+// LDS-DMA of one 1 KiB piece (16 bytes per lane: lane L's bytes land at lds_base + IMM + 16 L, read from
+// gaddr + IMM; non-temporal: the PCM is read once).  Inline assembly on purpose: for the builtin the compiler's
+// wait-count pass assumes that every later DS read may alias the DMA's LDS write and puts s_waitcnt vmcnt(0) in
+// front of it.  The kernel orders the DMA against its own DS traffic by hand: it is issued behind an explicit
+// s_waitcnt lgkmcnt(0) (the exchange reads have returned) and the hop is read behind an explicit s_waitcnt vmcnt(0).
+// M0 has no other user in this kernel (gfx9 DS instructions do not read it).
+template <int IMM>
+__device__ __forceinline__ void dma_piece(const void* gaddr, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2 nt"
+               :: "v"(gaddr), "s"(lds_base), "n"(IMM) : "memory");
+}
+// the eight pieces of a wave's hop image: global piece j at +512 j bytes, LDS piece j at +1024 j
+__device__ __forceinline__ void dma_hop(const float* g, unsigned lds_plane) {
+  dma_piece<0>(g, lds_plane);
+  dma_piece<512>(g, lds_plane + 512);
+  dma_piece<1024>(g, lds_plane + 1024);
+  dma_piece<1536>(g, lds_plane + 1536);
+  dma_piece<2048>(g, lds_plane + 2048);
+  dma_piece<2560>(g, lds_plane + 2560);
+  dma_piece<3072>(g, lds_plane + 3072);
+  dma_piece<3584>(g, lds_plane + 3584);
+}
+
+// Magnitude 2 sqrt(xr^2 + xi^2 + DBL_MIN): v_rsq_f64 seed (~2^-23) + one Newton step y (3 - r y) (~2e-14 relative)
+// without its division by two -- the window table carries that 1/2, so the arguments are the halved spectrum and the
+// result is |X|.  The DBL_MIN keeps the seed finite for an all-zero bin; sums of squares of the true spectrum below
+// DBL_MIN -- which the reference flushes to 0 (TAudioMath::Magnitude runs with DAZ + FZ, AudioMath.cpp:25-35) -- come
+// out as at most sqrt(5 DBL_MIN) = kFlushLevel: every mel sum of such bins stays below the 2e-42 floor of the
+// logarithm, and the statistics class drops them by comparing with that level.  tiny / three: SGPR pairs (a 64-bit
+// literal would cost a VGPR pair for the whole kernel).
+__device__ __forceinline__ double mag_sqrt_mel(double xr, double xi, double tiny, double three) {
+  const double x = fma(xi, xi, fma(xr, xr, tiny));
+  const double r = __builtin_amdgcn_rsq(x);
+  const double y = x * r;
+  return y * fma(-r, y, three);
+}
+
+// Lanes 0 and 32 (bins 32 r) are their own partners, at another register than everybody else's: two 64-bit moves
+// under EXEC = {0, 32} put their values in place, instead of four v_cndmask_b32 per row.  Only called where EXEC is
+// all ones (wave-uniform control flow).
+__device__ __forceinline__ void keep_lane0(double& re, double& im, double own_re, double own_im, unsigned long long lane0_mask) {
+  asm("s_mov_b64 exec, %4\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3\n\ts_mov_b64 exec, -1"
+      : "+v"(re), "+v"(im) : "v"(own_re), "v"(own_im), "s"(lane0_mask));
 }
 
 // ---- reduction of 16 per-lane values over the 32 lanes of each half, in registers: lane L ends with the total of
@@ -110,7 +144,7 @@ __device__ const double kLogConst[32] = {1.0 / 23.0, 1.0 / 21.0, 1.0 / 19.0, 1.0
                                          // constants of the statistics class (kC* below)
                                          1e-20, 32.0, 0.38268343236508984, -0.9238795325112867, 1.0 / 738.0,
                                          (double)(85.0f / 100.0), 43.0, -1.0 / 60.0, (double)1e-12f, 3.0,
-                                         1.44269504088896340736, 20.0 / 2.30258509299404568402, 2.2250738585072014e-308, 1.4916681477317095e-154, 511.0, 0.0, 0.0, 0.0};
+                                         1.44269504088896340736, 20.0 / 2.30258509299404568402, 2.2250738585072014e-308, 3.33547137486383e-154 /* kFlushLevel = sqrt(5 DBL_MIN) */, 511.0, 0.0, 0.0, 0.0};
 // indices into kLogConst of the statistics class' constants
 constexpr int kCEps = 14, kC32 = 15, kCRotRe = 16, kCRotIm = 17, kCRoll = 19, kCSqrtMin = 27, kC511 = 28;
 // (entries 18, 20..26 -- 1/738, 43, -1/60, 1e-12f, 3, log2 e, 20/ln 10, DBL_MIN -- served the closed forms while they
@@ -232,9 +266,14 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
   // between two exchanges: image [row][half][q] float2.  Lane L moves complex samples 2 (L & 15), +1 of row
   // 16 + 2 j + (L >> 5) of half (L >> 4) & 1.
   const int dh = (lane >> 4) & 1, drow = lane >> 5, dq = 2 * (lane & 15);
-  typedef __attribute__((address_space(1))) const void gvoid;
   typedef __attribute__((address_space(3))) void lvoid;
   unsigned char* const plane_bytes = lds_raw + Map::xchg + wave * kPlane32Bytes;
+  // the plane's LDS byte address as a wave-uniform scalar (M0 of the DMA)
+  const unsigned plane_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lvoid*)plane_bytes);
+  // scalar constants of the magnitude (laundered: the compiler must keep them in SGPR pairs, not fold them into VGPRs)
+  double k_tiny = 2.2250738585072014e-308, k_three = 3.0;
+  unsigned long long k_lane0 = 0x0000000100000001ull;   // EXEC of keep_lane0: lanes 0 and 32
+  asm volatile("" : "+s"(k_tiny), "+s"(k_three), "+s"(k_lane0));
   lds_vdouble* const hop = (lds_vdouble*)(plane_bytes + 256 * h + 8 * q);   // + 64 r (8-byte units: 512 bytes a row)
 
   const float* const pcm = reinterpret_cast<const float*>(a.pcm);
@@ -264,9 +303,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 #pragma unroll
     for (int r = 0; r < 16; ++r) lo[r] = src[32 * r];
     // frame 0's new hop (every DS operation of the previous chunk has been waited for)
-#pragma unroll
-    for (int j = 0; j < 8; ++j)
-      __builtin_amdgcn_global_load_lds((gvoid*)(dsrc + 128 * j), (lvoid*)(plane_bytes + 1024 * j), 16, 0, 0);
+    dma_hop(dsrc, plane_lds);
 
     double mel_acc = 0.0;  // mel sums of up to two finished frames per half: lane 2 f + slot
     // this lane's output element: coefficient (q >> 1) of the frame in slot q & 1
@@ -360,12 +397,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       // re-reads its own hop (no branch: the loop body stays one basic block).
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       AFX_STAMP(3);   // exchange
-      {
-        const float* const nd = dsrc + (size_t)min(fi + 1, last_d) * kHop;
-#pragma unroll
-        for (int j = 0; j < 8; ++j)
-          __builtin_amdgcn_global_load_lds((gvoid*)(nd + 128 * j), (lvoid*)(plane_bytes + 1024 * j), 16, 0, 0);
-      }
+      dma_hop(dsrc + (size_t)min(fi + 1, last_d) * kHop, plane_lds);
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- T + P2: v[k2] = Z[q + 32 k2]; the factors w1024^(n2 k1) are fused into the first radix-4 stage of
@@ -445,7 +477,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       };
       auto untangle = [&](int r) {
         cx<double> p = pp[r];
-        if (q == 0) p = v[(32 - r) & 31];
+        keep_lane0(p.re, p.im, v[(32 - r) & 31].re, v[(32 - r) & 31].im, k_lane0);   // q == 0: bin 32 r pairs with this lane's Z[1024 - 32 r]
         const cx<double> z = v[r];
         double2 wq = pw2[r];
         if (r >= kMel32Rows) {   // w2048^(q + 32 r) = w2048^(q + 32 (r - 12)) w2048^384
@@ -457,8 +489,8 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         if (PAIRS && r >= 8) {
           const double tr = fma(wq.x, orr, -wq.y * oi), ti = fma(wq.x, oi, wq.y * orr);   // w O
           const double xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
-          mag[r] = mag_sqrt_mel(xr * xr + xi * xi);
-          const double mv = mag_sqrt_mel(yr * yr + yi * yi);                              // |X[1024 - k]|
+          mag[r] = mag_sqrt_mel(xr, xi, k_tiny, k_three);
+          const double mv = mag_sqrt_mel(yr, yi, k_tiny, k_three);                        // |X[1024 - k]|
           if (r < kMel32Rows) park[32 * (r + 4) + q] = mv;    // M_8..M_11 wait in LDS (slots 12..15) for the registers of the FFT
           else {
             mir[r - kMel32Rows] = mv;
@@ -468,7 +500,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         } else {
           const double xr = fma(wq.x, orr, fma(-wq.y, oi, er));
           const double xi = fma(wq.x, oi, fma(wq.y, orr, ei));
-          mag[r] = mag_sqrt_mel(xr * xr + xi * xi);
+          mag[r] = mag_sqrt_mel(xr, xi, k_tiny, k_three);
         }
         if (FEAT == 1 && r >= kMel32Rows) accumulate(r);
       };
@@ -545,7 +577,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           if constexpr (PAIRS) {
             // bin 512 = lane 0 of row 16 is its own partner: E = 2 Re Z, w O = -2i Im Z (the window carries the 1/2)
             const double er = v[16].re + v[16].re, orr = v[16].im + v[16].im;
-            cmid = (q == 0) ? mag_sqrt_mel(er * er + orr * orr) : 0.0;
+            cmid = (q == 0) ? mag_sqrt_mel(er, orr, k_tiny, k_three) : 0.0;
             accumulate_at(cmid, logc[kC511], q == 0);
           }
         }

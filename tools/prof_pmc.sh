@@ -1,10 +1,10 @@
 #!/bin/bash
 # rocprofv3 PMC passes + kernel trace of one bench.py configuration.
-# usage: prof_pmc.sh <tag> <kernel-substring> [bench.py args...]; outputs gpurun_out/r02/<tag>_*.csv
+# usage: [PMC_PASSES='A B;C D'] [PMC_LIB=path] prof_pmc.sh <tag> <kernel-substring> [bench.py args...]; outputs gpurun_out/r03/<tag>_*.csv
 set -u
 TAG=$1; KSUB=$2; shift 2
 ROOT=$(pwd)
-O=$ROOT/gpurun_out/r02; mkdir -p $O
+O=$ROOT/gpurun_out/r03; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 PASSES=(
@@ -14,6 +14,8 @@ PASSES=(
  "FETCH_SIZE"
  "WRITE_SIZE"
 )
+if [ -n "${PMC_PASSES:-}" ]; then IFS=';' read -ra PASSES <<< "$PMC_PASSES"; fi
+[ -n "${PMC_LIB:-}" ] && export AFX_LIBRARY=$PMC_LIB
 i=0
 for P in "${PASSES[@]}"; do
   rm -rf /tmp/pmc_${TAG}_$i

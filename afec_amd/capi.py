@@ -61,7 +61,7 @@ EXPORTS = [
     "afx_algorithmic_bytes_per_frame", "afx_batch_create_from_raw", "afx_batch_fetch_samples",
     "afx_host_alloc", "afx_host_free", "afx_batch_record_layout", "afx_batch_fetch_records",
     "afx_batch_set_file_info", "afx_batch_rhythm_frames", "afx_batch_fetch_rhythm", "afx_batch_fetch_onset_functions",
-    "afx_set_blocking_wait",
+    "afx_plan_set_blocking_wait",
 ]
 RAW_I16, RAW_I24, RAW_F32 = 0, 1, 2
 

@@ -163,7 +163,7 @@ struct Workspace {
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipEvent_t ev_copy = nullptr;   // the host's waits for the plan's upload / download streams (and, when blocking, for this batch's stream)
-  bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_set_blocking_wait)
+  bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_plan_set_blocking_wait)
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
   Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff;   // rhythm tracker
@@ -180,6 +180,7 @@ struct afx_plan {
   // after afx_plan_destroy still finds its plan, its device and its workspace pool)
   std::atomic<int> refs{1};
   std::mutex pool_mutex;
+  std::atomic<bool> blocking_wait{false};   // afx_plan_set_blocking_wait: the host's waits of this plan's batches sleep
   std::vector<Workspace*> pool;
   afx_plan_desc desc;
   int first_bin, last_bin, bin_count;
@@ -410,7 +411,6 @@ void ws_free(Workspace* w) {
   delete w;
 }
 
-std::atomic<bool> g_blocking_wait(false);   // afx_set_blocking_wait: copy events of workspaces created from now on block too
 
 // pooled workspaces: at most 16 idle ones per plan, none larger than 4 GiB (a 1024-file batch of one-second files with
 // every descriptor needs ~1 GiB: magnitudes 8 KiB and PCM 8 KiB per frame)
@@ -423,6 +423,7 @@ Workspace* ws_acquire(afx_plan* plan, hipError_t* err) {
     if (!plan->pool.empty()) {
       Workspace* w = plan->pool.back();
       plan->pool.pop_back();
+      w->blocking = plan->blocking_wait.load();
       return w;
     }
   }
@@ -434,7 +435,7 @@ Workspace* ws_acquire(afx_plan* plan, hipError_t* err) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->side_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming);
-  w->blocking = g_blocking_wait.load();
+  w->blocking = plan->blocking_wait.load();
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_copy, hipEventDisableTiming);
   if (e != hipSuccess) { *err = e; ws_free(w); return nullptr; }
   return w;
@@ -575,7 +576,7 @@ const char* afx_build_info(void) {
 #define AFX_INFO_STAMPS "0"
 #endif
 #define AFX_INFO_ABL "0"   /* the ablation switches of round 1 are gone from the sources */
-  return "afx abi=" "3" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL;
+  return "afx abi=" "4" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL;
 }
 
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
@@ -965,22 +966,12 @@ struct CreateTiming {
 };
 CreateTiming g_create_timing;
 
-// HIP multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default), and the packets of streams
-// that share a queue execute in order.  A pipeline keeps 2 streams per batch in flight plus the plan's two copy streams:
-// on 4 queues six to eight batches in flight serialise (205 k one-second files/s on one MI355X), on 16 they do not
-// (268 k).  Not more than 16: once a process has created more queues than the device has hardware slots for (between
-// 18 and 24 on this system) they are time-sliced, and the same crawl drops to 175 k files/s.  The variable is read
-// when the HIP runtime initialises, so it is set when this library is loaded, and only when the process has not
-// chosen a value itself.
-struct HwQueueDefault {
-  HwQueueDefault() { setenv("GPU_MAX_HW_QUEUES", "16", /*overwrite=*/0); }
-} g_hw_queue_default;
 inline long long now_ns() {
   return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
 // The host's waits.  hipStreamSynchronize / hipEventSynchronize spin (one busy CPU per waiting thread); with
-// afx_set_blocking_wait the thread polls the workspace's copy event and sleeps in between.  The runtime's own
+// afx_plan_set_blocking_wait the thread polls the workspace's copy event and sleeps in between.  The runtime's own
 // alternatives did not serve: hipEventBlockingSync alone changes nothing here (the eight workers of a crawl still keep
 // 6.6 CPUs busy), and hipDeviceScheduleBlockingSync, set on a device that is already active, left a later
 // hipStreamSynchronize hanging.
@@ -1217,7 +1208,13 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
         contiguous = ((const char*)raws[i].data == base + files[i].raw_off);
       }
     if (contiguous && base) {
-      if ((e = upload_through_plan(plan, ws, d_raw, base, (size_t)raw_bytes)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
+      // up to the last valid file's real end: raw_bytes rounds every file up to 16 bytes, and the bytes behind the
+      // caller's last buffer are not the library's to read (a buffer may end at the end of a mapping)
+      int64_t used = 0;
+      for (int i = 0; i < n_bufs; ++i)
+        if (status[i] == AFX_OK)
+          used = files[i].raw_off + (int64_t)raws[i].n_frames * raws[i].channels * raw_bytes_per_sample(raws[i].format);
+      if ((e = upload_through_plan(plan, ws, d_raw, base, (size_t)used)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
     } else {
       for (int i = 0; i < n_bufs; ++i)
         if (status[i] == AFX_OK) {
@@ -1587,6 +1584,9 @@ void afx_batch_destroy(afx_batch* b) {
   struct Release { afx_plan* p; ~Release() { plan_release(p); } } release_plan_last{plan};
   hipSetDevice(b->plan->desc.device);
   if (b->stream) hipStreamSynchronize(b->stream);
+  // a run that failed between the rhythm chain's fork and its join leaves kernels on the side stream: they must be
+  // done before the workspace goes back to the pool
+  if (b->ws && b->ws->side_stream && (b->mask & AFX_D_RHYTHM)) hipStreamSynchronize(b->ws->side_stream);
 #if defined(AFX_STAMPS) && AFX_STAMPS
   if (g_stamp_buf) {
     unsigned long long h[16];
@@ -1629,7 +1629,11 @@ void afx_batch_destroy(afx_batch* b) {
   delete b;
 }
 
-void afx_set_blocking_wait(int32_t blocking) { g_blocking_wait = blocking != 0; }
+int afx_plan_set_blocking_wait(afx_plan* plan, int32_t blocking) {
+  if (!plan) return AFX_ERR_INVALID_ARG;
+  plan->blocking_wait = blocking != 0;
+  return AFX_OK;
+}
 
 // Page-locked host memory.  Large blocks are anonymous mappings on 2 MiB boundaries with MADV_HUGEPAGE, touched and then
 // registered with the runtime: page-locking huge pages takes a third of hipHostMalloc's time (7.3 vs 21-23 ms per

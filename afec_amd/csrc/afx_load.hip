@@ -193,7 +193,8 @@ __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned
   // written here, by the first workgroup of the file, so that the arena needs no memset (it is written exactly once)
   if (blockIdx.y == 0) {
     const int64_t slot = (p.out_n + 3) & ~(int64_t)3, tail = p.start_pad + n_copy;
-    for (int64_t n = threadIdx.x; n < p.start_pad; n += kLoadThreads) dst[n] = 0.0;
+    const int64_t pad = p.start_pad < slot ? p.start_pad : slot;   // a capped analysis may end inside the start pad
+    for (int64_t n = threadIdx.x; n < pad; n += kLoadThreads) dst[n] = 0.0;
     for (int64_t n = tail + threadIdx.x; n < slot; n += kLoadThreads) dst[n] = 0.0;
   }
   // groups of four source frames on the source's alignment (vector loads); frames before `lead` and behind the copied

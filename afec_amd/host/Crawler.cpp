@@ -11,6 +11,7 @@
 #include <memory>
 #include <mutex>
 #include <thread>
+#include <time.h>
 
 #include <sys/stat.h>
 
@@ -24,6 +25,12 @@ namespace {
 
 double Now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+double ProcessCpuSeconds() {
+  timespec t;
+  ::clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
 // page-locked host memory (afx_host_alloc), grown on demand
@@ -83,6 +90,7 @@ struct TFinishedBatch {
   std::vector<const TCrawlFile*> mFiles;
   std::vector<TFileProperties> mProperties;
   std::vector<std::string> mFailed;          // non-empty: the file is a failed sample with this reason
+  std::vector<char> mSkipped;                // 1: not analysed and not recorded (sampling rate other than the analyser's)
   std::vector<int> mBatchIndex;              // file -> index inside mResults, -1 for files that never reached the GPU
   TRecordBatch mResults;
   std::unique_ptr<TPinned> mpRecords, mpStatistics, mpRhythm;
@@ -139,10 +147,13 @@ TCrawler::TCrawler(const TCrawlOptions& Options) : mpImpl(new TImpl) {
   try {
     // one analyser (plan) per device, shared by that device's workers like the reference's const analyser; the
     // workers' waits for the device sleep instead of spinning (eight spinning threads per GPU would need eight CPUs
-    // per GPU for the same throughput)
-    afx_set_blocking_wait(1);
-    for (int Device : Options.mDevices)
+    // per GPU for the same throughput); the hardware-queue wish has to reach the runtime before its first call
+    if (Options.mHardwareQueues > 0)
+      ::setenv("GPU_MAX_HW_QUEUES", std::to_string(Options.mHardwareQueues).c_str(), /*overwrite=*/0);
+    for (int Device : Options.mDevices) {
       mpImpl->mAnalysers.emplace_back(new TSampleAnalyser(Options.mSampleRate, Options.mFftFrameSize, Options.mHopFrameSize, Device));
+      mpImpl->mAnalysers.back()->SetSleepingWaits(Options.mSleepingWaits);
+    }
   } catch (...) {
     delete mpImpl;
     throw;
@@ -228,6 +239,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
         Done.mFiles.assign(Shard[(size_t)d].begin() + (long)Begin, Shard[(size_t)d].begin() + (long)End);
         Done.mProperties.resize(n);
         Done.mFailed.assign(n, std::string());
+        Done.mSkipped.assign(n, 0);
         Done.mBatchIndex.assign(n, -1);
         // parse; lay the data chunks out in the page-locked staging buffer
         const double tParse0 = Now();
@@ -243,6 +255,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
             const TCrawlFile& f = *Done.mFiles[i];
             if (f.mpImage) Waves[i]->OpenForRead(f.mpImage, f.mImageSize, f.mFileName);
             else Waves[i]->OpenForRead(f.mFileName);
+            if (Waves[i]->SamplingRate() != Options.mSampleRate) { Done.mSkipped[i] = 1; continue; }
             TDecodedSample s = Waves[i]->DecodedSample(Widened[i]);
             TFileProperties& p = Done.mProperties[i];
             p.mFileType = "wav";
@@ -279,6 +292,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
           size_t MaxFrames = 0;
           for (const TDecodedSample& s : Decoded) MaxFrames += (size_t)(s.mNumberOfSampleFrames / Options.mHopFrameSize) + 3;
           size_t Capacity = MaxFrames * (size_t)TSampleAnalyser::kMaxStride;
+          int Attempts = 0;
           for (;;) {
             if (Done.mpRecords) Done.mpRecords->Reserve(Capacity * sizeof(double));
             else Done.mpRecords = Pool.Acquire(Capacity * sizeof(double));
@@ -286,6 +300,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
                                           (double*)Done.mpStatistics->mp, (double*)Done.mpRhythm->mp,
                                           Done.mpRhythm->mBytes / sizeof(double), Done.mResults))
               break;
+            if (++Attempts > 6) throw TReadableException("AnalyzeToRecords: the results do not fit the largest buffers tried");
             Capacity *= 2;
             Done.mpRhythm->Reserve(2 * Done.mpRhythm->mBytes);
           }
@@ -324,11 +339,13 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   std::thread Writer([&] {
     while (std::unique_ptr<TFinishedBatch> p = Queue.Pop()) {
       const double t0 = Now();
-      int64_t Failed = 0;
+      int64_t Failed = 0, Skipped = 0;
       for (size_t i = 0; i < p->mFiles.size(); ++i) {
         const TCrawlFile& f = *p->mFiles[i];
         try {
-          if (!p->mFailed[i].empty()) {
+          if (p->mSkipped[i]) {
+            ++Skipped;
+          } else if (!p->mFailed[i].empty()) {
             ++Failed;
             if (pPool) pPool->InsertFailedSample(f.mFileName, f.mModificationTime, p->mFailed[i]);
           } else if (pPool) {
@@ -347,11 +364,13 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
       RhythmPool.Release(std::move(p->mpRhythm));
       std::lock_guard<std::mutex> Lock(StatMutex);
       Total.mFailedFiles += Failed;
+      Total.mSkippedSampleRateFiles += Skipped;
       if (pPool) Total.mWriterSeconds += Now() - t0;
     }
   });
 
   const double Start = Now();
+  const double CpuStart = ProcessCpuSeconds();
   std::vector<std::thread> Workers;
   for (int d = 0; d < G; ++d)
     for (int w = 0; w < W; ++w) Workers.emplace_back(Worker, d);
@@ -359,6 +378,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   Queue.Close();
   Writer.join();
   Total.mSeconds = Now() - Start;
+  Total.mCpuSeconds = ProcessCpuSeconds() - CpuStart;
   if (std::getenv("AFEC_CRAWL_TIMING"))
     std::fprintf(stderr, "[afec crawl] %.1f ms wall; worker time summed over %d workers: parse + staging %.1f ms, GPU round trip %.1f ms\n",
                  Total.mSeconds * 1e3, G * W, PhaseSeconds[0] * 1e3, PhaseSeconds[1] * 1e3);
@@ -372,14 +392,13 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
 }  // namespace afec
 
 namespace {
-std::mutex gCrawlerMutex, gCrawlMutex;
+std::mutex gCrawlerMutex;
 std::atomic<int64_t> gBytesPerBatch(0);   // afec_crawl_set_bytes_per_batch: 0 = TCrawlOptions' default
 std::vector<std::pair<std::string, afec::TCrawler*>> gCrawlers;   // never destroyed at exit: the HIP runtime may be gone by then
 }  // namespace
 
 extern "C" void afec_crawl_release(void) {
   std::lock_guard<std::mutex> Lock(gCrawlerMutex);
-  std::lock_guard<std::mutex> Lock2(gCrawlMutex);
   for (auto& Entry : gCrawlers) delete Entry.second;
   gCrawlers.clear();
 }
@@ -405,11 +424,13 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     if (database_path) Options.mDatabasePath = database_path;
     if (gBytesPerBatch > 0) Options.mBytesPerBatch = gBytesPerBatch;
     // one crawler per (devices, geometry), kept between calls
+    // (the registry lock is held for the whole crawl: afec_crawl_release cannot delete a crawler that is in use, and
+    // crawls through this entry point run one at a time)
+    std::lock_guard<std::mutex> Lock(gCrawlerMutex);
     afec::TCrawler* pCrawler = nullptr;
     {
       std::string Key;
       for (int d : Options.mDevices) Key += std::to_string(d) + ",";
-      std::lock_guard<std::mutex> Lock(gCrawlerMutex);
       for (auto& Entry : gCrawlers)
         if (Entry.first == Key) pCrawler = Entry.second;
       if (!pCrawler) {
@@ -417,16 +438,14 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
         gCrawlers.emplace_back(Key, pCrawler);
       }
     }
-    afec::TCrawlStatistics s;
-    {
-      std::lock_guard<std::mutex> Lock(gCrawlMutex);   // one crawl at a time per crawler
-      s = pCrawler->Crawl(Files, Options);
-    }
+    const afec::TCrawlStatistics s = pCrawler->Crawl(Files, Options);
     if (stats) {
       stats[0] = (double)s.mFiles; stats[1] = (double)s.mFailedFiles; stats[2] = (double)s.mFrames; stats[3] = (double)s.mPcmBytes;
       stats[4] = (double)s.mResultBytes; stats[5] = s.mSeconds; stats[6] = s.mWriterSeconds;
       stats[7] = (double)s.mBatches;
       for (int32_t d = 0; d < n_devices; ++d) stats[8 + d] = (double)s.mFilesPerDevice[(size_t)d];
+      stats[8 + n_devices] = s.mCpuSeconds;
+      stats[9 + n_devices] = (double)s.mSkippedSampleRateFiles;
     }
     return 0;
   } catch (const std::exception& e) {

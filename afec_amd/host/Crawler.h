@@ -8,8 +8,9 @@
 //     chunks of its next batch of WAV files (TWaveFile), and runs LoadSample + every per-frame descriptor + the
 //     statistics on the GPU (afx_batch_create_from_raw / run); the C-ABI gives every batch its own streams and
 //     workspace and sends the large transfers of a plan through one upload and one download stream, so the upload of
-//     one worker's batch overlaps the kernels of another's and the download of a third (the library raises the HIP
-//     runtime's hardware-queue limit to 16 for that; the workers' waits sleep: afx_set_blocking_wait);
+//     one worker's batch overlaps the kernels of another's and the download of a third (the crawler asks the HIP
+//     runtime for 16 hardware queues for that and lets the workers' waits sleep: TCrawlOptions::mHardwareQueues,
+//     mSleepingWaits);
 //   * results come back as the raw per-frame records and statistics (one transfer each, afx_batch_fetch_records)
 //     and go through a bounded queue to ONE writer, which materialises TSampleDescriptors per file and inserts them
 //     into the reference's `assets` table (TSqliteSampleDescriptorPool) -- or just counts them.
@@ -38,15 +39,31 @@ struct TCrawlOptions {
                                     // 16-bit mono file needs ~10 x its size in device memory: PCM as doubles, spectra)
   std::string mDatabasePath;        // empty: results are counted, not stored
   int mSampleRate = 44100, mFftFrameSize = 2048, mHopFrameSize = 1024;
+  // Runtime knobs the crawler applies itself, to its own plans only (libafx_hip.so changes nothing process-wide):
+  // * the HIP runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and the
+  //   packets of a queue execute in order; with 2 streams per batch in flight + the plan's two copy streams the
+  //   crawl wants 16 (205 k -> 268 k one-second files/s on one MI355X; more than the device's ~20 hardware slots are
+  //   time-sliced: 175 k).  The runtime reads the variable when it initialises, so the first TCrawler of a process
+  //   sets it -- unless the variable is already set or mHardwareQueues is 0 -- and it takes effect only when no HIP
+  //   call was made before.
+  // * worker threads that wait for the device sleep between event polls (20 us naps) instead of spinning: the same
+  //   throughput with ~3 instead of ~7 busy CPUs per GPU.
+  int mHardwareQueues = 16;
+  bool mSleepingWaits = true;
 };
 
 struct TCrawlStatistics {
   int64_t mFiles = 0, mFailedFiles = 0, mFrames = 0, mBatches = 0;
+  // Files at another sampling rate than the analyser's: the reference resamples them (SampleAnalyser.cpp:563-607,
+  // libresample), this library does not.  They are neither analysed nor written as failed
+  // samples -- a later crawl with a resampling front end finds them missing, not broken.
+  int64_t mSkippedSampleRateFiles = 0;
   int64_t mPcmBytes = 0;            // bytes of PCM uploaded
   int64_t mResultBytes = 0;         // bytes of records + statistics downloaded
   double mSeconds = 0;              // first file read .. last result delivered to the writer
   double mWriterSeconds = 0;        // time the writer spent inserting (0 without a database)
   std::vector<int64_t> mFilesPerDevice;
+  double mCpuSeconds = 0;           // CPU time the process spent during the crawl (all threads): mCpuSeconds / mSeconds = busy CPUs
 };
 
 // file i -> device index i mod G
@@ -77,7 +94,8 @@ private:
 extern "C" {
 // C entry point of CrawlWaveFiles for callers without C++ (bench.py, tests): file images in memory.  The process keeps
 // one TCrawler per (devices, geometry) between calls (afec_crawl_release drops them), so a second crawl starts warm.
-// stats: [files, failed, frames, pcm_bytes, result_bytes, seconds, writer_seconds, batches, files on device 0, 1, ...];
+// stats: [files, failed, frames, pcm_bytes, result_bytes, seconds, writer_seconds, batches, files on device 0, 1, ...,
+// cpu_seconds, files skipped for their sampling rate] (8 + n_devices + 2 doubles);
 // returns 0, or -1 with the message in error.
 int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
                            const int32_t* devices, int32_t n_devices, int32_t workers_per_device, int32_t files_per_batch,

@@ -27,6 +27,8 @@ TSampleAnalyser::TSampleAnalyser(int SampleRate, int FftFrameSize, int HopFrameS
 
 TSampleAnalyser::~TSampleAnalyser() { afx_plan_destroy(mpPlan); }
 
+void TSampleAnalyser::SetSleepingWaits(bool Sleeping) { afx_plan_set_blocking_wait(mpPlan, Sleeping ? 1 : 0); }
+
 int64_t TSampleAnalyser::NumberOfFrames(int64_t NumberOfSamples) const { return afx_num_frames(mpPlan, NumberOfSamples); }
 
 namespace {
@@ -325,7 +327,8 @@ bool TSampleAnalyser::AnalyzeToRecords(const std::vector<TDecodedSample>& Files,
   Result = TRecordBatch();
   afx_batch_record_layout(Batch.mpBatch, &Result.mStride, Result.mOffsets, Result.mWidths);
   const size_t Frames = (size_t)afx_batch_total_frames(Batch.mpBatch);
-  if (Frames * (size_t)Result.mStride > RecordCapacity || Result.mStride > kMaxStride) return false;
+  if (Result.mStride > kMaxStride) throw TReadableException("AnalyzeToRecords: record stride exceeds kMaxStride");   // larger buffers would not help
+  if (Frames * (size_t)Result.mStride > RecordCapacity) return false;
   Result.mRhythmOffset.resize((size_t)n + 1);
   const size_t RhythmRows = (size_t)afx_batch_rhythm_frames(Batch.mpBatch, Result.mRhythmOffset.data());
   if (RhythmRows * 2 + (size_t)n * (AFX_NUM_RHYTHM_SCALARS + 2 * AFX_NUM_STATISTICS) > RhythmCapacity) return false;

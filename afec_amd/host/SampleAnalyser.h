@@ -117,6 +117,10 @@ public:
   TSampleAnalyser(const TSampleAnalyser&) = delete;
   TSampleAnalyser& operator=(const TSampleAnalyser&) = delete;
 
+  // how the host threads of this analyser's batches wait for the device: sleeping between polls (true) or spinning
+  // (the HIP runtime's default); afx_plan_set_blocking_wait
+  void SetSleepingWaits(bool Sleeping);
+
   // frames the loop yields for a normalised buffer (SampleAnalyser.cpp:760-764, 814)
   int64_t NumberOfFrames(int64_t NumberOfSamples) const;
 

@@ -66,7 +66,7 @@ void TWaveFile::Parse() {
       continue;
     }
     const size_t Next = c.mOffset + c.mSize + (c.mSize & 1);
-    if (Next > Position && Next + 8 < mSize) Position = Next;
+    if (Next > c.mOffset && Next + 8 < mSize) Position = Next;   // RiffFile.cpp:206: against the position behind the header, so an empty chunk ends the walk
     else break;
   }
   auto Find = [&](const char* pName) -> const TChunk* {
@@ -87,6 +87,7 @@ void TWaveFile::Parse() {
   const bool BitsOk = BitsPerSample == 8 || BitsPerSample == 16 || BitsPerSample == 24 || BitsPerSample == 32 || BitsPerSample == 64;
   if (!TagOk || !BitsOk || AvgBytesPerSec != (uint32_t)((uint64_t)Channels * SampleRate * BitsPerSample / 8))
     throw TReadableException("Unsupported file format.");
+  if (SampleRate == 0) throw TReadableException("Unsupported file format.");   // (the byte-rate check passes for 0 == 0)
 
   // WaveFile.cpp:398-405
   const uint32_t FrameBytes = (uint32_t)Channels * (BitsPerSample / 8);

@@ -52,7 +52,7 @@ def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, data
     c_images = (ctypes.c_void_p * n)(*[k.ctypes.data for k in keep])
     c_sizes = (ctypes.c_int64 * n)(*[len(b) for b in images])
     c_dev = (ctypes.c_int32 * len(devices))(*devices)
-    stats = (ctypes.c_double * (8 + len(devices)))()
+    stats = (ctypes.c_double * (10 + len(devices)))()
     err = ctypes.create_string_buffer(512)
     rc = L.afec_crawl_wave_images(c_names, c_images, c_sizes, n, c_dev, len(devices), workers, files_per_batch,
                                   database.encode() if database else None, stats, err, 512)
@@ -60,7 +60,9 @@ def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, data
         raise RuntimeError(err.value.decode())
     keys = ["files", "failed", "frames", "pcm_bytes", "result_bytes", "seconds", "writer_seconds", "batches"]
     out = dict(zip(keys, list(stats)[:8]))
-    out["files_per_device"] = [int(v) for v in list(stats)[8:]]
+    out["files_per_device"] = [int(v) for v in list(stats)[8:8 + len(devices)]]
+    out["cpu_seconds"] = stats[8 + len(devices)]   # process CPU time during the crawl: / seconds = busy CPUs
+    out["skipped_sample_rate"] = int(stats[9 + len(devices)])   # files at another rate than the analyser's (not resampled here)
     return out
 
 

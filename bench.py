@@ -21,6 +21,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The end-to-end leg is a pipeline with eight batches in flight: it wants 16 hardware queues (afec::TCrawler asks for
+# them itself, TCrawlOptions::mHardwareQueues, but the HIP runtime reads the variable at its first call, which in this
+# script is the headline plan's).  The headline measurement uses one stream and does not depend on it.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np  # noqa: E402
 
 import afec_amd as afx  # noqa: E402  (loads nothing GPU-side until a Plan is created)

@@ -122,10 +122,10 @@ typedef struct {
  * (for profiles: per-kernel durations are then not inflated by overlap; results are identical).
  * AFX_TIMING (any value, read when the library is loaded): wall time of the phases of afx_batch_create_from_raw, summed
  * over calls, printed to stderr when the process ends -- a diagnostic for pipelines, no effect on results.
- * GPU_MAX_HW_QUEUES (the HIP runtime's own variable: hardware queues its streams are multiplexed onto, 4 by default):
- * when it is unset the library sets it to 16 as it is loaded, so that the streams of six to eight batches in flight do
- * not serialise on shared queues (more than the device's hardware queue slots, about 20, would be time-sliced); this
- * takes effect when the library is loaded before the process' first HIP call. */
+ * The library does not touch the process' environment.  A pipeline that keeps several batches in flight per device
+ * wants GPU_MAX_HW_QUEUES=16 (the HIP runtime's own variable: hardware queues its streams are multiplexed onto, 4 by
+ * default; read when the runtime initialises): set it before the process' first HIP call, as afec::TCrawler does
+ * (TCrawlOptions::mHardwareQueues).  More than the device's hardware queue slots (about 20) would be time-sliced. */
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan);
 void afx_plan_destroy(afx_plan* plan);
 
@@ -345,12 +345,13 @@ int afx_batch_fetch_onset_functions(afx_batch* batch, float* odf);
 void* afx_host_alloc(int64_t bytes);
 void afx_host_free(void* p);
 
-/* How host threads wait for the device in afx_batch_create_from_raw, afx_batch_fetch_records and afx_batch_fetch_rhythm:
- * spinning (the HIP runtime's default: lowest latency, one busy CPU per waiting thread) or, with blocking != 0, sleeping
- * between polls of an event (20 us naps).  A pipeline with several batches in flight per device wants the latter:
- * the streaming driver of afec_amd/host keeps eight worker threads per GPU and reaches the same 270 k files/s with about
- * 3 instead of 7 busy CPUs.  Process-wide; applies to the batch workspaces created after the call. */
-void afx_set_blocking_wait(int32_t blocking);
+/* How host threads wait for the device in afx_batch_create_from_raw, afx_batch_fetch_records and afx_batch_fetch_rhythm
+ * of this plan's batches: spinning (the HIP runtime's default: lowest latency, one busy CPU per waiting thread) or, with
+ * blocking != 0, sleeping between polls of an event (20 us naps).  A pipeline with several batches in flight per device
+ * wants the latter: the streaming driver of afec_amd/host keeps eight worker threads per GPU and reaches the same
+ * 270 k files/s with about 3 instead of 7 busy CPUs (TCrawlOptions::mSleepingWaits).  Per plan; applies to the batches
+ * created after the call.  (ABI 3 had a process-wide afx_set_blocking_wait instead.) */
+int afx_plan_set_blocking_wait(afx_plan* plan, int32_t blocking);
 
 /* static facts for roofline accounting (bytes the algorithm must move per frame for `mask`) */
 int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int32_t pcm_dtype);

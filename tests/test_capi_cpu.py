@@ -84,15 +84,16 @@ def test_unsupported_geometry_is_rejected_before_touching_the_device(lib):
     assert ei.value.status == -1
 
 
-def test_library_raises_the_hardware_queue_limit_only_when_the_process_has_not_chosen():
-    """libafx_hip.so sets GPU_MAX_HW_QUEUES=16 as it is loaded (include/afx.h, environment notes) unless the variable is
-    already set -- checked in fresh processes through libc's getenv (os.environ does not see setenv from C)."""
+def test_loading_the_library_leaves_the_environment_alone():
+    """libafx_hip.so changes nothing process-wide when it is loaded: GPU_MAX_HW_QUEUES stays unset (the hardware-queue
+    wish is afec::TCrawler's, TCrawlOptions::mHardwareQueues) -- checked in a fresh process through libc's getenv
+    (os.environ does not see setenv from C)."""
     import subprocess
     import sys
     so = os.path.join(os.path.dirname(afec_amd.__file__), "lib", "libafx_hip.so")
     code = ("import ctypes, sys; ctypes.CDLL(sys.argv[1]); c = ctypes.CDLL(None); c.getenv.restype = ctypes.c_char_p; "
-            "print(c.getenv(b'GPU_MAX_HW_QUEUES').decode())")
+            "v = c.getenv(b'GPU_MAX_HW_QUEUES'); print('unset' if v is None else v.decode())")
     env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
-    assert subprocess.check_output([sys.executable, "-c", code, so], env=env).decode().strip() == "16"
+    assert subprocess.check_output([sys.executable, "-c", code, so], env=env).decode().strip() == "unset"
     env["GPU_MAX_HW_QUEUES"] = "4"
     assert subprocess.check_output([sys.executable, "-c", code, so], env=env).decode().strip() == "4"

@@ -146,3 +146,40 @@ def test_pads_are_zero_in_a_reused_workspace():
             row += nf
         batch.close()
     plan.close()
+
+
+def test_upload_reads_only_the_callers_bytes():
+    """A single buffer (or buffers that lie back to back) goes to the device in one transfer; that transfer must end
+    with the last file's last sample, not at the 16-byte slot behind it: here the samples end at the last byte of a
+    mapping whose next page is inaccessible (a file image, an mmap-backed array)."""
+    import ctypes
+    import mmap
+    page = mmap.PAGESIZE
+    m = mmap.mmap(-1, 4 * page)
+    base = ctypes.addressof(ctypes.c_char.from_buffer(m))
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    assert libc.mprotect(base + 3 * page, page, 0) == 0          # PROT_NONE behind the data
+    n = (3 * page - 6) // 2                                      # an odd number of samples: the slot rounds up by 6 bytes... and more
+    n -= 1                                                       # ends 2 bytes... keep it not a multiple of 16
+    view = np.frombuffer(m, dtype=np.int16, count=3 * page // 2)
+    rng = np.random.default_rng(3)
+    x = np.round(8000 * np.sin(2 * np.pi * 440 * np.arange(n) / 44100) + rng.uniform(-200, 200, n)).astype(np.int16)
+    tail = view[view.size - n:]                                  # the last n samples of the accessible pages
+    tail[:] = x
+    assert (tail.ctypes.data + 2 * n) == base + 3 * page and (2 * n) % 16 != 0
+    plan = afx.Plan(device=0)
+    try:
+        batch, infos = plan.batch_from_raw([(tail, 1)], afx.D_MFCC)
+        batch.run()
+        got = batch.fetch()["mfcc"]
+        batch.close()
+        b2, _ = plan.batch_from_raw([(x.copy(), 1)], afx.D_MFCC)
+        b2.run()
+        want = b2.fetch()["mfcc"]
+        b2.close()
+        np.testing.assert_array_equal(got, want)
+    finally:
+        plan.close()
+        del view, tail
+        libc.mprotect(base + 3 * page, page, 3)

@@ -48,6 +48,11 @@ def test_files_the_reference_rejects():
         (ok[:28] + struct.pack("<I", 12345) + ok[32:], "Unsupported file format."),    # AvgBytesPerSec does not match
         # an empty data chunk at the very end is not even visited by the chunk walk (RiffFile.cpp:206-207: strict <)
         (wav_bytes(np.zeros(0, np.int16), 1, 16), "Not a valid WAV file."),
+        # an empty chunk in front of `data` ends the chunk walk there (RiffFile.cpp:206: the next header must lie behind
+        # the position after this one), so `data` is never found
+        (ok[:36] + b"JUNK" + struct.pack("<I", 0) + ok[36:], "Not a valid WAV file."),
+        # a sampling rate of 0 (the byte-rate check alone would pass: 0 == 0)
+        (ok[:24] + struct.pack("<II", 0, 0) + ok[32:], "Unsupported file format."),
         # a data chunk shorter than one sample frame
         (wav_bytes(np.zeros(3, np.uint8), 2, 16)[:36] + b"data" + struct.pack("<I", 3) + b"\x00\x00\x00\x00", "Unsupported file format or corrupt file."),
     ]:

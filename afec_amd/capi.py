@@ -130,6 +130,11 @@ class _StatsOut(ctypes.Structure):
     _fields_ = [(n, ctypes.c_void_p) for n, _ in OUT_FIELDS if n != "magnitude"] + [("stats_status", ctypes.c_void_p)]
 
 
+def build_info():
+    """afx_build_info() of the loaded library: "afx abi=N arch=gfx950 stamps=0 ablation=0 src=<hash of its sources>"."""
+    return load_library().afx_build_info().decode()
+
+
 def library_path():
     return _LIB_PATH
 

@@ -576,7 +576,10 @@ const char* afx_build_info(void) {
 #define AFX_INFO_STAMPS "0"
 #endif
 #define AFX_INFO_ABL "0"   /* the ablation switches of round 1 are gone from the sources */
-  return "afx abi=" "4" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL;
+#ifndef AFX_SRC_HASH
+#define AFX_SRC_HASH "unknown"
+#endif
+  return "afx abi=" "4" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL " src=" AFX_SRC_HASH;
 }
 
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {

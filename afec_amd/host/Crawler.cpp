@@ -340,6 +340,13 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
     while (std::unique_ptr<TFinishedBatch> p = Queue.Pop()) {
       const double t0 = Now();
       int64_t Failed = 0, Skipped = 0;
+      try {
+        if (pPool) pPool->BeginTransaction();     // one commit per batch of files; the rows are those of one commit per file
+      } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> Lock(StatMutex);
+        if (FirstError.empty()) FirstError = e.what();
+        Abort = true;
+      }
       for (size_t i = 0; i < p->mFiles.size(); ++i) {
         const TCrawlFile& f = *p->mFiles[i];
         try {
@@ -358,6 +365,13 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
           if (FirstError.empty()) FirstError = e.what();
           Abort = true;
         }
+      }
+      try {
+        if (pPool) pPool->CommitTransaction();
+      } catch (const std::exception& e) {
+        std::lock_guard<std::mutex> Lock(StatMutex);
+        if (FirstError.empty()) FirstError = e.what();
+        Abort = true;
       }
       Pool.Release(std::move(p->mpRecords));
       StatisticsPool.Release(std::move(p->mpStatistics));

@@ -49,5 +49,9 @@ std::vector<uint8_t> ToMsgpack(const double* pValues, size_t Rows, size_t Width)
 // pInfo adds analyzation_offset_R (SampleAnalyser.cpp:748-749)
 std::vector<TColumn> LowLevelColumns(const TSampleDescriptors& Descriptors, const TSampleDataInfo* pInfo = nullptr,
                                      int SampleRate = 44100);
+// the same into a vector kept between files: the names are built on the first call only, later calls overwrite the
+// values and re-pack the BLOBs in place (what the database writer's per-file cost consists of)
+void RefillLowLevelColumns(std::vector<TColumn>& Columns, const TSampleDescriptors& Descriptors,
+                           const TSampleDataInfo* pInfo = nullptr, int SampleRate = 44100);
 
 }  // namespace afec

@@ -5,7 +5,7 @@
 #include <unistd.h>
 
 #include <cstdlib>
-#include <map>
+#include <unordered_map>
 
 namespace afec {
 
@@ -24,6 +24,8 @@ struct TSqliteApi {
   int (*bind_blob)(void*, int, const void*, int, void (*)(void*)) = nullptr;
   int (*bind_null)(void*, int) = nullptr;
   int (*step)(void*) = nullptr;
+  int (*reset)(void*) = nullptr;
+  int (*clear_bindings)(void*) = nullptr;
   int (*finalize)(void*) = nullptr;
   const char* (*errmsg)(void*) = nullptr;
 };
@@ -42,6 +44,19 @@ struct TSqliteSampleDescriptorPool::TImpl {
   TSqliteApi mApi;
   void* mpDatabase = nullptr;
   std::vector<TColumnSpec> mSchema;
+  // One INSERT statement for analysed files and one for failed ones, prepared when first needed and kept for the
+  // pool's life; every schema column's source resolved once: a value of LowLevelColumns (by position), a file
+  // property, or the placeholder of its type.  (Per file the writer used to rebuild the 461-placeholder SQL text,
+  // prepare it, and look every column up by name.)
+  void* mpInsert = nullptr;
+  void* mpInsertFailed = nullptr;
+  enum TSource { kValue, kFileType, kFileSize, kFileLength, kFileSampleRate, kFileChannelCount, kFileBitDepth,
+                 kEmptyBlob, kZeroReal, kEmptyText };
+  struct TBinding { TSource mSource; int mValueIndex; };
+  std::vector<TBinding> mBindings;      // per schema column
+  size_t mBoundColumnCount = 0;         // LowLevelColumns' size the bindings were resolved for
+  std::vector<TColumn> mValues;         // refilled per file (names and BLOB capacity persist)
+  bool mInTransaction = false;          // BeginTransaction .. CommitTransaction of the caller
 
   void Check(int Result, const char* pWhat) {
     if (Result != kSqliteOk && Result != kSqliteDone)
@@ -78,6 +93,8 @@ TSqliteSampleDescriptorPool::TSqliteSampleDescriptorPool(const std::string& Data
     Resolve(A.mpLibrary, "sqlite3_bind_blob", A.bind_blob);
     Resolve(A.mpLibrary, "sqlite3_bind_null", A.bind_null);
     Resolve(A.mpLibrary, "sqlite3_step", A.step);
+    Resolve(A.mpLibrary, "sqlite3_reset", A.reset);
+    Resolve(A.mpLibrary, "sqlite3_clear_bindings", A.clear_bindings);
     Resolve(A.mpLibrary, "sqlite3_finalize", A.finalize);
     Resolve(A.mpLibrary, "sqlite3_errmsg", A.errmsg);
     mpImpl->Check(A.open(DatabasePath.c_str(), &mpImpl->mpDatabase), "sqlite3_open");
@@ -125,66 +142,108 @@ TSqliteSampleDescriptorPool::TSqliteSampleDescriptorPool(const std::string& Data
 }
 
 TSqliteSampleDescriptorPool::~TSqliteSampleDescriptorPool() {
+  if (mpImpl->mInTransaction) mpImpl->mApi.exec(mpImpl->mpDatabase, "ROLLBACK", nullptr, nullptr, nullptr);
+  if (mpImpl->mpInsert) mpImpl->mApi.finalize(mpImpl->mpInsert);
+  if (mpImpl->mpInsertFailed) mpImpl->mApi.finalize(mpImpl->mpInsertFailed);
   mpImpl->mApi.close(mpImpl->mpDatabase);
   dlclose(mpImpl->mApi.mpLibrary);
   delete mpImpl;
+}
+
+void TSqliteSampleDescriptorPool::BeginTransaction() {
+  if (mpImpl->mInTransaction) return;
+  mpImpl->Execute("BEGIN");
+  mpImpl->mInTransaction = true;
+}
+
+void TSqliteSampleDescriptorPool::CommitTransaction() {
+  if (!mpImpl->mInTransaction) return;
+  mpImpl->mInTransaction = false;
+  mpImpl->Execute("COMMIT");
 }
 
 void TSqliteSampleDescriptorPool::InsertSample(const std::string& FileName, int ModificationTime,
                                                const TFileProperties& File, const TSampleDescriptors& Results,
                                                const TSampleDataInfo* pInfo) {
   TImpl& I = *mpImpl;
-  const std::vector<TColumn> Values = LowLevelColumns(Results, pInfo);
-  std::map<std::string, const TColumn*> ByName;
-  for (const TColumn& c : Values) ByName[c.mName] = &c;
-
-  // SqliteSampleDescriptorPool.cpp:1591-1640: all keys, INSERT OR REPLACE, one transaction per file
-  std::string Sql = "INSERT OR REPLACE into assets(filename,modtime,status";
-  for (const TColumnSpec& c : I.mSchema) Sql += "," + c.mName;
-  Sql += ") values(?,?,?";
-  for (size_t i = 0; i < I.mSchema.size(); ++i) Sql += ",?";
-  Sql += ")";
-  I.Execute("BEGIN");
-  void* pStatement = nullptr;
-  try {
-    I.Check(I.mApi.prepare_v2(I.mpDatabase, Sql.c_str(), -1, &pStatement, nullptr), "prepare");
-    I.Check(I.mApi.bind_text(pStatement, 1, FileName.c_str(), -1, kSqliteTransient), "bind filename");
-    I.Check(I.mApi.bind_int(pStatement, 2, ModificationTime), "bind modtime");
-    I.Check(I.mApi.bind_text(pStatement, 3, "succeeded", -1, kSqliteTransient), "bind status");
-    int Index = 4;
+  RefillLowLevelColumns(I.mValues, Results, pInfo);
+  if (!I.mpInsert) {
+    // SqliteSampleDescriptorPool.cpp:1591-1640: all keys, INSERT OR REPLACE
+    std::string Sql = "INSERT OR REPLACE into assets(filename,modtime,status";
+    for (const TColumnSpec& c : I.mSchema) Sql += "," + c.mName;
+    Sql += ") values(?,?,?";
+    for (size_t i = 0; i < I.mSchema.size(); ++i) Sql += ",?";
+    Sql += ")";
+    I.Check(I.mApi.prepare_v2(I.mpDatabase, Sql.c_str(), -1, &I.mpInsert, nullptr), "prepare");
+  }
+  if (I.mBoundColumnCount != I.mValues.size()) {
+    std::unordered_map<std::string, int> ByName;
+    for (size_t i = 0; i < I.mValues.size(); ++i) ByName[I.mValues[i].mName] = (int)i;
+    I.mBindings.clear();
     for (const TColumnSpec& c : I.mSchema) {
-      int r = kSqliteOk;
       const auto Found = ByName.find(c.mName);
-      if (Found != ByName.end()) {
-        const TColumn& v = *Found->second;
-        r = (v.mType == TColumn::kReal) ? I.mApi.bind_double(pStatement, Index, v.mReal)
-                                        : I.mApi.bind_blob(pStatement, Index, v.mBlob.data(), (int)v.mBlob.size(), kSqliteTransient);
-      } else if (c.mName == "file_type_S") r = I.mApi.bind_text(pStatement, Index, File.mFileType.c_str(), -1, kSqliteTransient);
-      else if (c.mName == "file_size_R") r = I.mApi.bind_int(pStatement, Index, File.mFileSize);
-      else if (c.mName == "file_length_R") r = I.mApi.bind_double(pStatement, Index, File.mFileLength);
-      else if (c.mName == "file_sample_rate_R") r = I.mApi.bind_int(pStatement, Index, File.mFileSampleRate);
-      else if (c.mName == "file_channel_count_R") r = I.mApi.bind_int(pStatement, Index, File.mFileChannelCount);
-      else if (c.mName == "file_bit_depth_R") r = I.mApi.bind_int(pStatement, Index, File.mFileBitDepth);
+      TImpl::TBinding b{TImpl::kEmptyText, -1};
+      if (Found != ByName.end()) b = {TImpl::kValue, Found->second};
+      else if (c.mName == "file_type_S") b.mSource = TImpl::kFileType;
+      else if (c.mName == "file_size_R") b.mSource = TImpl::kFileSize;
+      else if (c.mName == "file_length_R") b.mSource = TImpl::kFileLength;
+      else if (c.mName == "file_sample_rate_R") b.mSource = TImpl::kFileSampleRate;
+      else if (c.mName == "file_channel_count_R") b.mSource = TImpl::kFileChannelCount;
+      else if (c.mName == "file_bit_depth_R") b.mSource = TImpl::kFileBitDepth;
       else {
         // a descriptor this library does not compute: a well-formed placeholder, because the reference's reader
         // unpacks every BLOB column of a "succeeded" row (SqliteSampleDescriptorPool.cpp:1004-1014): an empty
         // msgpack array for the vectors, 0 for the scalars
-        static const unsigned char kEmptyMsgpackArray[1] = {0x90};
         const std::string Type = c.mpSqliteType;
-        if (Type == "BLOB") r = I.mApi.bind_blob(pStatement, Index, kEmptyMsgpackArray, 1, kSqliteTransient);
-        else if (Type == "REAL") r = I.mApi.bind_double(pStatement, Index, 0.0);
-        else r = I.mApi.bind_text(pStatement, Index, "", -1, kSqliteTransient);
+        b.mSource = (Type == "BLOB") ? TImpl::kEmptyBlob : ((Type == "REAL") ? TImpl::kZeroReal : TImpl::kEmptyText);
       }
-      I.Check(r, c.mName.c_str());
+      I.mBindings.push_back(b);
+    }
+    I.mBoundColumnCount = I.mValues.size();
+  }
+  // one transaction per file (SqliteSampleDescriptorPool.cpp:1591-1640) unless the caller has opened one around a
+  // batch of files: the rows are the same either way
+  const bool OwnTransaction = !I.mInTransaction;
+  if (OwnTransaction) I.Execute("BEGIN");
+  void* const pStatement = I.mpInsert;
+  try {
+    // SQLITE_STATIC (nullptr) for everything that outlives the step: no copies inside sqlite
+    I.Check(I.mApi.bind_text(pStatement, 1, FileName.c_str(), (int)FileName.size(), nullptr), "bind filename");
+    I.Check(I.mApi.bind_int(pStatement, 2, ModificationTime), "bind modtime");
+    I.Check(I.mApi.bind_text(pStatement, 3, "succeeded", 9, nullptr), "bind status");
+    static const unsigned char kEmptyMsgpackArray[1] = {0x90};
+    int Index = 4;
+    for (const TImpl::TBinding& b : I.mBindings) {
+      int r = kSqliteOk;
+      switch (b.mSource) {
+        case TImpl::kValue: {
+          const TColumn& v = I.mValues[(size_t)b.mValueIndex];
+          r = (v.mType == TColumn::kReal) ? I.mApi.bind_double(pStatement, Index, v.mReal)
+                                          : I.mApi.bind_blob(pStatement, Index, v.mBlob.data(), (int)v.mBlob.size(), nullptr);
+          break;
+        }
+        case TImpl::kFileType: r = I.mApi.bind_text(pStatement, Index, File.mFileType.c_str(), (int)File.mFileType.size(), nullptr); break;
+        case TImpl::kFileSize: r = I.mApi.bind_int(pStatement, Index, File.mFileSize); break;
+        case TImpl::kFileLength: r = I.mApi.bind_double(pStatement, Index, File.mFileLength); break;
+        case TImpl::kFileSampleRate: r = I.mApi.bind_int(pStatement, Index, File.mFileSampleRate); break;
+        case TImpl::kFileChannelCount: r = I.mApi.bind_int(pStatement, Index, File.mFileChannelCount); break;
+        case TImpl::kFileBitDepth: r = I.mApi.bind_int(pStatement, Index, File.mFileBitDepth); break;
+        case TImpl::kEmptyBlob: r = I.mApi.bind_blob(pStatement, Index, kEmptyMsgpackArray, 1, nullptr); break;
+        case TImpl::kZeroReal: r = I.mApi.bind_double(pStatement, Index, 0.0); break;
+        case TImpl::kEmptyText: r = I.mApi.bind_text(pStatement, Index, "", 0, nullptr); break;
+      }
+      I.Check(r, "bind");
       ++Index;
     }
     I.Check(I.mApi.step(pStatement), "insert");
-    I.mApi.finalize(pStatement);
-    pStatement = nullptr;
-    I.Execute("COMMIT");
+    I.mApi.reset(pStatement);
+    I.mApi.clear_bindings(pStatement);
+    if (OwnTransaction) I.Execute("COMMIT");
   } catch (...) {
-    if (pStatement) I.mApi.finalize(pStatement);
+    I.mApi.reset(pStatement);
+    I.mApi.clear_bindings(pStatement);
     I.mApi.exec(I.mpDatabase, "ROLLBACK", nullptr, nullptr, nullptr);
+    I.mInTransaction = false;
     throw;
   }
 }
@@ -193,22 +252,26 @@ void TSqliteSampleDescriptorPool::InsertFailedSample(const std::string& FileName
                                                      const std::string& Reason) {
   TImpl& I = *mpImpl;
   // SqliteSampleDescriptorPool.cpp:1655-1690
-  I.Execute("BEGIN");
-  void* pStatement = nullptr;
-  try {
+  if (!I.mpInsertFailed)
     I.Check(I.mApi.prepare_v2(I.mpDatabase, "INSERT OR REPLACE into assets(filename, modtime, status) values (?,?,?)", -1,
-                              &pStatement, nullptr), "prepare");
+                              &I.mpInsertFailed, nullptr), "prepare");
+  const bool OwnTransaction = !I.mInTransaction;
+  if (OwnTransaction) I.Execute("BEGIN");
+  void* const pStatement = I.mpInsertFailed;
+  try {
     const std::string Status = "error: " + Reason;
-    I.Check(I.mApi.bind_text(pStatement, 1, FileName.c_str(), -1, kSqliteTransient), "bind filename");
+    I.Check(I.mApi.bind_text(pStatement, 1, FileName.c_str(), (int)FileName.size(), nullptr), "bind filename");
     I.Check(I.mApi.bind_int(pStatement, 2, ModificationTime), "bind modtime");
-    I.Check(I.mApi.bind_text(pStatement, 3, Status.c_str(), -1, kSqliteTransient), "bind status");
+    I.Check(I.mApi.bind_text(pStatement, 3, Status.c_str(), (int)Status.size(), nullptr), "bind status");
     I.Check(I.mApi.step(pStatement), "insert");
-    I.mApi.finalize(pStatement);
-    pStatement = nullptr;
-    I.Execute("COMMIT");
+    I.mApi.reset(pStatement);
+    I.mApi.clear_bindings(pStatement);
+    if (OwnTransaction) I.Execute("COMMIT");
   } catch (...) {
-    if (pStatement) I.mApi.finalize(pStatement);
+    I.mApi.reset(pStatement);
+    I.mApi.clear_bindings(pStatement);
     I.mApi.exec(I.mpDatabase, "ROLLBACK", nullptr, nullptr, nullptr);
+    I.mInTransaction = false;
     throw;
   }
 }

@@ -30,7 +30,14 @@ public:
   TSqliteSampleDescriptorPool(const TSqliteSampleDescriptorPool&) = delete;
   TSqliteSampleDescriptorPool& operator=(const TSqliteSampleDescriptorPool&) = delete;
 
-  // INSERT OR REPLACE of one analysed file in its own transaction, status "succeeded"
+  // A caller that inserts many files in a row may put them into one transaction (the crawler's writer: one per batch
+  // of files): the rows are identical, the commits (journal + fsync) are not paid per file.  Without these calls every
+  // insert is its own transaction like the reference's (SqliteSampleDescriptorPool.cpp:1591-1640, 1655-1690).  A
+  // failing insert rolls the open transaction back and throws.
+  void BeginTransaction();
+  void CommitTransaction();
+
+  // INSERT OR REPLACE of one analysed file (in its own transaction unless one is open), status "succeeded"
   void InsertSample(const std::string& FileName, int ModificationTime, const TFileProperties& File,
                     const TSampleDescriptors& Results, const TSampleDataInfo* pInfo = nullptr);
   // the row of a file that could not be analysed: status "error: <Reason>", every descriptor NULL

@@ -245,9 +245,20 @@ def kernel_profile(precision, mask_name, workload):
         return None
     try:
         key = (f"{workload}_everything" if mask_name == "everything" else workload) if workload != "c2" else f"{mask_name}_{precision}"
-        return json.load(open(p)).get(key)
+        all_profiles = json.load(open(p))
+        prof = all_profiles.get(key)
     except Exception:
         return None
+    if prof is None:
+        return None
+    # counters belong to the build they were measured on: afx_build_info() carries a hash of the library's sources
+    measured_on, loaded = all_profiles.get("_build_info"), afx.build_info()
+    if measured_on != loaded:
+        print(f"warning: profiles/kernel_profiles.json was measured on [{measured_on}], the loaded library is [{loaded}]: "
+              f"roofline.traffic / roofline.valu are not quoted (re-run tools/profile_config.py + tools/make_kernel_profiles.py)",
+              file=sys.stderr)
+        return {"stale": True, "measured_on": measured_on}
+    return prof
 
 
 def secondary_rate(plan, mask, buffers, steps=5):
@@ -367,14 +378,28 @@ def main():
                    "upload_GB_per_s": st["pcm_bytes"] / st["seconds"] / 1e9, "download_GB_per_s": st["result_bytes"] / st["seconds"] / 1e9,
                    # 55 GB/s: one page-locked upload stream on this host link (tools/link_rate.py, profiles/r02/README.md)
                    "upload_frac_of_host_link": st["pcm_bytes"] / st["seconds"] / 55e9,
+                   "busy_host_cpus": st["cpu_seconds"] / st["seconds"],
                    "workers": 8, "files_per_batch": 512}
+            # the same crawl with the single writer inserting every file into the reference's sqlite `assets` table
+            # (461 columns, ~68 KB of msgpack per one-second file; one transaction per batch of 512 files), database on
+            # tmpfs: the writer, not the GPU, bounds it
+            import tempfile
+            shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+            with tempfile.TemporaryDirectory(dir=shm) as td:
+                sd = end_to_end("c4", 4096, device, 8, 99, database=os.path.join(td, "afec-ll.db"), repeats=2, files_per_batch=512)
+                e2e["files_per_s_with_database"] = sd["files"] / sd["seconds"]
+                e2e["database_writer_files_per_s"] = sd["files"] / sd["writer_seconds"] if sd["writer_seconds"] else None
+                e2e["database"] = "sqlite `assets` table on tmpfs, 4096 files, best of 2 (INSERT OR REPLACE into the same file)"
         except Exception as e:  # noqa: BLE001  (the headline must not depend on the host library)
-            e2e = {"error": str(e)}
+            e2e = dict(e2e or {}, error=str(e))
 
     if rank == 0:
         launch_ms = ev_ms / args.steps
         achieved = bytes_per_frame * frames / (launch_ms * 1e-3) / 1e9
         prof = kernel_profile(args.precision, args.mask, args.workload)
+        stale_profile = prof if (prof and prof.get("stale")) else None
+        if stale_profile:
+            prof = None
         valu = None
         if prof and prof.get("valu_cycles_per_frame"):
             # f64 VALU ceiling of this instruction mix: 4 SIMDs x 256 CUs x clock / pipe cycles per frame
@@ -414,10 +439,15 @@ def main():
                 "pcm": "f32 resident in HBM" if pcm_kind == afx.PCM_F32 else "f64 (LoadSample output) resident in HBM",
                 "parallelism": f"replicas x{world} (buffers sharded, no collective)",
             },
-            # "bound": the roofline the path is priced against (a streaming scan of PCM: HBM).  What the
-            # counters say actually limits these f64 kernels is in "limiter" / "valu": the vector ALU, not HBM.
+            # achieved / peak / frac / traffic: the HBM roofline the path is priced against (a streaming scan of PCM,
+            # SURVEY 8d), also as the "hbm" object.  "bound": the resource the counters say binds these f64 kernels --
+            # the vector ALU ("valu_f64", with its own ceiling in "valu") -- or "hbm" when no current profile says so.
             "roofline": {
-                "bound": "hbm",
+                "bound": "valu_f64" if valu else "hbm",
+                "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": None if not prof else prof["bytes_per_frame"] * frames},
+                "profile_build": afx.build_info() if prof else None,
+                "profile_stale": stale_profile["measured_on"] if stale_profile else None,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

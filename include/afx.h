@@ -33,7 +33,8 @@ enum {
 };
 const char* afx_status_str(int status);
 const char* afx_last_error(void); /* thread-local detail text of the last failing call */
-/* "afx abi=N arch=gfx950 stamps=0 ablation=0": the shipped library carries no diagnostic / ablation switch */
+/* "afx abi=N arch=gfx950 stamps=0 ablation=0 src=<hash of the library's sources>": the shipped library carries no
+ * diagnostic / ablation switch; the hash ties committed profiler counters to the build they were measured on */
 const char* afx_build_info(void);
 
 /* ---- PCM sample types of afx_buf.dtype ---- */

@@ -8,6 +8,7 @@
 //   host_test analyse   TSampleAnalyser::AnalyzeLowLevelDescriptors vs the oracle (GPU)
 #include <cmath>
 #include <cstdio>
+#include <chrono>
 #include <cstring>
 #include <random>
 #include <vector>
@@ -111,6 +112,54 @@ static int WriteDatabase(const char* pPath) {
   Pool.InsertSample("Kicks/one.wav", 1700000000, File, D, &Info);
   Pool.InsertSample("Kicks/one.wav", 1700000001, File, D, &Info);      // INSERT OR REPLACE: still one row
   Pool.InsertFailedSample("Kicks/broken.wav", 1700000002, "could not decode");
+  // the writer's fast path: several files in one transaction, the column vector refilled in place -- a longer and a
+  // shorter series than the file before (BLOB buffers are reused), without the load info (one column fewer)
+  Pool.BeginTransaction();
+  afec::TSampleDescriptors Long = D, Short = D;
+  Long.mSpectralCentroid.mValues.assign(40, 0.5);
+  Long.mCepstrumBands.mValues.assign(40, std::array<double, 14>{});
+  Short.mSpectralCentroid.mValues.assign(1, 7.0);
+  Short.mCepstrumBands.mValues.clear();
+  Pool.InsertSample("Batch/long.wav", 1700000003, File, Long, &Info);
+  Pool.InsertSample("Batch/short.wav", 1700000004, File, Short, &Info);
+  Pool.InsertFailedSample("Batch/broken.wav", 1700000005, "could not decode");
+  Pool.InsertSample("Batch/noinfo.wav", 1700000006, File, D, nullptr);
+  Pool.InsertSample("Batch/again.wav", 1700000007, File, D, &Info);
+  Pool.CommitTransaction();
+  return 0;
+}
+
+// rows per second of the writer alone (no GPU): argv[2] = database path, argv[3] = rows, argv[4] = rows per transaction
+// (0: one transaction per row, the reference's way)
+static int WriterRate(const char* pPath, int Rows, int PerTransaction) {
+  afec::TSqliteSampleDescriptorPool Pool(pPath);
+  afec::TSampleDescriptors D = SyntheticDescriptors();
+  // a one-second file's worth of frames in every series
+  const size_t Frames = 40;
+  for (afec::TFramedScalarData* p : {&D.mAmplitudeSilence, &D.mAmplitudePeak, &D.mAmplitudeRms, &D.mAmplitudeEnvelope, &D.mSpectralRms,
+                                     &D.mSpectralCentroid, &D.mSpectralRolloff, &D.mSpectralSpread, &D.mSpectralSkewness,
+                                     &D.mSpectralKurtosis, &D.mSpectralFlatness, &D.mSpectralInharmonicity, &D.mSpectralComplexity,
+                                     &D.mSpectralContrast, &D.mSpectralFlux, &D.mF0, &D.mF0Confidence, &D.mFailSafeF0,
+                                     &D.mTristimulus1, &D.mTristimulus2, &D.mTristimulus3, &D.mAutoCorrelation})
+    p->mValues.assign(Frames, 0.125);
+  D.mRhythmComplexOnsets.mValues.assign(340, 0.0);
+  D.mRhythmPercussiveOnsets.mValues.assign(340, 0.0);
+  for (afec::TFramedVectorData<14>* p : {&D.mSpectralRmsBands, &D.mSpectralFlatnessBands, &D.mSpectralFluxBands,
+                                         &D.mSpectralComplexityBands, &D.mSpectralContrastBands, &D.mCepstrumBands})
+    p->mValues.assign(Frames, std::array<double, 14>{});
+  D.mSpectrumBands.mValues.assign(Frames, std::array<double, 28>{});
+  const afec::TSampleDataInfo Info = {0.5f, 0.25f, -2205, 90000};
+  afec::TFileProperties File;
+  File.mFileType = "wav"; File.mFileSize = 176444; File.mFileLength = 1.0; File.mFileSampleRate = 44100;
+  File.mFileChannelCount = 2; File.mFileBitDepth = 16;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int i = 0; i < Rows; ++i) {
+    if (PerTransaction > 0 && i % PerTransaction == 0) Pool.BeginTransaction();
+    Pool.InsertSample("Rate/file" + std::to_string(i) + ".wav", 1700000000 + i, File, D, &Info);
+    if (PerTransaction > 0 && (i % PerTransaction == PerTransaction - 1 || i == Rows - 1)) Pool.CommitTransaction();
+  }
+  const double s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  std::printf("%d rows in %.3f s = %.0f rows/s (%d per transaction)\n", Rows, s, Rows / s, PerTransaction);
   return 0;
 }
 
@@ -253,6 +302,7 @@ int main(int argc, char** argv) {
     if (argc >= 2 && !std::strcmp(argv[1], "nodevice")) rc = TestNoDevice();
     else if (argc >= 3 && !std::strcmp(argv[1], "columns")) rc = DumpColumns(argv[2]);
     else if (argc >= 3 && !std::strcmp(argv[1], "sqlite")) rc = WriteDatabase(argv[2]);
+    else if (argc >= 5 && !std::strcmp(argv[1], "writer_rate")) rc = WriterRate(argv[2], std::atoi(argv[3]), std::atoi(argv[4]));
     else if (argc >= 2 && !std::strcmp(argv[1], "analyse")) rc = TestAnalyse();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());

@@ -169,8 +169,20 @@ def test_descriptor_database_is_the_references_schema(tmp_path):
     assert [(r[1], r[2]) for r in info] == full_schema()
     assert len(info) == 3 + 6 + 4 + 22 * 14 + 2 * (14 + 6) + 2 + 7 * 14          # 461 columns
     assert [r[1] for r in info if r[5]] == ["filename"]                           # PRIMARY KEY
-    rows = con.execute("SELECT filename, modtime, status FROM assets ORDER BY filename").fetchall()
+    rows = con.execute("SELECT filename, modtime, status FROM assets WHERE filename LIKE 'Kicks/%' ORDER BY filename").fetchall()
     assert rows == [("Kicks/broken.wav", 1700000002, "error: could not decode"), ("Kicks/one.wav", 1700000001, "succeeded")]
+    # the rows written inside one transaction through the refilled column vector: each carries its own values
+    batch = {r[0]: r for r in con.execute("SELECT filename, status, spectral_centroid_VR, cepstrum_bands_VVR, analyzation_offset_R, "
+                                          "effectve_length_24dB_R FROM assets WHERE filename LIKE 'Batch/%'")}
+    assert sorted(batch) == ["Batch/again.wav", "Batch/broken.wav", "Batch/long.wav", "Batch/noinfo.wav", "Batch/short.wav"]
+    assert batch["Batch/broken.wav"][1] == "error: could not decode" and batch["Batch/broken.wav"][2] is None
+    assert msgpack.unpackb(batch["Batch/long.wav"][2]) == [0.5] * 40 and len(msgpack.unpackb(batch["Batch/long.wav"][3])) == 40
+    assert msgpack.unpackb(batch["Batch/short.wav"][2]) == [7.0] and msgpack.unpackb(batch["Batch/short.wav"][3]) == []
+    assert msgpack.unpackb(batch["Batch/again.wav"][2]) == column_values(5, 0, 1).tolist()
+    assert msgpack.unpackb(batch["Batch/again.wav"][3]) == column_values(5, 14, 3).tolist()
+    # without the load info the analysis offset is a column this library did not compute: the REAL placeholder
+    assert batch["Batch/noinfo.wav"][4] == 0.0 and batch["Batch/again.wav"][4] != 0.0
+    assert all(batch[k][5] == 1.25 for k in batch if k != "Batch/broken.wav")
     con.row_factory = sqlite3.Row
     ok = con.execute("SELECT * FROM assets WHERE filename = 'Kicks/one.wav'").fetchone()
     assert (ok["file_type_S"], ok["file_size_R"], ok["file_length_R"], ok["file_sample_rate_R"],
@@ -232,8 +244,24 @@ def test_descriptor_database_version_rules(tmp_path):
     out = subprocess.run([BIN, "sqlite", older], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     con = sqlite3.connect(older)
-    assert con.execute("SELECT count(*) FROM assets").fetchone()[0] == 2
+    assert con.execute("SELECT count(*) FROM assets").fetchone()[0] == 7      # INSERT OR REPLACE: the same 7 files
     con.close()
+
+
+def test_writer_rate_probe_runs(tmp_path):
+    """`host_test writer_rate`: the database writer alone (no GPU), rows of a one-second stereo file; the numbers are
+    quoted in DESIGN.md section 7.  Here only that it runs and that batching the commits does not change the rows."""
+    import sqlite3
+    build()
+    dbs = []
+    for per_txn in (0, 16):
+        db = str(tmp_path / f"rate{per_txn}.db")
+        out = subprocess.run([BIN, "writer_rate", db, "40", str(per_txn)], capture_output=True, text=True)
+        assert out.returncode == 0 and "rows/s" in out.stdout, out.stdout + out.stderr
+        con = sqlite3.connect(db)
+        dbs.append(con.execute("SELECT * FROM assets ORDER BY filename").fetchall())
+        con.close()
+    assert len(dbs[0]) == 40 and dbs[0] == dbs[1]
 
 
 @pytest.mark.gpu

@@ -11,11 +11,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r02"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
-CLOCK_GHZ = 1.85   # measured in-kernel (s_memtime / s_memrealtime, stamps build) under the f64 load
-LIMITER = {"c2_f64": "f64 VALU issue (with the CU's LDS at ~70 %)"}
+CLOCK_GHZ = 1.88   # measured in-kernel (s_memtime / s_memrealtime, stamps build) under the f64 load: 1.82-1.90 over boxes
+LIMITER = {"c2_f64": "f64 VALU work under the chip's power limit (clock 1.8-1.9 of 2.4 GHz); LDS ~70 % busy beside it"}
 
 os.makedirs(DST, exist_ok=True)
 out = {"_comment": "Per bench configuration, from rocprofv3 passes on MI355X (tools/profile_config.py; raw summaries "
@@ -23,10 +23,18 @@ out = {"_comment": "Per bench configuration, from rocprofv3 passes on MI355X (to
                    "FETCH_SIZE half-count correction, calibrated for 16-B streaming reads only), VALU pipe cycles per frame = "
                    "4*SQ_ACTIVE_INST_VALU/frames summed over the kernels of one step (rhythm kernels on the batch's own stream: "
                    "AFX_SIDE_STREAM=0), clock = in-kernel s_memtime/s_memrealtime of the stamps build under this load."}
+builds = set()
+for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
+    builds.add(json.load(open(f)).get("build_info"))
+if len(builds) != 1:
+    sys.exit(f"the profiles of {SRC} come from more than one build (or none): {builds}")
+out["_build_info"] = builds.pop()   # afx_build_info() of the library the counters were measured on (bench.py checks it)
 for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
     tag = os.path.basename(f)[len("profile_"):-len(".json")]
     d = json.load(open(f))
-    kernels = sorted(d["kernels"], key=lambda k: -d["kernels"][k].get("ms_per_step", 0.0))
+    # steady-state time per step (warm-up launches dropped, tools/profile_config.py) where the trace gave it
+    ms = {k: v.get("ms_per_step_steady", v.get("ms_per_step", 0.0)) for k, v in d["kernels"].items()}
+    kernels = sorted(d["kernels"], key=lambda k: -ms[k])
     out[tag] = {
         "bytes_per_frame": d["per_frame"]["hbm_bytes"],
         "valu_cycles_per_frame": d["per_frame"]["valu_cycles"],
@@ -35,12 +43,12 @@ for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
         "frames_profiled": d["frames_per_step"],
         "limiter": LIMITER.get(tag, "f64 VALU issue"),
         "kernels": kernels,
-        "kernel_ms_per_step": {k: round(d["kernels"][k].get("ms_per_step", 0.0), 4) for k in kernels},
+        "kernel_ms_per_step": {k: round(ms[k], 4) for k in kernels},
         "dominant_kernel": kernels[0] if kernels else None,
         "source": f"profiles/{ROUND}/profile_{tag}.json",
     }
     shutil.copy(f, DST)
-for pat in ("*_kernel_stats.csv", "*_pmc_summary.csv", "*_pmc.csv", "rhythm_report.md", "parity_report.md", "ubench_*.txt",
+for pat in ("*_kernel_stats.csv", "*_kernel_steady.csv", "*_pmc_summary.csv", "*_pmc.csv", "rhythm_report.md", "parity_report.md", "ubench_*.txt",
             "bench_default.json", "pytest_gpu.log"):
     for f in glob.glob(os.path.join(SRC, pat)):
         shutil.copy(f, DST)

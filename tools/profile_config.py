@@ -20,7 +20,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("AFX_ROUND", "r02")
+ROUND = os.environ.get("AFX_ROUND", "r03")
 STEPS, WARMUP = 10, 2
 
 
@@ -63,6 +63,25 @@ def main():
             k = kernels.setdefault(short(row["Name"]), {})
             k["calls_per_step"] = int(row["Calls"]) / launches
             k["ms_per_step"] = float(row["TotalDurationNs"]) / launches * 1e-6
+    # steady-state durations: the --stats rows mix the warm-up launches (cold caches, clock ramp) with the timed ones;
+    # from the trace itself, per kernel, only the launches behind the first WARMUP steps count
+    trace = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+    if trace:
+        per = collections.defaultdict(list)
+        for row in csv.DictReader(open(trace[0])):
+            if "afx::" in row["Kernel_Name"]:
+                per[short(row["Kernel_Name"])].append((int(row["Start_Timestamp"]), int(row["End_Timestamp"]) - int(row["Start_Timestamp"])))
+        with open(os.path.join(out_dir, f"{tag}_kernel_steady.csv"), "w") as fo:
+            fo.write("kernel,launches_counted,launches_dropped,mean_ns,min_ns,max_ns\n")
+            for name, runs in per.items():
+                runs.sort()
+                per_step = max(1, round(len(runs) / launches))
+                steady = [dur for _, dur in runs[per_step * WARMUP:]]
+                if not steady:
+                    continue
+                k = kernels.setdefault(name, {})
+                k["ms_per_step_steady"] = sum(steady) / (len(steady) / per_step) * 1e-6
+                fo.write(f"{name},{len(steady)},{per_step * WARMUP},{sum(steady) / len(steady):.0f},{min(steady)},{max(steady)}\n")
     passes = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
                       "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"])]
@@ -82,7 +101,10 @@ def main():
     clock = None
     if tot.get("GRBM_GUI_ACTIVE") and tot.get("ms_per_step"):
         clock = tot["GRBM_GUI_ACTIVE"] / 8.0 / (tot["ms_per_step"] * 1e-3) / 1e9   # profiled runs: lower bound of the free-running clock
+    sys.path.insert(0, ROOT)
+    import afec_amd
     summary = {
+        "build_info": afec_amd.build_info(),
         "bench_args": bench_args,
         "frames_per_step": frames,
         "unprofiled_value_frames_per_s": bench["value"],

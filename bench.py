@@ -447,7 +447,7 @@ def main():
                 "hbm": {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": None if not prof else prof["bytes_per_frame"] * frames},
                 "profile_build": afx.build_info() if prof else None,
-                "profile_stale": stale_profile["measured_on"] if stale_profile else None,
+                "profile_stale": (stale_profile["measured_on"] or "a build that recorded no hash") if stale_profile else None,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

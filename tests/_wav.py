@@ -27,3 +27,23 @@ def wav_bytes(data, channels, bits, is_float=False, rate=44100, extra_chunks=Fal
         chunks += b"cue " + struct.pack("<I", 4) + struct.pack("<I", 0)
     body = b"WAVE" + chunks
     return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def parse_wav(image):
+    """Minimal RIFF / WAVE parse for the tests' own use (PCM only): -> (channels, rate, bits, frames, payload bytes).
+    Raises ValueError for anything that is not a PCM WAVE file."""
+    if len(image) < 12 or image[:4] != b"RIFF" or image[8:12] != b"WAVE":
+        raise ValueError("not a RIFF / WAVE image")
+    i, fmt, payload = 12, None, None
+    while i + 8 <= len(image):
+        name, size = image[i:i + 4], struct.unpack("<I", image[i + 4:i + 8])[0]
+        if name == b"fmt ":
+            fmt = struct.unpack("<HHIIHH", image[i + 8:i + 24])
+        elif name == b"data":
+            payload = image[i + 8:i + 8 + size]
+        i += 8 + size + (size & 1)
+    if fmt is None or payload is None or fmt[0] != 1:
+        raise ValueError("no PCM fmt / data chunk")
+    channels, rate, bits = fmt[1], fmt[2], fmt[5]
+    frames = len(payload) // (channels * bits // 8)
+    return channels, rate, bits, frames, payload[:frames * channels * bits // 8]

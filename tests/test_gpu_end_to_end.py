@@ -26,11 +26,49 @@ def synth_file(rng, seconds, stereo):
     return (x * 32767).astype(np.int16), 1
 
 
-@pytest.mark.parametrize("shape", ["c3_mono_2s", "c4_stereo_1s"])
-def test_pipeline_matches_oracle_on_sampled_files(shape):
+def check_properties_of_every_file(res, stats, infos, n_files, ora):
+    """Size-independent properties, checked on ALL files of the batch (the oracle comparison below samples)."""
+    off = res["frame_offset"]
+    counts = np.diff(off)
+    for i in range(n_files):
+        assert counts[i] == ora.num_frames(infos[i]["n_samples"], cap=True), i          # the frame-count rule, SA:760-764, 814
+    total = int(off[-1])
+    for field in FIELDS:
+        if field != "mag":
+            assert np.all(np.isfinite(res[field])), field
+    assert np.all(res["spectral_rms"] >= 0) and np.all(res["amplitude_rms"] >= 0)
+    assert np.all(res["amplitude_peak"] <= 1.0) and np.all(res["amplitude_rms"] <= res["amplitude_peak"] + 1e-15)
+    roll = res["spectral_rolloff"]
+    assert np.all(roll == np.round(roll / 43.0) * 43.0) and np.all((roll >= 0) & (roll <= 738 * 43))   # 43 x a bin count
+    cplx = res["sub_complexity"]
+    assert np.all(cplx == np.round(cplx)) and np.all(cplx >= 0)
+    assert np.all(np.abs(res["spectral_flux"]) <= 1.0 + 1e-12) and np.all(np.abs(res["sub_flux"]) <= 1.0 + 1e-12)   # Pearson r
+    assert np.all((res["spectral_flatness"] >= 0) & (res["spectral_flatness"] <= 1.0))
+    assert np.all((res["spectral_centroid"] >= 0) & (res["spectral_centroid"] <= 737.0))
+    # a frame's 28 band energies are sums of |X|^2 over disjoint bin ranges of bins 1..1023
+    assert np.all(res["spectrum_bands"] >= 0)
+    # first frame of every file: flux against itself (SA:937-940) is 1 unless the frame is silent
+    first = res["spectral_flux"].reshape(total)[off[:-1]]
+    assert np.all((np.abs(first - 1.0) < 1e-9) | (first == 0.0))
+    # statistics: min <= median, mean <= max; variance >= 0; series of one frame keep the initial zeros (Statistics.cpp:72-89)
+    for field, (a, b) in FIELDS.items():
+        if field == "mag":
+            continue
+        st = stats[field].reshape(n_files, b - a, 13)
+        assert np.all(np.isfinite(st)), field
+        mn, mx, med, mean, var = st[..., 0], st[..., 1], st[..., 2], st[..., 3], st[..., 5]
+        span = 1e-9 * (1.0 + np.abs(mx))
+        assert np.all(mn <= med + span) and np.all(med <= mx + span) and np.all(mn <= mean + span) and np.all(mean <= mx + span), field
+        assert np.all(var >= 0), field
+
+
+@pytest.mark.parametrize("shape,n_files,n_sampled", [("c3_mono_2s", 1000, 32), ("c4_stereo_1s", 300, 8)])
+def test_pipeline_matches_oracle_on_sampled_files(shape, n_files, n_sampled):
+    """c3: BASELINE.json configs[2] at its full size -- 1000 synthetic 2.0 s files in ONE batch; c4: a 300-file slice of
+    configs[3]'s per-GPU share (the share itself, 12 500 files, runs in bench.py).  Properties on every file, the oracle
+    pipeline on a sample."""
     rng = np.random.default_rng(51)
     stereo = shape.startswith("c4")
-    n_files = 300
     files = [synth_file(rng, 1.0 if stereo else 2.0, stereo) for _ in range(n_files)]
     plan = afx.Plan()
     mask = afx.D_ALL_LOW_LEVEL | afx.D_STATISTICS
@@ -41,7 +79,8 @@ def test_pipeline_matches_oracle_on_sampled_files(shape):
     assert stats["stats_status"].tolist() == [0] * n_files and res["buf_status"].tolist() == [0] * n_files
     off = res["frame_offset"]
     ora = Oracle()
-    for i in rng.choice(n_files, 8, replace=False):
+    check_properties_of_every_file(res, stats, infos, n_files, ora)
+    for i in rng.choice(n_files, n_sampled, replace=False):
         data, ch = files[i]
         mono, info = _oracle.load_sample(data, ch)
         assert infos[i]["n_samples"] == info["n_samples"] and infos[i]["data_offset"] == info["data_offset"]
@@ -66,12 +105,13 @@ def test_pipeline_matches_oracle_on_sampled_files(shape):
                     continue                          # discrete series: compared above frame by frame
                 err = np.abs(gs[w] - want)
                 ok = err <= tol * np.abs(want) + scale
-                # TStatistics::Centroid / Spread / Flatness divide by the *sum* (mean) of the series: for a
-                # series that sums to rounding residue (e.g. band flux values of +-1) they are decided by the
-                # last bit of the inputs in any implementation
+                # TStatistics::Centroid and Spread divide by the *sum* of the series (Statistics.cpp:459-506): for a series
+                # that sums to rounding residue (e.g. band flux values of +-1) they are decided by the last bit of the
+                # inputs in any implementation -- and so are skewness / kurtosis, which are functions of exactly those
+                # two (Statistics.cpp:510-554: ((x - centroid) / spread)^3, ^4).  Nothing else is waived.
                 series = ref[:, a + w]
                 if abs(series.sum()) < 1e-6 * np.abs(series).sum():
-                    ok[[6, 7, 8, 9, 10]] = True
+                    ok[[6, 7, 8, 9]] = True
                 assert np.all(ok), (shape, int(i), field, w, gs[w], want)
     batch.close()
     plan.close()

@@ -2,7 +2,7 @@
 # Final GPU round of a build: full GPU test suite, default bench line, per-configuration rocprofv3 summaries
 # (tools/profile_config.py: kernel trace + separate PMC passes), rhythm kernel stats / PMC, parity report.
 set -u
-O=gpurun_out/${AFX_ROUND:-r02}; mkdir -p $O
+O=gpurun_out/${AFX_ROUND:-r03}; mkdir -p $O
 timeout 1200 python -m pytest tests -m gpu -q --timeout 150 --timeout-method thread > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
 cp gpurun_out/parity_report.md $O/parity_report.md 2>/dev/null
 timeout 600 python bench.py > $O/bench_default.json 2> $O/bench_default.err; tail -c 600 $O/bench_default.json; echo

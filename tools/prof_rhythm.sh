@@ -1,7 +1,7 @@
 #!/bin/bash
 # per-kernel time of the rhythm tracker for each workload of tools/rhythm_report.py (rocprofv3 --kernel-trace --stats)
 set -u
-O=$PWD/gpurun_out/${AFX_ROUND:-r02}; mkdir -p $O
+O=$PWD/gpurun_out/${AFX_ROUND:-r03}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 for w in short loops long long256; do
   rm -rf /tmp/prt_$w

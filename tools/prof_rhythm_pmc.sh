@@ -2,7 +2,7 @@
 # PMC counters of the rhythm kernels on one workload of tools/rhythm_report.py (separate pass, no trace domains)
 set -u
 W=${1:-short}
-O=$PWD/gpurun_out/${AFX_ROUND:-r02}; mkdir -p $O
+O=$PWD/gpurun_out/${AFX_ROUND:-r03}; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/prp_$W
 AFX_RT_ONLY=$W rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE SQ_WAVES --output-format csv -d /tmp/prp_$W -o p -- python3 $GRAFT_REPO_ROOT/tools/rhythm_report.py > /dev/null 2>&1

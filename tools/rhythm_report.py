@@ -15,7 +15,7 @@ sys.path.insert(0, ROOT)
 import afec_amd as afx  # noqa: E402
 from tests import _oracle  # noqa: E402
 
-OUT = os.path.join(ROOT, "gpurun_out", os.environ.get("AFX_ROUND", "r02"))
+OUT = os.path.join(ROOT, "gpurun_out", os.environ.get("AFX_ROUND", "r03"))
 os.makedirs(OUT, exist_ok=True)
 GOLD = np.load(os.path.join(ROOT, "tests", "golden", "rhythm.npz"))
 lines = ["# rhythm tracker: GPU vs oracle, and kernel time", ""]

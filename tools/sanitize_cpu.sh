@@ -3,7 +3,7 @@
 # available on the pool.  Writes profiles/<round>/sanitize_cpu.txt.
 set -eu
 cd "$(dirname "$0")/.."
-R=${AFX_ROUND:-r02}
+R=${AFX_ROUND:-r03}
 mkdir -p /tmp/afx_san profiles/$R
 g++ -std=c++17 -O1 -g -fno-omit-frame-pointer -fsanitize=address,undefined -fno-sanitize-recover=undefined -ffp-contract=off \
     -o /tmp/afx_san/sanitize tests/sanitize/sanitize_main.cpp afec_amd/host/WaveFile.cpp afec_amd/host/DescriptorColumns.cpp \

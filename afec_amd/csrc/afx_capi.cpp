@@ -166,11 +166,11 @@ struct Workspace {
   bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_plan_set_blocking_wait)
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
   Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
-  Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff;   // rhythm tracker
+  Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff, rt_long, rt_polar;   // rhythm tracker
   Buf stat_tmp;                                                                 // half-wave statistics class
   size_t bytes() const {
     return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
-           efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap + queue.cap + rt_files.cap + rt_odf.cap +
+           efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap + queue.cap + rt_files.cap + rt_long.cap + rt_polar.cap + rt_odf.cap +
            rt_onsets.cap + rt_scratch.cap + rt_scalars.cap + rt_stats.cap + rt_foff.cap + stat_tmp.cap;
   }
 };
@@ -237,6 +237,12 @@ struct afx_batch {
   std::vector<int32_t> file_offset;        // [n_bufs]: mDataOffset default
   bool rt_files_dirty = false;
   afx::RhythmFile* d_rt_files = nullptr;
+  // long files of a small batch (afx_rhythm.hip): [n_long] file indices, [n_long + 1] round offsets (int32), [n_long + 1]
+  // frame offsets (int64) in one device buffer; the polar scratch
+  int32_t rt_n_long = 0, rt_long_rounds = 0;
+  int64_t rt_long_rows = 0;
+  void* d_rt_long = nullptr;
+  float2* d_rt_polar = nullptr;
   float* d_rt_odf = nullptr;
   double* d_rt_onsets = nullptr;
   double* d_rt_scratch = nullptr;
@@ -399,7 +405,7 @@ void free_tables(afx_plan* p) {
 void ws_free(Workspace* w) {
   if (!w) return;
   for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
-                            &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place, &w->queue, &w->rt_files, &w->rt_odf,
+                            &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place, &w->queue, &w->rt_files, &w->rt_long, &w->rt_polar, &w->rt_odf,
                             &w->rt_onsets, &w->rt_scratch, &w->rt_scalars, &w->rt_stats, &w->rt_foff, &w->stat_tmp}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
@@ -928,6 +934,44 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
       b->file_offset[(size_t)i] = file_offset ? (*file_offset)[(size_t)i] : 0;
     }
     b->rt_offset[(size_t)n_bufs] = rows;
+    // A batch of few files does not fill the chip with one workgroup per file, and a long file is hundreds of
+    // dependent rounds for its workgroup (a lone 20 s file: 430 rounds, 5.7 ms): such files take the three-kernel path
+    std::vector<int32_t> long_files, long_round_off;
+    std::vector<int64_t> long_frame_off;
+    if (n_bufs <= afx::kRhythmLongBatchFiles) {
+      int32_t rounds = 0;
+      int64_t lrows = 0;
+      for (int i = 0; i < n_bufs; ++i)
+        if (b->rt_files[(size_t)i].frames >= afx::kRhythmLongFrames) {
+          long_files.push_back(i);
+          long_round_off.push_back(rounds);
+          long_frame_off.push_back(lrows);
+          b->rt_files[(size_t)i].long_slot = (int32_t)long_files.size();
+          rounds += (b->rt_files[(size_t)i].frames + 15) / 16;
+          lrows += (b->rt_files[(size_t)i].frames + afx::kRhythmLongPad - 1) / afx::kRhythmLongPad * afx::kRhythmLongPad;
+        }
+      long_round_off.push_back(rounds);
+      long_frame_off.push_back(lrows);
+      b->rt_n_long = (int32_t)long_files.size();
+      b->rt_long_rounds = rounds;
+      if (b->rt_n_long > 0) {
+        const size_t nl = long_files.size();
+        // layout: int64 frame offsets [nl + 1], then int32 round offsets [nl + 1], then int32 file indices [nl]
+        std::vector<unsigned char> blob((nl + 1) * 8 + (nl + 1) * 4 + nl * 4);
+        std::memcpy(blob.data(), long_frame_off.data(), (nl + 1) * 8);
+        std::memcpy(blob.data() + (nl + 1) * 8, long_round_off.data(), (nl + 1) * 4);
+        std::memcpy(blob.data() + (nl + 1) * 12, long_files.data(), nl * 4);
+        if ((e = ws_reserve(w.rt_long, blob.size())) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm long files)"));
+        // (magnitude, phase) pairs, then the follower's float per bin: 12 bytes per bin and frame
+        if ((e = ws_reserve(w.rt_polar, (size_t)lrows * 256 * (sizeof(float2) + sizeof(float)))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm polar)"));
+        b->rt_long_rows = lrows;
+        b->d_rt_long = w.rt_long.p;
+        b->d_rt_polar = (float2*)w.rt_polar.p;
+        // (blocking copy: the blob is a local)
+        if ((e = hipMemcpyAsync(b->d_rt_long, blob.data(), blob.size(), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(rhythm long files)"));
+        if ((e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));
+      }
+    }
     set_rhythm_context(b, nullptr);
     if ((e = ws_reserve(w.rt_files, b->rt_files.size() * sizeof(afx::RhythmFile))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(rhythm files)"));
     b->d_rt_files = (afx::RhythmFile*)w.rt_files.p;
@@ -1069,6 +1113,15 @@ int run_rhythm(afx_batch* b, hipStream_t stream) {
   for (const afx::RhythmFile& rf : b->rt_files)
     if (rf.frames <= afx::kRhythmLdsFrames) ra.lds_frames = std::max(ra.lds_frames, rf.frames);
   ra.odf = b->d_rt_odf; ra.onsets = b->d_rt_onsets; ra.scratch = b->d_rt_scratch; ra.scalars = b->d_rt_scalars;
+  ra.n_long = b->rt_n_long; ra.long_rounds = b->rt_long_rounds;
+  if (b->rt_n_long > 0) {
+    const size_t nl = (size_t)b->rt_n_long;
+    ra.long_frame_off = (const int64_t*)b->d_rt_long;
+    ra.long_round_off = (const int32_t*)((const unsigned char*)b->d_rt_long + (nl + 1) * 8);
+    ra.long_files = (const int32_t*)((const unsigned char*)b->d_rt_long + (nl + 1) * 12);
+    ra.long_polar = b->d_rt_polar;
+    ra.long_den = (float*)(b->d_rt_polar + b->rt_long_rows * 256);
+  }
   HIP_TRY(afx::launch_rhythm(ra, stream));
   if (b->d_rt_stats) {
     afx::StatsArgs sa{};

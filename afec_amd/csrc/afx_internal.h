@@ -209,7 +209,7 @@ struct RhythmFile {
   int64_t sample_off;   // first sample of the buffer in the PCM arena
   int64_t frame0;       // first row of the buffer's 512/128 frames in the batch-wide arrays
   int32_t frames;       // 512/128 frames of the analysed prefix (SampleAnalyser.cpp:991)
-  int32_t pad;
+  int32_t long_slot;    // > 0: the file's onset functions come from the long-file kernels (slot long_slot - 1)
   double duration_s;    // SampleDurationInSeconds (SampleAnalyser.cpp:1001-1002)
   double offset_s;      // OnsetOffsetInSeconds    (SampleAnalyser.cpp:1003-1004)
 };
@@ -237,7 +237,19 @@ struct RhythmArgs {
   double* onsets;               // [total_frames][2]: TRhythmTracker::Onsets (complex, percussive)
   double* scratch;              // [8][total_frames]
   double* scalars;              // [n_files][14]
+  // long files of a small batch: onset functions by three kernels instead of one workgroup per file (afx_rhythm.hip)
+  int32_t n_long, long_rounds;          // files on that path; rounds of 16 frames they have together
+  const int32_t* long_files;            // [n_long]: index into files
+  const int32_t* long_round_off;        // [n_long + 1]: first round of each
+  const int64_t* long_frame_off;        // [n_long + 1]: first row of each in long_polar
+  float2* long_polar;                   // [long frames][256]: (magnitude, phase)
+  float* long_den;                      // [long frames][256]: what the whitening divides the magnitude by
 };
+// which files take the long-file path: a batch of few files (the chip is not filled by one workgroup per file) and a file of
+// at least this many 512/128 frames (3 s)
+constexpr int kRhythmLongBatchFiles = 64, kRhythmLongFrames = 1024;
+// rows of a long file in long_polar / long_den: its frames rounded up to a multiple of this (the follower kernel's batches)
+constexpr int kRhythmLongPad = 48;
 hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream);
 
 // ---- LoadSample front end (SampleAnalyser.cpp:484-718) ----

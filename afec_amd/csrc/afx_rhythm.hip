@@ -90,19 +90,146 @@ __device__ __forceinline__ void dft16(C (&v)[16]) {
   f32x32::dft16_rest(v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8], v[9], v[10], v[11], v[12], v[13], v[14], v[15]);
 }
 
+// TOnsetFftProcessor::LoadFrame (OD.cpp:116-160) for one frame by one 16-lane group (lane q): window, FFT, magnitude and
+// phase of bins q + 16 r as float.  z[j] = (w x)[2j] + i (w x)[2j+1], j = 16 n1 + n2: lane n2 = q holds n1 = 0..15.  The
+// window table carries the 1/2 of the real-input untangle (an exact scaling).  xg: the group's exchange plane (kPlane
+// doubles of LDS).
+template <typename PCM>
+__device__ __forceinline__ void onset_polar_frame(const PCM* xf, double* xg, const RhythmArgs& a, int q, float (&magf)[16],
+                                                  float (&phf)[16]) {
+  const C* tw = reinterpret_cast<const C*>(a.tw256);   // [n2][k1]: w256^(n2 k1)
+  const C* ut = reinterpret_cast<const C*>(a.ut512);   // [r][q]:   w512^(q + 16 r)
+  C v[16];
+#pragma unroll
+  for (int n1 = 0; n1 < 16; ++n1) {
+    const int j = 16 * n1 + q;
+    double x0, x1, w0, w1;
+    load2(xf + 2 * j, x0, x1);
+    load2(a.window + 2 * j, w0, w1);
+    v[n1] = {w0 * x0, w1 * x1};
+  }
+  dft16(v);                                         // Y[k1][n2 = q]
+  C u[16];
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + q] = v[k1].re;
+  wave_lds_fence();
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) u[n2].re = xg[q * 17 + n2];
+  wave_lds_fence();
+#pragma unroll
+  for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + q] = v[k1].im;
+  wave_lds_fence();
+#pragma unroll
+  for (int n2 = 0; n2 < 16; ++n2) u[n2].im = xg[q * 17 + n2];
+  wave_lds_fence();
+  // lane k1 = q: factors w256^(n2 k1) fused into the first radix-4 stage of the DFT over n2
+  {
+    C w[16];
+#pragma unroll
+    for (int n2 = 1; n2 < 16; ++n2) w[n2] = tw[n2 * 16 + q];
+    f32x32::radix4_tw3(u[0], u[4], u[8], u[12], w[4], w[8], w[12]);
+#pragma unroll
+    for (int b = 1; b < 4; ++b) f32x32::radix4_tw4(u[b], u[b + 4], u[b + 8], u[b + 12], w[b], w[b + 4], w[b + 8], w[b + 12]);
+  }
+  f32x32::dft16_rest(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7], u[8], u[9], u[10], u[11], u[12], u[13], u[14], u[15]);
+  // u[r] = Z[k], k = q + 16 r.  Untangle with the partner Z[(256 - k) & 255] through the group's plane.
+  C p[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xg[q + 16 * r] = u[r].re;
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r].re = xg[(256 - (q + 16 * r)) & 255];
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) xg[q + 16 * r] = u[r].im;
+  wave_lds_fence();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) p[r].im = xg[(256 - (q + 16 * r)) & 255];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const C A = u[r], B = p[r], w = ut[r * 16 + q];
+    const double er = A.re + B.re, ei = A.im - B.im, orr = A.im + B.im, oi = B.re - A.re;
+    const double re = er + (w.re * orr - w.im * oi);
+    // the reference transform is e^{+i} (ooura_cdft(.., 1, ..), Fourier.cpp:243-262): conjugate of this one
+    double im = -(ei + (w.re * oi + w.im * orr));
+    if (q + 16 * r == 0) im = 0.0;                          // Im[0] of a real frame is +0
+    magf[r] = (float)sqrt(re * re + im * im);               // TAudioMath::Magnitude, AudioMath.cpp:497-503
+    phf[r] = (float)atan2(im, re);                          // TAudioMath::Phase, AudioMath.cpp:637-643
+  }
+}
+
+// Whiten (OD.cpp:186-240), the follower step of one bin: psp is the adaptive maximum (double), the return value the
+// float the magnitude is divided by
+__device__ __forceinline__ float onset_follow(float mg, double& psp, float relax_coef) {
+  double value = (double)fabsf(mg);
+  const double old = psp;
+  if (value < old) value = value + (old - value) * (double)relax_coef;
+  psp = value;
+  const double fl = (double)0.1f;                                     // mWhiteningFloor, OD.cpp:47
+  return (float)((fl > psp) ? fl : psp);
+}
+
+// The terms of both onset functions for one bin of one frame (OD.cpp:380-458) from the whitened magnitude m and the
+// phase ph of the frame and what the frame before left: pred_mag = its |m|, yester_phase = its phase, yester_diff =
+// its rewrapped phase step.  Returns the rectified complex-domain deviation, pw the power term.
+__device__ __forceinline__ float onset_terms(float m, float ph, float pred_mag, float yester_phase, float yester_diff, float& pw) {
+  const float cur = fabsf(m);
+  float dev = 0.f;
+  if (cur > 0.01f) {                                                  // mOdfparam, OD.cpp:299
+    if (!(cur < pred_mag)) {                                          // Rectify: ignore decreasing bins
+      const float pred_phase = yester_phase + yester_diff;
+      float d = pred_phase - ph;
+      d = phase_rewrap(d);
+      const float cs = cosf_glibc(d);
+      dev = sqrtf(pred_mag * pred_mag + cur * cur - pred_mag * cur * cs);
+    }
+  }
+  pw = m * m;
+  return dev;
+}
+
+// the two onset-function values of frame `fr` of a round from its 255 + 1 staged terms (rows of kRow floats), added in the
+// reference's order (15 at a time in registers so that the LDS reads of a group are in flight together)
+__device__ __forceinline__ float onset_sum(const float* plane_p, const float* plane_c, int fr, int type, const RhythmArgs& a) {
+  float v;
+  if (type == 0) {          // kFunctionRComplex: double sum of the float deviations, OD.cpp:398-458
+    const float* row = plane_c + fr * kRow;
+    double total = 0.0;
+    for (int i0 = 0; i0 < kRtBins; i0 += 15) {
+      float t[15];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) t[k] = row[i0 + k];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) total += (double)t[k];
+    }
+    v = (float)total;
+    v *= a.norm_complex;
+  } else {                  // kFunctionPower: float sum, OD.cpp:380-388 (mNyquist = Im[0] = 0)
+    const float* row = plane_p + fr * kRow;
+    v = (0.f * 0.f) + row[255];
+    for (int i0 = 0; i0 < kRtBins; i0 += 15) {
+      float t[15];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) t[k] = row[i0 + k];
+#pragma unroll
+      for (int k = 0; k < 15; ++k) v += t[k];
+    }
+    v *= a.norm_power;
+  }
+  return v;
+}
+
 template <typename PCM>
 __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel(RhythmArgs a) {
   __shared__ double s_x[kRound * kPlane];   // 34,816 B: exchange planes of the FFT stage, then the float polar / term rows
   const RhythmFile f = a.files[blockIdx.x];
   const int T = f.frames;
-  if (T <= 0) return;
+  if (T <= 0 || f.long_slot > 0) return;    // long files of small batches: the three kernels below
   const int tid = threadIdx.x, g = tid >> 4, q = tid & 15;
   const PCM* x = reinterpret_cast<const PCM*>(a.pcm) + f.sample_off;
   double* xg = s_x + g * kPlane;
   float* plane_p = reinterpret_cast<float*>(s_x);      // [16][257]: magnitudes, then the power terms m^2
   float* plane_c = plane_p + kRound * kRow;            // [16][257]: phases, then the complex-domain deviations
-  const C* tw = reinterpret_cast<const C*>(a.tw256);   // [n2][k1]: w256^(n2 k1)
-  const C* ut = reinterpret_cast<const C*>(a.ut512);   // [r][q]:   w512^(q + 16 r)
   // state of bin `tid` across the frames of the file
   double psp = 0.0;                         // whitening follower, OD.cpp:63-65, 186-230
   float pred_mag = 0.f, yester_phase = 0.f, yester_diff = 0.f;   // mpOther, OD.cpp:300-305
@@ -110,69 +237,7 @@ __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel
   for (int t0 = 0; t0 < T; t0 += kRound) {
     const int nf = min(kRound, T - t0);
     float magf[16], phf[16];
-    if (g < nf) {
-      // ---- TOnsetFftProcessor::LoadFrame (OD.cpp:116-160): window, FFT, magnitude and phase of bins 0..254 ----
-      // z[j] = (w x)[2j] + i (w x)[2j+1], j = 16 n1 + n2: lane n2 = q holds n1 = 0..15.  The window table carries the
-      // 1/2 of the real-input untangle (an exact scaling).
-      C v[16];
-      const PCM* xf = x + (int64_t)(t0 + g) * kRtHop;
-#pragma unroll
-      for (int n1 = 0; n1 < 16; ++n1) {
-        const int j = 16 * n1 + q;
-        double x0, x1, w0, w1;
-        load2(xf + 2 * j, x0, x1);
-        load2(a.window + 2 * j, w0, w1);
-        v[n1] = {w0 * x0, w1 * x1};
-      }
-      dft16(v);                                         // Y[k1][n2 = q]
-      C u[16];
-#pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + q] = v[k1].re;
-      wave_lds_fence();
-#pragma unroll
-      for (int n2 = 0; n2 < 16; ++n2) u[n2].re = xg[q * 17 + n2];
-      wave_lds_fence();
-#pragma unroll
-      for (int k1 = 0; k1 < 16; ++k1) xg[k1 * 17 + q] = v[k1].im;
-      wave_lds_fence();
-#pragma unroll
-      for (int n2 = 0; n2 < 16; ++n2) u[n2].im = xg[q * 17 + n2];
-      wave_lds_fence();
-      // lane k1 = q: factors w256^(n2 k1) fused into the first radix-4 stage of the DFT over n2
-      {
-        C w[16];
-#pragma unroll
-        for (int n2 = 1; n2 < 16; ++n2) w[n2] = tw[n2 * 16 + q];
-        f32x32::radix4_tw3(u[0], u[4], u[8], u[12], w[4], w[8], w[12]);
-#pragma unroll
-        for (int b = 1; b < 4; ++b) f32x32::radix4_tw4(u[b], u[b + 4], u[b + 8], u[b + 12], w[b], w[b + 4], w[b + 8], w[b + 12]);
-      }
-      f32x32::dft16_rest(u[0], u[1], u[2], u[3], u[4], u[5], u[6], u[7], u[8], u[9], u[10], u[11], u[12], u[13], u[14], u[15]);
-      // u[r] = Z[k], k = q + 16 r.  Untangle with the partner Z[(256 - k) & 255] through the group's plane.
-      C p[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xg[q + 16 * r] = u[r].re;
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p[r].re = xg[(256 - (q + 16 * r)) & 255];
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) xg[q + 16 * r] = u[r].im;
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < 16; ++r) p[r].im = xg[(256 - (q + 16 * r)) & 255];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const C A = u[r], B = p[r], w = ut[r * 16 + q];
-        const double er = A.re + B.re, ei = A.im - B.im, orr = A.im + B.im, oi = B.re - A.re;
-        const double re = er + (w.re * orr - w.im * oi);
-        // the reference transform is e^{+i} (ooura_cdft(.., 1, ..), Fourier.cpp:243-262): conjugate of this one
-        double im = -(ei + (w.re * oi + w.im * orr));
-        if (q + 16 * r == 0) im = 0.0;                          // Im[0] of a real frame is +0
-        magf[r] = (float)sqrt(re * re + im * im);               // TAudioMath::Magnitude, AudioMath.cpp:497-503
-        phf[r] = (float)atan2(im, re);                          // TAudioMath::Phase, AudioMath.cpp:637-643
-      }
-    }
+    if (g < nf) onset_polar_frame(x + (int64_t)(t0 + g) * kRtHop, xg, a, q, magf, phf);
     __syncthreads();   // every group is done with its exchange plane: the polar rows take the space
     if (g < nf) {
 #pragma unroll
@@ -186,28 +251,13 @@ __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel
     if (tid < kRtBins) {
       for (int fr = 0; fr < nf; ++fr) {
         const float mg = plane_p[fr * kRow + tid], ph = plane_c[fr * kRow + tid];
-        double value = (double)fabsf(mg);
-        const double old = psp;
-        if (value < old) value = value + (old - value) * (double)a.relax_coef;
-        psp = value;
-        const double fl = (double)0.1f;                                     // mWhiteningFloor, OD.cpp:47
-        const float m = mg / (float)((fl > psp) ? fl : psp);
-        const float cur = fabsf(m);
-        float dev = 0.f;
-        if (cur > 0.01f) {                                                  // mOdfparam, OD.cpp:299
-          if (!(cur < pred_mag)) {                                          // Rectify: ignore decreasing bins
-            const float pred_phase = yester_phase + yester_diff;
-            float d = pred_phase - ph;
-            d = phase_rewrap(d);
-            const float cs = cosf_glibc(d);
-            dev = sqrtf(pred_mag * pred_mag + cur * cur - pred_mag * cur * cs);
-          }
-        }
-        pred_mag = cur;
+        const float m = mg / onset_follow(mg, psp, a.relax_coef);
+        float pw;
+        const float dev = onset_terms(m, ph, pred_mag, yester_phase, yester_diff, pw);
+        pred_mag = fabsf(m);
         const float diff = ph - yester_phase;
         yester_phase = ph;
         yester_diff = phase_rewrap(diff);
-        const float pw = m * m;
         plane_p[fr * kRow + tid] = pw;
         plane_c[fr * kRow + tid] = dev;
         // mDC is (float)Re[0] and mBin[0].mMagn is |Re[0]|: the same float up to sign, whitened by the same follower
@@ -221,35 +271,119 @@ __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel
     //      sides of a divergent branch ----
     if ((tid & 63) < nf && tid < 128) {
       const int fr = tid & 63, type = tid >> 6;
-      float v;
-      // 255 terms added in bin order, 15 at a time in registers so that the LDS reads of a group are in flight together
-      if (type == 0) {          // kFunctionRComplex: double sum of the float deviations, OD.cpp:398-458
-        const float* row = plane_c + fr * kRow;
-        double total = 0.0;
-        for (int i0 = 0; i0 < kRtBins; i0 += 15) {
-          float t[15];
-#pragma unroll
-          for (int k = 0; k < 15; ++k) t[k] = row[i0 + k];
-#pragma unroll
-          for (int k = 0; k < 15; ++k) total += (double)t[k];
-        }
-        v = (float)total;
-        v *= a.norm_complex;
-      } else {                  // kFunctionPower: float sum, OD.cpp:380-388 (mNyquist = Im[0] = 0)
-        const float* row = plane_p + fr * kRow;
-        v = (0.f * 0.f) + row[255];
-        for (int i0 = 0; i0 < kRtBins; i0 += 15) {
-          float t[15];
-#pragma unroll
-          for (int k = 0; k < 15; ++k) t[k] = row[i0 + k];
-#pragma unroll
-          for (int k = 0; k < 15; ++k) v += t[k];
-        }
-        v *= a.norm_power;
-      }
-      a.odf[(f.frame0 + t0 + fr) * 2 + type] = v;
+      a.odf[(f.frame0 + t0 + fr) * 2 + type] = onset_sum(plane_p, plane_c, fr, type, a);
     }
     __syncthreads();
+  }
+}
+
+// ---- long files of a small batch (RhythmFile::long_slot > 0): the same arithmetic as three kernels, so that a lone
+//      20 s file is not 430 dependent rounds of one workgroup.  Only the follower is a recurrence over the frames; the
+//      deviation needs the two frames before it, nothing older.
+//        onset_polar_kernel   one workgroup per round of 16 frames: FFT -> (magnitude, phase) floats in global memory
+//        onset_follow_kernel  one workgroup per file, thread = bin, frames in order: the adaptive maximum, i.e. what
+//                             the magnitude is divided by (long_den)
+//        onset_terms_kernel   one workgroup per round: the terms of both functions (they need frames t, t-1, t-2) and the
+//                             ordered sums
+//      polar: [long frames][256] float2 and den: [long frames][256] float, the long files back to back
+//      (RhythmArgs::long_frame_off) ----
+__device__ __forceinline__ int long_file_of_round(const RhythmArgs& a, int round, int& round_in_file) {
+  int i = 0;
+  while (i + 1 < a.n_long && round >= a.long_round_off[i + 1]) ++i;
+  round_in_file = round - a.long_round_off[i];
+  return i;
+}
+
+template <typename PCM>
+__global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_polar_kernel(RhythmArgs a) {
+  __shared__ double s_x[kRound * kPlane];
+  int round;
+  const int slot = long_file_of_round(a, blockIdx.x, round);
+  const RhythmFile f = a.files[a.long_files[slot]];
+  const int T = f.frames, t0 = round * kRound, tid = threadIdx.x, g = tid >> 4, q = tid & 15;
+  if (t0 + g >= T) return;
+  const PCM* x = reinterpret_cast<const PCM*>(a.pcm) + f.sample_off;
+  float magf[16], phf[16];
+  onset_polar_frame(x + (int64_t)(t0 + g) * kRtHop, s_x + g * kPlane, a, q, magf, phf);
+  float2* row = a.long_polar + (a.long_frame_off[slot] + t0 + g) * 256;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) row[q + 16 * r] = float2{magf[r], phf[r]};
+}
+
+__global__ __launch_bounds__(256) void onset_follow_kernel(RhythmArgs a) {
+  const int slot = blockIdx.x, tid = threadIdx.x;
+  const int T = a.files[a.long_files[slot]].frames;
+  const float2* p = a.long_polar + a.long_frame_off[slot] * 256 + tid;
+  float* den = a.long_den + a.long_frame_off[slot] * 256 + tid;
+  double psp = 0.0;
+  // The chain per frame is a handful of dependent operations; a global load is a thousand cycles.  Three batches of 16
+  // frames rotate: while one is worked on, the loads of the next two are in flight.  A file's rows are padded to a
+  // multiple of the three batches (kRhythmLongPad): no bounds checks, the rows behind the last frame are scratch.
+  // Only the recurrence runs here; the division by the follower is onset_terms_kernel's.
+  constexpr int B = kRhythmLongPad / 3;
+  float m0[B], m1[B], m2[B];
+  auto load = [&](float (&m)[B], const float2* from) {
+#pragma unroll
+    for (int k = 0; k < B; ++k) m[k] = from[k * 256].x;
+  };
+  auto work = [&](float (&m)[B], float* to) {
+#pragma unroll
+    for (int k = 0; k < B; ++k) to[k * 256] = onset_follow(m[k], psp, a.relax_coef);
+  };
+  const int steps = (T + kRhythmLongPad - 1) / kRhythmLongPad;
+  load(m0, p);
+  load(m1, p + B * 256);
+  load(m2, p + 2 * B * 256);
+  for (int i = 0; i < steps; ++i) {
+    const bool more = i + 1 < steps;     // (the loads behind the last step would leave the file's rows)
+    const float2* const nxt = p + (more ? 3 * B * 256 : 0);
+    work(m0, den);
+    load(m0, nxt);
+    work(m1, den + B * 256);
+    load(m1, nxt + B * 256);
+    work(m2, den + 2 * B * 256);
+    load(m2, nxt + 2 * B * 256);
+    p = nxt;
+    den += 3 * B * 256;
+  }
+}
+
+__global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_terms_kernel(RhythmArgs a) {
+  __shared__ float s_p[kRound * kRow], s_c[kRound * kRow];
+  int round;
+  const int slot = long_file_of_round(a, blockIdx.x, round);
+  const RhythmFile f = a.files[a.long_files[slot]];
+  const int T = f.frames, t0 = round * kRound, tid = threadIdx.x;
+  const int nf = min(kRound, T - t0);
+  const float2* base = a.long_polar + a.long_frame_off[slot] * 256 + tid;
+  if (tid < kRtBins) {
+    // (whitened magnitude, phase) of frames t0 - 2 .. t0 + nf - 1; the frames before the file are zeros (mpOther, OD.cpp:300-305)
+    const float* const den = a.long_den + a.long_frame_off[slot] * 256 + tid;
+    auto at = [&](int t) -> float2 {
+      if (t < 0) return float2{0.f, 0.f};
+      const float2 v = base[(int64_t)t * 256];
+      return float2{v.x / den[(int64_t)t * 256], v.y};
+    };
+    const float2 v2 = at(t0 - 2), v1 = at(t0 - 1);
+    float pred_mag = fabsf(v1.x), yester_phase = v1.y, yester_diff = phase_rewrap(v1.y - v2.y);
+    if (t0 == 0) yester_diff = 0.f;            // (rewrap(0 - 0) is 0 as well: kept explicit)
+    for (int fr = 0; fr < nf; ++fr) {
+      const float2 v = at(t0 + fr);
+      float pw;
+      const float dev = onset_terms(v.x, v.y, pred_mag, yester_phase, yester_diff, pw);
+      pred_mag = fabsf(v.x);
+      const float diff = v.y - yester_phase;
+      yester_phase = v.y;
+      yester_diff = phase_rewrap(diff);
+      s_p[fr * kRow + tid] = pw;
+      s_c[fr * kRow + tid] = dev;
+      if (tid == 0) s_p[fr * kRow + 255] = pw;
+    }
+  }
+  __syncthreads();
+  if ((tid & 63) < nf && tid < 128) {
+    const int fr = tid & 63, type = tid >> 6;
+    a.odf[(f.frame0 + t0 + fr) * 2 + type] = onset_sum(s_p, s_c, fr, type, a);
   }
 }
 
@@ -773,8 +907,16 @@ __global__ __launch_bounds__(256) void rhythm_final_kernel(RhythmArgs a) {
 hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream) {
   if (a.n_files <= 0) return hipSuccess;
   if (a.total_frames > 0) {
-    if (a.pcm_dtype == 1) hipLaunchKernelGGL(onset_function_kernel<double>, dim3(a.n_files), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(onset_function_kernel<float>, dim3(a.n_files), dim3(256), 0, stream, a);
+    if (a.n_long < a.n_files) {     // (every file long: nothing for the one-workgroup-per-file kernel)
+      if (a.pcm_dtype == 1) hipLaunchKernelGGL(onset_function_kernel<double>, dim3(a.n_files), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL(onset_function_kernel<float>, dim3(a.n_files), dim3(256), 0, stream, a);
+    }
+    if (a.n_long > 0) {
+      if (a.pcm_dtype == 1) hipLaunchKernelGGL(onset_polar_kernel<double>, dim3(a.long_rounds), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL(onset_polar_kernel<float>, dim3(a.long_rounds), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(onset_follow_kernel, dim3(a.n_long), dim3(256), 0, stream, a);
+      hipLaunchKernelGGL(onset_terms_kernel, dim3(a.long_rounds), dim3(256), 0, stream, a);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

@@ -245,9 +245,10 @@ struct RhythmArgs {
   float2* long_polar;                   // [long frames][256]: (magnitude, phase)
   float* long_den;                      // [long frames][256]: what the whitening divides the magnitude by
 };
-// which files take the long-file path: a batch of few files (the chip is not filled by one workgroup per file) and a file of
-// at least this many 512/128 frames (3 s)
-constexpr int kRhythmLongBatchFiles = 64, kRhythmLongFrames = 1024;
+// which files take the long-file path: a batch of at most this many files (one workgroup per file leaves CUs idle and
+// runs hundreds of dependent rounds; measured on 20 s files: 1 file 5.8 -> 0.35 ms, 256 files 5.9 -> 5.8 ms: the
+// paths meet there) and a file of at least this many 512/128 frames (3 s)
+constexpr int kRhythmLongBatchFiles = 256, kRhythmLongFrames = 1024;
 // rows of a long file in long_polar / long_den: its frames rounded up to a multiple of this (the follower kernel's batches)
 constexpr int kRhythmLongPad = 48;
 hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream);

@@ -6,6 +6,7 @@
 //   * oracle: per-frame loop, neighbours, LoadSample, statistics, rhythm tracker on ragged and degenerate inputs
 //     (the checker must itself be memory-clean, the GPU parity tests trust it).
 #include <cmath>
+#include <array>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -104,6 +105,27 @@ int main() {
     D.mRhythmComplexOnsets.mValues.assign(100, 0.25);
     const auto Columns = afec::LowLevelColumns(D, nullptr);
     std::printf("columns: %zu\n", Columns.size());
+    // the writer's refill path: one vector reused over files of different lengths, with and without the load info
+    std::vector<afec::TColumn> Reused;
+    afec::TSampleDataInfo Info = {0.5f, 0.25f, -2205, 90000};
+    size_t Bytes = 0;
+    for (int Round = 0; Round < 50; ++Round) {
+      afec::TSampleDescriptors E;
+      const size_t n = (size_t)((Round * 37) % 91);
+      E.mSpectralCentroid.mValues.assign(n, 1.5);
+      E.mCepstrumBands.mValues.assign((size_t)((Round * 13) % 23), std::array<double, 14>{});
+      E.mSpectrumBands.mValues.assign(n / 2, std::array<double, 28>{});
+      E.mRhythmPercussiveOnsets.mValues.assign((size_t)(Round * 70000 / 49), 0.125);     // up to the 32-bit array header
+      afec::RefillLowLevelColumns(Reused, E, (Round % 3 == 0) ? nullptr : &Info);
+      const auto Fresh = afec::LowLevelColumns(E, (Round % 3 == 0) ? nullptr : &Info);
+      if (Fresh.size() != Reused.size()) { std::printf("refill: column count differs\n"); return 1; }
+      for (size_t i = 0; i < Fresh.size(); ++i) {
+        if (Fresh[i].mName != Reused[i].mName || Fresh[i].mType != Reused[i].mType || Fresh[i].mBlob != Reused[i].mBlob ||
+            (Fresh[i].mType == afec::TColumn::kReal && Fresh[i].mReal != Reused[i].mReal)) { std::printf("refill: column %zu differs\n", i); return 1; }
+        Bytes += Reused[i].mBlob.size();
+      }
+    }
+    std::printf("refill: 50 files, %zu BLOB bytes, identical to fresh columns\n", Bytes);
   }
 
   // ---- oracle ----

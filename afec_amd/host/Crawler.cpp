@@ -180,7 +180,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   TPinnedPool& RhythmPool = mpImpl->mRhythmPool;
   TPinnedPool& StagingPool = mpImpl->mStagingPool;
   std::unique_ptr<TSqliteSampleDescriptorPool> pPool;
-  if (!Options.mDatabasePath.empty()) pPool.reset(new TSqliteSampleDescriptorPool(Options.mDatabasePath));
+  if (!Options.mDatabasePath.empty()) pPool.reset(new TSqliteSampleDescriptorPool(Options.mDatabasePath, Options.mDatabasePragmas));
 
   // shards: file i -> device i mod G, in crawl order
   std::vector<std::vector<const TCrawlFile*>> Shard((size_t)G);
@@ -419,6 +419,12 @@ extern "C" void afec_crawl_release(void) {
 
 extern "C" void afec_crawl_set_bytes_per_batch(int64_t bytes) { gBytesPerBatch = bytes; }
 
+namespace { std::mutex gPragmaMutex; std::string gDatabasePragmas; }
+extern "C" void afec_crawl_set_database_pragmas(const char* pragmas) {
+  std::lock_guard<std::mutex> Lock(gPragmaMutex);
+  gDatabasePragmas = pragmas ? pragmas : "";
+}
+
 extern "C" int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
                                       const int32_t* devices, int32_t n_devices, int32_t workers_per_device,
                                       int32_t files_per_batch, const char* database_path, double* stats, char* error,
@@ -437,6 +443,10 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     if (files_per_batch > 0) Options.mFilesPerBatch = files_per_batch;
     if (database_path) Options.mDatabasePath = database_path;
     if (gBytesPerBatch > 0) Options.mBytesPerBatch = gBytesPerBatch;
+    {
+      std::lock_guard<std::mutex> Lock(gPragmaMutex);
+      Options.mDatabasePragmas = gDatabasePragmas;
+    }
     // one crawler per (devices, geometry), kept between calls
     // (the registry lock is held for the whole crawl: afec_crawl_release cannot delete a crawler that is in use, and
     // crawls through this entry point run one at a time)

@@ -38,6 +38,7 @@ struct TCrawlOptions {
   int64_t mBytesPerBatch = 128 << 20;  // a batch also ends before the file that takes it over this many file bytes (a
                                     // 16-bit mono file needs ~10 x its size in device memory: PCM as doubles, spectra)
   std::string mDatabasePath;        // empty: results are counted, not stored
+  std::string mDatabasePragmas;     // run when the database is opened ("" = sqlite's defaults, like the reference; SqlitePool.h)
   int mSampleRate = 44100, mFftFrameSize = 2048, mHopFrameSize = 1024;
   // Runtime knobs the crawler applies itself, to its own plans only (libafx_hip.so changes nothing process-wide):
   // * the HIP runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and the
@@ -109,4 +110,6 @@ int afec_shard_of_file(int64_t file_index, int32_t n_devices);
 void afec_crawl_release(void);
 // TCrawlOptions::mBytesPerBatch of the crawls that follow (0: the default)
 void afec_crawl_set_bytes_per_batch(int64_t bytes);
+// TCrawlOptions::mDatabasePragmas of the crawls that follow (NULL or "": none)
+void afec_crawl_set_database_pragmas(const char* pragmas);
 }

@@ -75,7 +75,7 @@ struct TSqliteSampleDescriptorPool::TImpl {
   }
 };
 
-TSqliteSampleDescriptorPool::TSqliteSampleDescriptorPool(const std::string& DatabasePath) : mpImpl(new TImpl) {
+TSqliteSampleDescriptorPool::TSqliteSampleDescriptorPool(const std::string& DatabasePath, const std::string& Pragmas) : mpImpl(new TImpl) {
   TSqliteApi& A = mpImpl->mApi;
   A.mpLibrary = dlopen("libsqlite3.so.0", RTLD_NOW | RTLD_LOCAL);
   if (!A.mpLibrary) {
@@ -98,6 +98,7 @@ TSqliteSampleDescriptorPool::TSqliteSampleDescriptorPool(const std::string& Data
     Resolve(A.mpLibrary, "sqlite3_finalize", A.finalize);
     Resolve(A.mpLibrary, "sqlite3_errmsg", A.errmsg);
     mpImpl->Check(A.open(DatabasePath.c_str(), &mpImpl->mpDatabase), "sqlite3_open");
+    if (!Pragmas.empty()) mpImpl->Execute(Pragmas);
     mpImpl->mSchema = LowLevelSchema();
     // TSqliteSampleDescriptorPool::InitializeDatabase (SqliteSampleDescriptorPool.cpp:1224-1358): an existing assets
     // table is kept only at the current version; a newer database is refused, an older one is thrown away
@@ -117,6 +118,7 @@ TSqliteSampleDescriptorPool::TSqliteSampleDescriptorPool(const std::string& Data
         mpImpl->mpDatabase = nullptr;
         const bool DeleteSucceeded = (::unlink(DatabasePath.c_str()) == 0);
         mpImpl->Check(A.open(DatabasePath.c_str(), &mpImpl->mpDatabase), "sqlite3_open (upgrade)");
+        if (!Pragmas.empty()) mpImpl->Execute(Pragmas);
         if (!DeleteSucceeded) {
           mpImpl->Execute("DROP table 'assets'");
           mpImpl->Execute("VACUUM");

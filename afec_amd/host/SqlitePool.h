@@ -25,7 +25,11 @@ struct TFileProperties {
 
 class TSqliteSampleDescriptorPool {
 public:
-  explicit TSqliteSampleDescriptorPool(const std::string& DatabasePath);
+  // Pragmas: statements run right after the database is opened, before any table exists ("" = none: sqlite's defaults,
+  // like the reference).  They tune how sqlite writes, not what: e.g. "PRAGMA page_size=65536; PRAGMA
+  // journal_mode=MEMORY; PRAGMA synchronous=OFF" (rows of ~68 KB otherwise span 17 overflow pages of 4 KB; the
+  // rollback journal and the fsync per commit go away) -- the file stays a plain sqlite database with the same table.
+  explicit TSqliteSampleDescriptorPool(const std::string& DatabasePath, const std::string& Pragmas = std::string());
   ~TSqliteSampleDescriptorPool();
   TSqliteSampleDescriptorPool(const TSqliteSampleDescriptorPool&) = delete;
   TSqliteSampleDescriptorPool& operator=(const TSqliteSampleDescriptorPool&) = delete;

@@ -79,3 +79,11 @@ def set_bytes_per_batch(n_bytes):
     L.afec_crawl_set_bytes_per_batch.restype = None
     L.afec_crawl_set_bytes_per_batch.argtypes = [ctypes.c_int64]
     L.afec_crawl_set_bytes_per_batch(int(n_bytes))
+
+
+def set_database_pragmas(pragmas):
+    """TCrawlOptions::mDatabasePragmas of the crawls that follow ("" or None: sqlite's defaults, like the reference)."""
+    L = lib()
+    L.afec_crawl_set_database_pragmas.restype = None
+    L.afec_crawl_set_database_pragmas.argtypes = [ctypes.c_char_p]
+    L.afec_crawl_set_database_pragmas(pragmas.encode() if pragmas else None)

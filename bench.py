@@ -392,6 +392,14 @@ def main():
                 e2e["files_per_s_with_database"] = sd["files"] / sd["seconds"]
                 e2e["database_writer_files_per_s"] = sd["files"] / sd["writer_seconds"] if sd["writer_seconds"] else None
                 e2e["database"] = "sqlite `assets` table on tmpfs, 4096 files, best of 2 (INSERT OR REPLACE into the same file)"
+                # the same with TCrawlOptions::mDatabasePragmas: 64 KiB pages, journal in memory, no fsync per commit
+                from afec_amd import hostlib
+                try:
+                    hostlib.set_database_pragmas("PRAGMA page_size=65536; PRAGMA journal_mode=MEMORY; PRAGMA synchronous=OFF")
+                    sp = end_to_end("c4", 4096, device, 8, 99, database=os.path.join(td, "afec-ll-tuned.db"), repeats=2, files_per_batch=512)
+                    e2e["files_per_s_with_database_pragmas"] = sp["files"] / sp["seconds"]
+                finally:
+                    hostlib.set_database_pragmas("")
         except Exception as e:  # noqa: BLE001  (the headline must not depend on the host library)
             e2e = dict(e2e or {}, error=str(e))
 

@@ -131,8 +131,8 @@ static int WriteDatabase(const char* pPath) {
 
 // rows per second of the writer alone (no GPU): argv[2] = database path, argv[3] = rows, argv[4] = rows per transaction
 // (0: one transaction per row, the reference's way)
-static int WriterRate(const char* pPath, int Rows, int PerTransaction) {
-  afec::TSqliteSampleDescriptorPool Pool(pPath);
+static int WriterRate(const char* pPath, int Rows, int PerTransaction, const char* pPragmas) {
+  afec::TSqliteSampleDescriptorPool Pool(pPath, pPragmas ? pPragmas : "");
   afec::TSampleDescriptors D = SyntheticDescriptors();
   // a one-second file's worth of frames in every series
   const size_t Frames = 40;
@@ -302,7 +302,7 @@ int main(int argc, char** argv) {
     if (argc >= 2 && !std::strcmp(argv[1], "nodevice")) rc = TestNoDevice();
     else if (argc >= 3 && !std::strcmp(argv[1], "columns")) rc = DumpColumns(argv[2]);
     else if (argc >= 3 && !std::strcmp(argv[1], "sqlite")) rc = WriteDatabase(argv[2]);
-    else if (argc >= 5 && !std::strcmp(argv[1], "writer_rate")) rc = WriterRate(argv[2], std::atoi(argv[3]), std::atoi(argv[4]));
+    else if (argc >= 5 && !std::strcmp(argv[1], "writer_rate")) rc = WriterRate(argv[2], std::atoi(argv[3]), std::atoi(argv[4]), argc >= 6 ? argv[5] : nullptr);
     else if (argc >= 2 && !std::strcmp(argv[1], "analyse")) rc = TestAnalyse();
   } catch (const std::exception& e) {
     std::printf("EXCEPTION: %s\n", e.what());

@@ -230,3 +230,22 @@ def test_crawl_is_sharded_over_devices():
     assert two["files_per_device"] == [(len(images) + 1) // 2, len(images) // 2]
     for k in ("files", "failed", "frames"):
         assert one[k] == two[k]
+
+
+def test_database_pragmas_change_how_sqlite_writes_not_what(tmp_path):
+    """TCrawlOptions::mDatabasePragmas (larger pages, journal in memory, no fsync per commit: about twice the writer's
+    rate): the same rows, a plain sqlite file."""
+    from afec_amd import hostlib
+    images, names, _ = make_crawl(40)
+    dbs = [str(tmp_path / "default.db"), str(tmp_path / "tuned.db")]
+    _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=16, database=dbs[0])
+    try:
+        hostlib.set_database_pragmas("PRAGMA page_size=65536; PRAGMA journal_mode=MEMORY; PRAGMA synchronous=OFF")
+        _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=16, database=dbs[1])
+    finally:
+        hostlib.set_database_pragmas("")
+    a, b = rows_by_hash(dbs[0]), rows_by_hash(dbs[1])
+    assert len(a) == len(images) - 1 and a == b
+    con = sqlite3.connect(dbs[1])
+    assert con.execute("PRAGMA page_size").fetchone()[0] == 65536 and con.execute("PRAGMA user_version").fetchone()[0] == 2
+    con.close()

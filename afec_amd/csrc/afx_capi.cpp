@@ -1022,12 +1022,15 @@ inline long long now_ns() {
 // alternatives did not serve: hipEventBlockingSync alone changes nothing here (the eight workers of a crawl still keep
 // 6.6 CPUs busy), and hipDeviceScheduleBlockingSync, set on a device that is already active, left a later
 // hipStreamSynchronize hanging.
+constexpr int kNapCeilingUs = 300;
 hipError_t wait_for_event(Workspace* ws, hipEvent_t ev) {
   if (!ws->blocking) return hipEventSynchronize(ev);
-  for (;;) {
+  // naps grow from 20 us to kNapCeilingUs: what a crawl waits for takes milliseconds (an upload 1.6 ms, a batch's
+  // kernels 10+ ms), other batches are in flight meanwhile, and every poll is a system call + a wake-up
+  for (int nap = 20;; nap = std::min(nap + nap / 2, kNapCeilingUs)) {
     const hipError_t e = hipEventQuery(ev);
     if (e != hipErrorNotReady) return e;
-    std::this_thread::sleep_for(std::chrono::microseconds(20));
+    std::this_thread::sleep_for(std::chrono::microseconds(nap));
   }
 }
 hipError_t wait_for_stream(Workspace* ws, hipStream_t stream) {

@@ -33,6 +33,12 @@ double ProcessCpuSeconds() {
   return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
 
+double ThreadCpuSeconds() {
+  timespec t;
+  ::clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t);
+  return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
+}
+
 // page-locked host memory (afx_host_alloc), grown on demand
 struct TPinned {
   void* mp = nullptr;
@@ -44,6 +50,17 @@ struct TPinned {
     mBytes = Bytes + Bytes / 4;
     mp = afx_host_alloc((int64_t)mBytes);
     if (!mp) { mBytes = 0; throw TReadableException("page-locked host memory exhausted"); }
+  }
+  // the same, keeping the first Used bytes
+  void Grow(size_t Bytes, size_t Used) {
+    if (Bytes <= mBytes) return;
+    const size_t NewBytes = Bytes + Bytes / 4;
+    void* pNew = afx_host_alloc((int64_t)NewBytes);
+    if (!pNew) throw TReadableException("page-locked host memory exhausted");
+    if (Used) std::memcpy(pNew, mp, Used);
+    afx_host_free(mp);
+    mp = pNew;
+    mBytes = NewBytes;
   }
 };
 
@@ -198,6 +215,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   Total.mFilesPerDevice.assign((size_t)G, 0);
   double PhaseSeconds[2] = {0, 0};   // summed over workers: parse + staging copy, GPU round trip
   double GpuSeconds[3] = {0, 0, 0};  // of the round trip: upload + LoadSample, kernels enqueue, download + wait
+  double PhaseCpuSeconds[3] = {0, 0, 0};   // CPU time of the threads: workers parse + staging, workers GPU round trip, writer
   std::mutex StatMutex;
   TBoundedQueue Queue((size_t)(2 * G * W));
   std::atomic<bool> Abort(false);
@@ -212,19 +230,17 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
         ~TStagingLease() { mPool.Release(std::move(mp)); }
       } Lease{StagingPool, StagingPool.Acquire(0)};
       TPinned& Staging = *Lease.mp;
-      std::vector<std::unique_ptr<TWaveFile>> Waves;
-      std::vector<std::vector<unsigned char>> Widened;
       for (;;) {
         if (Abort) return;
         // the next FilesPerBatch files of the shard, or fewer when their bytes reach the batch's budget (long files:
         // the staging buffer, the device workspace and the result buffers all scale with the PCM of a batch)
         size_t Begin, End;
+        int64_t BatchBytes = 0;
         {
           std::lock_guard<std::mutex> Lock(CursorMutex[(size_t)d]);
           const std::vector<const TCrawlFile*>& Mine = Shard[(size_t)d];
           Begin = End = Cursor[(size_t)d];
           if (Begin >= Mine.size()) return;
-          int64_t BatchBytes = 0;
           while (End < Mine.size() && End - Begin < (size_t)FilesPerBatch) {
             const int64_t Size = FileBytes(*Mine[End]);
             if (End > Begin && BatchBytes + Size > BytesPerBatch) break;
@@ -242,47 +258,47 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
         Done.mSkipped.assign(n, 0);
         Done.mBatchIndex.assign(n, -1);
         // parse; lay the data chunks out in the page-locked staging buffer
-        const double tParse0 = Now();
-        Waves.clear();
-        Widened.assign(n, std::vector<unsigned char>());
+        const double tParse0 = Now(), cParse0 = ThreadCpuSeconds();
+        // Every file's samples go straight to their place in the page-locked staging buffer (the device arena's layout:
+        // payloads back to back, 16-byte aligned, so that the C-ABI uploads the batch in one transfer): a memcpy out of
+        // a file image, a pread out of the page cache for a file on disk.  The buffer is sized from the files' sizes
+        // up front; only 8-bit files (widened to int16) can make it grow on the way.
         std::vector<TDecodedSample> Decoded;
         std::vector<size_t> Offset;
         size_t Bytes = 0;
         int64_t PcmBytes = 0;
+        Staging.Reserve((size_t)BatchBytes + 16 * n + 64);
+        TWaveFile Wave;
         for (size_t i = 0; i < n; ++i) {
-          Waves.emplace_back(new TWaveFile);
           try {
             const TCrawlFile& f = *Done.mFiles[i];
-            if (f.mpImage) Waves[i]->OpenForRead(f.mpImage, f.mImageSize, f.mFileName);
-            else Waves[i]->OpenForRead(f.mFileName);
-            if (Waves[i]->SamplingRate() != Options.mSampleRate) { Done.mSkipped[i] = 1; continue; }
-            TDecodedSample s = Waves[i]->DecodedSample(Widened[i]);
+            if (f.mpImage) Wave.OpenForRead(f.mpImage, f.mImageSize, f.mFileName);
+            else Wave.OpenForRead(f.mFileName);
+            if (Wave.SamplingRate() != Options.mSampleRate) { Done.mSkipped[i] = 1; Wave.Close(); continue; }
+            TDecodedSample s = Wave.DescribeSample();
+            const size_t Size = Wave.SampleDataBytes();
+            if (Bytes + Size + 64 > Staging.mBytes) Staging.Grow(Bytes + Size + 64, Bytes);
+            Wave.ReadSampleData((char*)Staging.mp + Bytes);
+            Wave.Close();
             TFileProperties& p = Done.mProperties[i];
             p.mFileType = "wav";
-            p.mFileSize = (int)Waves[i]->FileSizeInBytes();
-            p.mFileLength = (double)Waves[i]->NumSamples() / (double)Waves[i]->SamplingRate();
-            p.mFileSampleRate = Waves[i]->SamplingRate();
-            p.mFileChannelCount = Waves[i]->NumChannels();
-            p.mFileBitDepth = Waves[i]->BitsPerSample();
-            const size_t bps = s.mFormat == AFX_RAW_I16 ? 2 : (s.mFormat == AFX_RAW_I24 ? 3 : (s.mFormat == AFX_RAW_F64 ? 8 : 4));
-            const size_t Size = (size_t)s.mNumberOfSampleFrames * (size_t)s.mNumberOfChannels * bps;
+            p.mFileSize = (int)Wave.FileSizeInBytes();
+            p.mFileLength = (double)Wave.NumSamples() / (double)Wave.SamplingRate();
+            p.mFileSampleRate = Wave.SamplingRate();
+            p.mFileChannelCount = Wave.NumChannels();
+            p.mFileBitDepth = Wave.BitsPerSample();
             Done.mBatchIndex[i] = (int)Decoded.size();
             Decoded.push_back(s);
             Offset.push_back(Bytes);
-            Bytes += (Size + 15) & ~(size_t)15;   // the device arena's layout: the C-ABI then uploads the batch in one transfer
+            Bytes += (Size + 15) & ~(size_t)15;
             PcmBytes += (int64_t)Size;
           } catch (const TReadableException& e) {
+            Wave.Close();
             Done.mFailed[i] = e.what();
           }
         }
-        Staging.Reserve(Bytes + 64);
-        for (size_t k = 0; k < Decoded.size(); ++k) {
-          const size_t bps = Decoded[k].mFormat == AFX_RAW_I16 ? 2 : (Decoded[k].mFormat == AFX_RAW_I24 ? 3 : (Decoded[k].mFormat == AFX_RAW_F64 ? 8 : 4));
-          const size_t Size = (size_t)Decoded[k].mNumberOfSampleFrames * (size_t)Decoded[k].mNumberOfChannels * bps;
-          std::memcpy((char*)Staging.mp + Offset[k], Decoded[k].mpInterleavedSamples, Size);
-          Decoded[k].mpInterleavedSamples = (char*)Staging.mp + Offset[k];
-        }
-        const double tGpu0 = Now();
+        for (size_t k = 0; k < Decoded.size(); ++k) Decoded[k].mpInterleavedSamples = (char*)Staging.mp + Offset[k];
+        const double tGpu0 = Now(), cGpu0 = ThreadCpuSeconds();
         // GPU: LoadSample + descriptors + statistics; results straight into page-locked buffers
         int64_t Frames = 0, ResultBytes = 0;
         if (!Decoded.empty()) {
@@ -313,11 +329,13 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
               Done.mFailed[i] = std::string(afx_status_str(Done.mResults.mStatus[(size_t)k]));
           }
         }
-        const double tGpu1 = Now();
+        const double tGpu1 = Now(), cGpu1 = ThreadCpuSeconds();
         {
           std::lock_guard<std::mutex> Lock(StatMutex);
           PhaseSeconds[0] += tGpu0 - tParse0;
           PhaseSeconds[1] += tGpu1 - tGpu0;
+          PhaseCpuSeconds[0] += cGpu0 - cParse0;
+          PhaseCpuSeconds[1] += cGpu1 - cGpu0;
           for (int k = 0; k < 3; ++k) GpuSeconds[k] += Done.mResults.mSeconds[k];
           Total.mFiles += (int64_t)n;
           Total.mBatches += 1;
@@ -338,7 +356,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   // the single writer (SampleAnalyser.cpp:413-415: one mutex around the pool)
   std::thread Writer([&] {
     while (std::unique_ptr<TFinishedBatch> p = Queue.Pop()) {
-      const double t0 = Now();
+      const double t0 = Now(), c0 = ThreadCpuSeconds();
       int64_t Failed = 0, Skipped = 0;
       try {
         if (pPool) pPool->BeginTransaction();     // one commit per batch of files; the rows are those of one commit per file
@@ -380,6 +398,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
       Total.mFailedFiles += Failed;
       Total.mSkippedSampleRateFiles += Skipped;
       if (pPool) Total.mWriterSeconds += Now() - t0;
+      PhaseCpuSeconds[2] += ThreadCpuSeconds() - c0;
     }
   });
 
@@ -399,6 +418,10 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   if (std::getenv("AFEC_CRAWL_TIMING"))
     std::fprintf(stderr, "[afec crawl]   round trip = create (upload, LoadSample) %.1f ms + enqueue %.1f ms + fetch (wait, download) %.1f ms\n",
                  GpuSeconds[0] * 1e3, GpuSeconds[1] * 1e3, GpuSeconds[2] * 1e3);
+  if (std::getenv("AFEC_CRAWL_TIMING"))
+    std::fprintf(stderr, "[afec crawl]   CPU %.1f ms (%.2f busy CPUs): workers parse + staging %.1f ms, workers GPU round trip %.1f ms, writer %.1f ms, other threads %.1f ms\n",
+                 Total.mCpuSeconds * 1e3, Total.mCpuSeconds / Total.mSeconds, PhaseCpuSeconds[0] * 1e3, PhaseCpuSeconds[1] * 1e3,
+                 PhaseCpuSeconds[2] * 1e3, (Total.mCpuSeconds - PhaseCpuSeconds[0] - PhaseCpuSeconds[1] - PhaseCpuSeconds[2]) * 1e3);
   if (!FirstError.empty()) throw TReadableException(FirstError);
   return Total;
 }
@@ -478,19 +501,35 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
   }
 }
 
+namespace {
+int WaveProbe(afec::TWaveFile& Wave, int64_t* props, void* payload, int64_t payload_capacity) {
+  const afec::TDecodedSample s = Wave.DescribeSample();
+  const int64_t Bytes = (int64_t)Wave.SampleDataBytes();
+  props[0] = Wave.NumChannels(); props[1] = Wave.SamplingRate(); props[2] = Wave.BitsPerSample();
+  props[3] = (int64_t)Wave.SampleType(); props[4] = Wave.NumSamples(); props[5] = s.mFormat; props[6] = Bytes;
+  if (payload && Bytes <= payload_capacity) Wave.ReadSampleData(payload);
+  return 0;
+}
+}  // namespace
+
 extern "C" int afec_wave_probe(const void* image, int64_t size, int64_t* props, void* payload, int64_t payload_capacity,
                                char* error, int32_t error_size) {
   try {
     afec::TWaveFile Wave;
     Wave.OpenForRead(image, (size_t)size);
-    std::vector<unsigned char> Storage;
-    const afec::TDecodedSample s = Wave.DecodedSample(Storage);
-    const int64_t bps = s.mFormat == AFX_RAW_I16 ? 2 : (s.mFormat == AFX_RAW_I24 ? 3 : (s.mFormat == AFX_RAW_F64 ? 8 : 4));
-    const int64_t Bytes = s.mNumberOfSampleFrames * s.mNumberOfChannels * bps;
-    props[0] = Wave.NumChannels(); props[1] = Wave.SamplingRate(); props[2] = Wave.BitsPerSample();
-    props[3] = (int64_t)Wave.SampleType(); props[4] = Wave.NumSamples(); props[5] = s.mFormat; props[6] = Bytes;
-    if (payload && Bytes <= payload_capacity) std::memcpy(payload, s.mpInterleavedSamples, (size_t)Bytes);
-    return 0;
+    return WaveProbe(Wave, props, payload, payload_capacity);
+  } catch (const std::exception& e) {
+    if (error && error_size > 0) std::snprintf(error, (size_t)error_size, "%s", e.what());
+    return -1;
+  }
+}
+
+extern "C" int afec_wave_probe_file(const char* path, int64_t* props, void* payload, int64_t payload_capacity, char* error,
+                                    int32_t error_size) {
+  try {
+    afec::TWaveFile Wave;
+    Wave.OpenForRead(std::string(path));
+    return WaveProbe(Wave, props, payload, payload_capacity);
   } catch (const std::exception& e) {
     if (error && error_size > 0) std::snprintf(error, (size_t)error_size, "%s", e.what());
     return -1;

@@ -93,7 +93,8 @@ private:
 }  // namespace afec
 
 extern "C" {
-// C entry point of CrawlWaveFiles for callers without C++ (bench.py, tests): file images in memory.  The process keeps
+// C entry point of CrawlWaveFiles for callers without C++ (bench.py, tests): file images in memory, or -- images ==
+// NULL -- files on disk, names[i] being their paths.  The process keeps
 // one TCrawler per (devices, geometry) between calls (afec_crawl_release drops them), so a second crawl starts warm.
 // stats: [files, failed, frames, pcm_bytes, result_bytes, seconds, writer_seconds, batches, files on device 0, 1, ...,
 // cpu_seconds, files skipped for their sampling rate] (8 + n_devices + 2 doubles);
@@ -106,6 +107,9 @@ int afec_crawl_wave_images(const char* const* names, const void* const* images, 
 // (8-bit files widened to int16) is copied there (payload_capacity bytes).  Returns 0, or -1 with the reader's message.
 int afec_wave_probe(const void* image, int64_t size, int64_t* props /* [7] */, void* payload, int64_t payload_capacity,
                     char* error, int32_t error_size);
+// the same for a file on disk (TWaveFile::OpenForRead(FileName): head parsed, data chunk read by pread)
+int afec_wave_probe_file(const char* path, int64_t* props /* [7] */, void* payload, int64_t payload_capacity, char* error,
+                         int32_t error_size);
 int afec_shard_of_file(int64_t file_index, int32_t n_devices);
 void afec_crawl_release(void);
 // TCrawlOptions::mBytesPerBatch of the crawls that follow (0: the default)

@@ -18,6 +18,8 @@ def lib():
         L = ctypes.CDLL(os.path.join(ROOT, "afec_amd", "lib", "libafx_host.so"))
         L.afec_wave_probe.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
                                       ctypes.c_int64, ctypes.c_char_p, ctypes.c_int32]
+        L.afec_wave_probe_file.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p, ctypes.c_int64,
+                                           ctypes.c_char_p, ctypes.c_int32]
         L.afec_shard_of_file.argtypes = [ctypes.c_int64, ctypes.c_int32]
         L.afec_crawl_wave_images.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_void_p),
                                              ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
@@ -42,15 +44,32 @@ def wave_probe(image):
     return d, payload[:d["payload_bytes"]].tobytes()
 
 
-def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, database=None):
-    """images: list of bytes (WAV file images).  -> dict of statistics."""
+def wave_probe_file(path):
+    """wave_probe for a file on disk (the reader parses the head and reads the data chunk by pread)."""
     L = lib()
-    n = len(images)
+    props = (ctypes.c_int64 * 7)()
+    err = ctypes.create_string_buffer(256)
+    payload = np.zeros(2 * (os.path.getsize(path) if os.path.isfile(path) else 0) + 16, dtype=np.uint8)
+    rc = L.afec_wave_probe_file(str(path).encode(), props, payload.ctypes.data, payload.size, err, 256)
+    if rc != 0:
+        raise RuntimeError(err.value.decode())
+    keys = ["channels", "rate", "bits", "sample_type", "frames", "raw_format", "payload_bytes"]
+    d = dict(zip(keys, [int(v) for v in props]))
+    return d, payload[:d["payload_bytes"]].tobytes()
+
+
+def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, database=None):
+    """images: list of bytes (WAV file images), or None: names are the paths of files on disk.  -> dict of statistics."""
+    L = lib()
+    n = len(images) if images is not None else len(names)
     names = names or [f"file{i:06d}.wav" for i in range(n)]
-    keep = [np.frombuffer(b, dtype=np.uint8) for b in images]
     c_names = (ctypes.c_char_p * n)(*[s.encode() for s in names])
-    c_images = (ctypes.c_void_p * n)(*[k.ctypes.data for k in keep])
-    c_sizes = (ctypes.c_int64 * n)(*[len(b) for b in images])
+    if images is not None:
+        keep = [np.frombuffer(b, dtype=np.uint8) for b in images]
+        c_images = (ctypes.c_void_p * n)(*[k.ctypes.data for k in keep])
+        c_sizes = (ctypes.c_int64 * n)(*[len(b) for b in images])
+    else:
+        c_images = c_sizes = None
     c_dev = (ctypes.c_int32 * len(devices))(*devices)
     stats = (ctypes.c_double * (10 + len(devices)))()
     err = ctypes.create_string_buffer(512)

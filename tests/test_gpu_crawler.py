@@ -249,3 +249,29 @@ def test_database_pragmas_change_how_sqlite_writes_not_what(tmp_path):
     con = sqlite3.connect(dbs[1])
     assert con.execute("PRAGMA page_size").fetchone()[0] == 65536 and con.execute("PRAGMA user_version").fetchone()[0] == 2
     con.close()
+
+
+def test_files_on_disk_give_the_rows_of_their_images(tmp_path):
+    """The crawler reads files on disk itself (TCrawlFile::mpImage == nullptr: head parsed, data chunk pread into the
+    page-locked staging buffer): the same rows as for the same bytes handed over as images under the same names; a
+    path that does not exist becomes a failed sample with the reference's text (RiffFile.cpp:128-131)."""
+    images, names, _ = make_crawl(60)
+    paths = []
+    for name, image in zip(names, images):
+        p = tmp_path / "files" / name
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(image)
+        paths.append(str(p))
+    dbs = [str(tmp_path / "images.db"), str(tmp_path / "disk.db")]
+    from_images = _host.crawl(images, paths, workers=2, files_per_batch=16, database=dbs[0])
+    from_disk = _host.crawl(None, paths + [str(tmp_path / "files" / "gone.wav")], workers=2, files_per_batch=16, database=dbs[1])
+    assert from_disk["files"] == from_images["files"] + 1 and from_disk["failed"] == from_images["failed"] + 1
+    for k in ("frames", "pcm_bytes", "skipped_sample_rate"):
+        assert from_disk[k] == from_images[k], k
+    a, b = rows_by_hash(dbs[0]), rows_by_hash(dbs[1])
+    gone = b.pop(str(tmp_path / "files" / "gone.wav"))
+    assert gone and a == b and len(a) == len(images) - 1
+    con = sqlite3.connect(dbs[1])
+    status = con.execute("SELECT status FROM assets WHERE filename = ?", (str(tmp_path / "files" / "gone.wav"),)).fetchone()[0]
+    con.close()
+    assert "Failed to open the file" in status

@@ -71,6 +71,42 @@ def test_odd_chunks_extensible_headers_and_truncated_data():
     props, payload = _host.wave_probe(cut)
     assert props["frames"] == (len(cut) - 44) // 4 and payload == x.tobytes()[:props["frames"] * 4]
 
+def test_files_on_disk_read_like_their_images(tmp_path):
+    """TWaveFile::OpenForRead(FileName) parses the file's head and reads the data chunk by pread (what the crawler does
+    for files on disk: straight into its staging buffer); it must see exactly what the image reader sees -- all sample
+    types, a data chunk behind the 4 KiB head (a large chunk in front of it), files shorter than the head, and the
+    same error texts."""
+    z = np.load(GOLD)
+    images = {name: z["wav_" + name].tobytes() for name in NAMES}
+    x = (np.arange(30000) % 251 - 125).astype(np.int16)
+    plain = wav_bytes(x, 2, 16)
+    images["big_chunk_first"] = plain[:36] + b"LIST" + struct.pack("<I", 10000) + bytes(10000) + plain[36:]
+    images["u8_behind_head"] = wav_bytes(((np.arange(9001) * 7) % 256).astype(np.uint8), 1, 8)
+    images["tiny"] = wav_bytes(x[:10], 1, 16)
+    images["truncated"] = plain[:-1000]
+    fixtures = os.path.join(os.path.dirname(__file__), "golden", "wav")
+    for f in sorted(os.listdir(fixtures)):
+        if f.endswith(".wav") and not f.startswith("_"):
+            images["fixture_" + f] = open(os.path.join(fixtures, f), "rb").read()
+    for name, image in images.items():
+        path = tmp_path / (name + ".wav")
+        path.write_bytes(image)
+        assert _host.wave_probe_file(path) == _host.wave_probe(image), name
+    for k, image in enumerate([b"", b"RIFF", b"this is not a wave file, just some text that is long enough to be walked as chunks........",
+                               plain.replace(b"data", b"dat_"), plain[:20] + struct.pack("<H", 2) + plain[22:]]):
+        path = tmp_path / f"bad{k}.wav"
+        path.write_bytes(image)
+        with pytest.raises(RuntimeError) as from_file:
+            _host.wave_probe_file(path)
+        with pytest.raises(RuntimeError) as from_image:
+            _host.wave_probe(image)
+        assert str(from_file.value) == str(from_image.value)
+    with pytest.raises(RuntimeError) as ei:
+        _host.wave_probe_file(tmp_path / "missing.wav")
+    assert str(ei.value) == f"Failed to open the file '{tmp_path / 'missing.wav'}'."
+    with pytest.raises(RuntimeError):
+        _host.wave_probe_file(tmp_path)                       # a directory
+
 
 def test_shard_assignment():
     """File i of a crawl goes to device i mod G (one self-contained task per file, Crawler.cpp:706-728)."""

@@ -63,7 +63,7 @@ EXPORTS = [
     "afx_batch_set_file_info", "afx_batch_rhythm_frames", "afx_batch_fetch_rhythm", "afx_batch_fetch_onset_functions",
     "afx_plan_set_blocking_wait",
 ]
-RAW_I16, RAW_I24, RAW_F32 = 0, 1, 2
+RAW_I16, RAW_I24, RAW_F32, RAW_I32, RAW_F64 = 0, 1, 2, 3, 4
 
 # afx_out fields: name -> width per frame, in declaration order
 OUT_FIELDS = [
@@ -326,8 +326,9 @@ class Plan:
         return Batch(self, bufs, mask)
 
     def batch_from_raw(self, raws, mask=D_ALL_LOW_LEVEL):
-        """raws: list of (array, channels[, sample_rate]); array dtype int16 / float32 (interleaved,
-        shape [frames*channels] or [frames, channels]) or uint8 of packed 24-bit little-endian samples.
+        """raws: list of (array, channels[, sample_rate]); array dtype int16 / int32 / float32 / float64 (interleaved,
+        shape [frames*channels] or [frames, channels]) or uint8 of packed 24-bit little-endian samples; files at another
+        sample_rate than the plan's are converted on the GPU (SampleAnalyser.cpp:563-607).
         Returns (Batch, list of load-info dicts): the LoadSample front end on the GPU."""
         n = len(raws)
         arr = (_Raw * max(1, n))()
@@ -342,8 +343,12 @@ class Plan:
                 fmt, frames = RAW_F32, data.size // max(channels, 1)
             elif data.dtype == np.uint8:
                 fmt, frames = RAW_I24, data.size // (3 * max(channels, 1))
+            elif data.dtype == np.int32:
+                fmt, frames = RAW_I32, data.size // max(channels, 1)
+            elif data.dtype == np.float64:
+                fmt, frames = RAW_F64, data.size // max(channels, 1)
             else:
-                raise TypeError("raw PCM must be int16, float32 or uint8 (packed int24)")
+                raise TypeError("raw PCM must be int16, int32, float32, float64 or uint8 (packed int24)")
             keep.append(data)
             arr[i].data = data.ctypes.data if data.size else None
             arr[i].format, arr[i].channels, arr[i].sample_rate, arr[i].n_frames = fmt, channels, rate, frames

@@ -144,6 +144,8 @@ struct DeviceTables {
   double* rt_ut = nullptr;
   double* rt_canny = nullptr;
   double* rt_rayleigh = nullptr;
+  // sample-rate conversion (afx_resample.hip): uploaded by the first batch that holds a file at another rate
+  float* rs_filter = nullptr;
 };
 
 }  // namespace
@@ -168,10 +170,11 @@ struct Workspace {
   Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff, rt_long, rt_polar;   // rhythm tracker
   Buf stat_tmp;                                                                 // half-wave statistics class
+  Buf rs_files, rs_groups, rs_ngroups;                                          // sample-rate conversion (afx_resample.hip)
   size_t bytes() const {
     return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
            efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap + queue.cap + rt_files.cap + rt_long.cap + rt_polar.cap + rt_odf.cap +
-           rt_onsets.cap + rt_scratch.cap + rt_scalars.cap + rt_stats.cap + rt_foff.cap + stat_tmp.cap;
+           rt_onsets.cap + rt_scratch.cap + rt_scalars.cap + rt_stats.cap + rt_foff.cap + stat_tmp.cap + rs_files.cap + rs_groups.cap + rs_ngroups.cap;
   }
 };
 
@@ -235,6 +238,7 @@ struct afx_batch {
   std::vector<afx::RhythmFile> rt_files;   // [n_bufs]
   std::vector<int64_t> file_samples;       // [n_bufs]: mOriginalNumberOfSamples default (the buffer's / file's own length)
   std::vector<int32_t> file_offset;        // [n_bufs]: mDataOffset default
+  std::vector<int32_t> file_rate;          // [n_bufs]: mOriginalSampleRate default (0: the plan's rate)
   bool rt_files_dirty = false;
   afx::RhythmFile* d_rt_files = nullptr;
   // long files of a small batch (afx_rhythm.hip): [n_long] file indices, [n_long + 1] round offsets (int32), [n_long + 1]
@@ -399,6 +403,7 @@ void free_tables(afx_plan* p) {
   hipFree(p->dev.melw); hipFree(p->dev.dct);
   hipFree(p->dev.win32); hipFree(p->dev.tw32); hipFree(p->dev.post32); hipFree(p->dev.melw32);
   hipFree(p->dev.rt_window); hipFree(p->dev.rt_tw); hipFree(p->dev.rt_ut); hipFree(p->dev.rt_canny); hipFree(p->dev.rt_rayleigh);
+  hipFree(p->dev.rs_filter);
   p->dev = DeviceTables{};
 }
 
@@ -406,7 +411,8 @@ void ws_free(Workspace* w) {
   if (!w) return;
   for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
                             &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place, &w->queue, &w->rt_files, &w->rt_long, &w->rt_polar, &w->rt_odf,
-                            &w->rt_onsets, &w->rt_scratch, &w->rt_scalars, &w->rt_stats, &w->rt_foff, &w->stat_tmp}) hipFree(b->p);
+                            &w->rt_onsets, &w->rt_scratch, &w->rt_scalars, &w->rt_stats, &w->rt_foff, &w->stat_tmp, &w->rs_files, &w->rs_groups,
+                            &w->rs_ngroups}) hipFree(b->p);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->ev_fork) hipEventDestroy(w->ev_fork);
@@ -712,7 +718,8 @@ namespace {
 // is float arithmetic (AudioMath.inl:134-137) and the division by the int 1000 stays in float
 void set_rhythm_context(afx_batch* b, const afx_file_info* info) {
   for (int32_t i = 0; i < b->n_bufs; ++i) {
-    const int rate = (info && info[i].original_sample_rate > 0) ? info[i].original_sample_rate : b->plan->desc.sample_rate;
+    const int own_rate = (i < (int32_t)b->file_rate.size() && b->file_rate[(size_t)i] > 0) ? b->file_rate[(size_t)i] : b->plan->desc.sample_rate;
+    const int rate = (info && info[i].original_sample_rate > 0) ? info[i].original_sample_rate : own_rate;
     const int samples = (int)(info ? info[i].original_samples : b->file_samples[(size_t)i]);
     const int offset = info ? info[i].data_offset : b->file_offset[(size_t)i];
     afx::RhythmFile& rf = b->rt_files[(size_t)i];
@@ -729,7 +736,8 @@ template <typename Fill>
 int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const std::vector<int64_t>& lengths,
                 const std::vector<int32_t>& status, bool zero_arena, Fill fill, afx_batch** out_batch,
                 Workspace* acquired = nullptr, const std::vector<int64_t>* file_samples = nullptr,
-                const std::vector<int32_t>* file_offset = nullptr, bool wait_for_uploads = true) {
+                const std::vector<int32_t>* file_offset = nullptr, bool wait_for_uploads = true,
+                const std::vector<int32_t>* file_rate = nullptr) {
   const bool want_stats = (mask & AFX_D_STATISTICS) != 0;
   mask &= ~(uint32_t)AFX_D_STATISTICS;   // the kernels see the descriptor bits only
 
@@ -921,6 +929,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     b->rt_files.assign((size_t)n_bufs, afx::RhythmFile{});
     b->file_samples.assign((size_t)n_bufs, 0);
     b->file_offset.assign((size_t)n_bufs, 0);
+    if (file_rate) b->file_rate = *file_rate;
     int64_t rows = 0;
     for (int i = 0; i < n_bufs; ++i) {
       b->rt_offset[(size_t)i] = rows;
@@ -1069,6 +1078,51 @@ hipError_t download_through_plan(afx_batch* b, const Download* items, int n) {
     if (e != hipSuccess) return e;
   }
   return wait_for_event(ws, ws->ev_copy);
+}
+
+// The converter's filter: right wing of a Kaiser-windowed sinc, Nmult = 35 zero crossings x 4096 values each
+// (resample.c:104-124 -> lrsLpFilter / Izero, filterkit.c:66-113; roll-off 0.9, beta 6), computed in double and stored
+// as float like the library does.  Uploaded once per plan, by the first batch that needs it.
+hipError_t resample_filter_table(afx_plan* plan) {
+  std::lock_guard<std::mutex> lock(plan->pool_mutex);
+  if (plan->dev.rs_filter) return hipSuccess;
+  constexpr int kNpc = 4096, kNwing = kNpc * (35 - 1) / 2;
+  auto izero = [](double x) {
+    double sum = 1, u = 1;
+    int n = 1;
+    const double halfx = x / 2.0;
+    do {
+      double temp = halfx / (double)n;
+      n += 1;
+      temp *= temp;
+      u *= temp;
+      sum += u;
+    } while (u >= 1E-21 * sum);
+    return sum;
+  };
+  const double pi = 3.14159265358979232846, frq = 0.5 * 0.90, beta = 6;
+  std::vector<double> c((size_t)kNwing);
+  c[0] = 2.0 * frq;
+  for (int i = 1; i < kNwing; ++i) {
+    const double temp = pi * (double)i / (double)kNpc;
+    c[(size_t)i] = std::sin(2.0 * temp * frq) / temp;
+  }
+  const double ibeta = 1.0 / izero(beta), inm1 = 1.0 / ((double)(kNwing - 1));
+  for (int i = 1; i < kNwing; ++i) {
+    const double temp = (double)i * inm1;
+    double temp1 = 1.0 - temp * temp;
+    temp1 = (temp1 < 0 ? 0 : temp1);
+    c[(size_t)i] *= izero(beta * std::sqrt(temp1)) * ibeta;
+  }
+  std::vector<float> imp((size_t)kNwing);
+  for (int i = 0; i < kNwing; ++i) imp[(size_t)i] = (float)c[(size_t)i];
+  float* d = nullptr;
+  hipError_t e = hipMalloc((void**)&d, imp.size() * sizeof(float));
+  if (e != hipSuccess) return e;
+  e = hipMemcpy(d, imp.data(), imp.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { hipFree(d); return e; }
+  plan->dev.rs_filter = d;
+  return hipSuccess;
 }
 
 // bytes per sample of the decoded PCM formats (0: unknown format)
@@ -1226,18 +1280,53 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
 
   std::vector<int32_t> status((size_t)n_bufs, AFX_OK);
   std::vector<afx::LoadFile> files((size_t)n_bufs);
+  std::vector<afx::ResampleFile> conv;    // files at another rate than the plan's: converted on the GPU first
+  std::vector<int32_t> conv_buf;          // their buffer indices
+  std::vector<int32_t> file_rate((size_t)n_bufs, 0);
   int64_t raw_bytes = 0;
   for (int i = 0; i < n_bufs; ++i) {
     const afx_raw& r = raws[i];
     const int bps = raw_bytes_per_sample(r.format);
-    // SampleAnalyser.cpp:472-482: 1..8 channels, non-empty; resampling (sample_rate != plan rate,
-    // SampleAnalyser.cpp:563-607) is not part of this front end
-    const bool good = bps && r.data && r.n_frames > 0 && r.n_frames < 0x7FFFFFFF && r.channels >= 1 && r.channels <= 8 &&
-                      (r.sample_rate == 0 || r.sample_rate == plan->desc.sample_rate);
+    // SampleAnalyser.cpp:472-482: 1..8 channels, non-empty
+    const bool good = bps && r.data && r.n_frames > 0 && r.n_frames < 0x7FFFFFFF && r.channels >= 1 && r.channels <= 8 && r.sample_rate >= 0;
     files[i] = afx::LoadFile{0, 0, 0, 0};
-    if (!good) { status[i] = (bps && r.data && r.n_frames > 0 && r.channels >= 1 && r.channels <= 8) ? AFX_ERR_UNSUPPORTED : AFX_ERR_BAD_BUFFER; continue; }
+    if (!good) { status[i] = AFX_ERR_BAD_BUFFER; continue; }
     files[i] = afx::LoadFile{raw_bytes, r.n_frames, r.channels, r.format};
     raw_bytes += ((int64_t)r.n_frames * r.channels * bps + 15) & ~(int64_t)15;
+  }
+  // Sample-rate conversion (SampleAnalyser.cpp:563-607): Speed = file rate / analyser rate in double, the converter runs
+  // at factor 1 / Speed and fills NewSizeInSamples = max(1, d2iRound(n / Speed)) samples.  The mono mix and the converted
+  // samples of such a file live behind the decoded PCM of the batch in the raw arena; the LoadSample kernels then read
+  // the converted samples as a mono file of "16-bit floats".
+  int64_t conv_bytes = 0, group_slots = 0, conv_max_in = 0;
+  for (int i = 0; i < n_bufs; ++i) {
+    const afx_raw& r = raws[i];
+    if (status[i] != AFX_OK || r.sample_rate == 0 || r.sample_rate == plan->desc.sample_rate) continue;
+    file_rate[(size_t)i] = r.sample_rate;
+    const double speed = (double)r.sample_rate / (double)plan->desc.sample_rate;
+    if (speed == 1.0) continue;
+    const double factor = 1.0 / speed, scaled = (double)(int)r.n_frames / speed;
+    const double n_out_d = std::floor(scaled + 0.5);               // TMath::d2iRound of a positive value (InlineMath.inl:823-826)
+    // libresample's window must hold the filter's reach: factors below ~1/100 are outside what its 4096-sample buffer and
+    // this restatement of its bookkeeping cover (a 4.4 MHz file)
+    if (n_out_d >= 2147483647.0 || factor < 0.01) { status[i] = AFX_ERR_UNSUPPORTED; files[i] = afx::LoadFile{0, 0, 0, 0}; continue; }
+    afx::ResampleFile c{};
+    c.raw_off = files[i].raw_off; c.n_in = r.n_frames; c.channels = r.channels; c.format = r.format; c.factor = factor;
+    c.n_out = std::max<int64_t>(1, (int64_t)n_out_d);
+    c.mono_off = raw_bytes + conv_bytes;
+    conv_bytes += (c.n_in * 4 + 15) & ~(int64_t)15;
+    c.out_off = raw_bytes + conv_bytes;
+    conv_bytes += (c.n_out * 4 + 15) & ~(int64_t)15;
+    // group records: one per 16 output samples and one more per input window (resample.c:133-142: Xoff, XSize)
+    const unsigned xoff = (unsigned)(((35 + 1) / 2.0) * std::max(1.0, 1.0 / factor) + 10);
+    const unsigned xsize = std::max(2 * xoff + 10, 4096u);
+    const int64_t per_window = std::max<int64_t>(1, (int64_t)xsize - 2 * (int64_t)xoff - 16);
+    c.group_cap = (int32_t)std::min<int64_t>(c.n_out / 16 + c.n_in / per_window + 4, 0x7FFFFFFF);
+    c.group_off = group_slots;
+    group_slots += c.group_cap;
+    conv_max_in = std::max(conv_max_in, c.n_in);
+    conv.push_back(c);
+    conv_buf.push_back(i);
   }
   const long long t_begin = now_ns();
   // device staging of the decoded PCM and the scan results lives in the batch's pooled workspace
@@ -1251,7 +1340,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
   afx::LoadScan* d_scan = nullptr;
   std::vector<afx::LoadScan> scan((size_t)n_bufs);
   if (n_bufs > 0) {
-    if ((e = ws_reserve(ws->raw, (size_t)raw_bytes + 16)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(raw)"));
+    if ((e = ws_reserve(ws->raw, (size_t)(raw_bytes + conv_bytes) + 16)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(raw)"));
     if ((e = ws_reserve(ws->files, files.size() * sizeof(afx::LoadFile))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(files)"));
     if ((e = ws_reserve(ws->scan, scan.size() * sizeof(afx::LoadScan))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(scan)"));
     if ((e = ws_reserve(ws->partial, (size_t)n_bufs * afx::load_scan_blocks_per_file(n_bufs) * 16)) != hipSuccess) return bail(hip_fail(e, "hipMalloc(partial)"));
@@ -1281,6 +1370,19 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
           if ((e = hipMemcpyAsync(d_raw + files[i].raw_off, raws[i].data, (size_t)raws[i].n_frames * raws[i].channels * bps,
                                   hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(raw)"));
         }
+    }
+    if (!conv.empty()) {
+      if ((e = resample_filter_table(plan)) != hipSuccess) return bail(hip_fail(e, "resample filter"));
+      if ((e = ws_reserve(ws->rs_files, conv.size() * sizeof(afx::ResampleFile))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(resample files)"));
+      if ((e = ws_reserve(ws->rs_groups, (size_t)group_slots * sizeof(afx::ResampleGroup))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(resample groups)"));
+      if ((e = ws_reserve(ws->rs_ngroups, conv.size() * sizeof(int32_t))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(resample counts)"));
+      // (pageable source: the copy has left `conv` when the call returns)
+      if ((e = hipMemcpyAsync(ws->rs_files.p, conv.data(), conv.size() * sizeof(afx::ResampleFile), hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(resample files)"));
+      if ((e = afx::launch_resample(d_raw, (const afx::ResampleFile*)ws->rs_files.p, (int)conv.size(), group_slots, conv_max_in,
+                                    (afx::ResampleGroup*)ws->rs_groups.p, (int32_t*)ws->rs_ngroups.p, plan->dev.rs_filter, s)) != hipSuccess)
+        return bail(hip_fail(e, "resample"));
+      for (size_t k = 0; k < conv.size(); ++k)
+        files[(size_t)conv_buf[k]] = afx::LoadFile{conv[k].out_off, conv[k].n_out, 1, afx::kRawMonoFloat};
     }
     if ((e = hipMemcpyAsync(d_files, files.data(), files.size() * sizeof(afx::LoadFile), hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(files)"));
     // -48 dB of full scale (MSilenceThresholdDb, SampleAnalyser.cpp:51, 648-649)
@@ -1332,13 +1434,13 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
   std::vector<int32_t> file_offset((size_t)n_bufs, 0);
   for (int i = 0; i < n_bufs; ++i)
     if (status[i] == AFX_OK) {
-      file_samples[(size_t)i] = files[i].n_frames;                                // mOriginalNumberOfSamples, SampleAnalyser.cpp:464
+      file_samples[(size_t)i] = raws[i].n_frames;                                 // mOriginalNumberOfSamples, SampleAnalyser.cpp:464 (before the conversion)
       file_offset[(size_t)i] = (int32_t)(-place[i].lead + place[i].start_pad);    // mDataOffset, SampleAnalyser.cpp:701
     }
   const long long t_placed = now_ns();
   // the decoded PCM has arrived (the scan was waited for): nothing of the caller's is read after this point
   const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/false, fill, out_batch, ws, &file_samples,
-                             &file_offset, /*wait_for_uploads=*/false);
+                             &file_offset, /*wait_for_uploads=*/false, &file_rate);
   if (g_create_timing.on) {
     const long long t_end = now_ns();
     g_create_timing.ns[0] += t_scanned - t_begin; g_create_timing.ns[1] += t_placed - t_scanned;

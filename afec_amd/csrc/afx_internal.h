@@ -275,10 +275,30 @@ struct LoadPlace {   // per file, where the normalised samples go
   int64_t start_pad; // zeros in front (StartFrameOffset)
   double scaling;    // FinalScaling
 };
+constexpr int kRawMonoFloat = 5;   // LoadFile::format of a converted file: mono floats already in the "16-bit float" range
 int load_scan_blocks_per_file(int n_files);      // partial_scratch holds n_files x this x 16 bytes
 hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int n_files, double silence_floor,
                             void* partial_scratch, LoadScan* scan, hipStream_t stream);
 hipError_t launch_load_write(const unsigned char* raw, const LoadFile* files, const LoadPlace* place, int n_files,
                              double* arena, hipStream_t stream);
+
+// ---- sample-rate conversion in front of the LoadSample kernels (SampleAnalyser.cpp:563-607 -> libresample; afx_resample.hip) ----
+struct ResampleFile {
+  int64_t raw_off;    // the file's decoded PCM in the raw arena (bytes)
+  int64_t mono_off;   // its mono mix, n_in floats (bytes from the arena's start, 16-byte aligned)
+  int64_t out_off;    // the converted samples, n_out floats
+  int64_t group_off;  // the file's first group record
+  int64_t n_in, n_out;
+  int32_t channels, format;
+  int32_t group_cap, pad;
+  double factor;      // analyser rate / file rate = 1 / Speed
+};
+struct ResampleGroup {   // up to 16 consecutive output samples of one input window
+  double t0;             // the converter's time at the first of them, relative to the window
+  int32_t base;          // input sample the window starts at
+  int32_t out0, count, pad;
+};
+hipError_t launch_resample(unsigned char* raw, const ResampleFile* files, int n_files, int64_t group_slots, int64_t max_n_in,
+                           ResampleGroup* groups, int32_t* n_groups, const float* filter, hipStream_t stream);
 
 }  // namespace afx

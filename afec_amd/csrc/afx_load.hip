@@ -19,6 +19,7 @@ namespace {
 // the reference's decoders hand LoadSample "16-bit floats" (CoreFileFormats/Export/SampleConverter.h)
 __device__ __forceinline__ float to_16bit_float(const unsigned char* raw, int format, int64_t idx) {
   if (format == 0) return (float)reinterpret_cast<const short*>(raw)[idx];            // :446-449
+  if (format == kRawMonoFloat) return reinterpret_cast<const float*>(raw)[idx];       // converted samples (afx_resample.hip)
   if (format == 1) {                                                                  // :474-486
     const unsigned char* b = raw + 3 * idx;
     const int v = (int)(((unsigned)b[0] | ((unsigned)b[1] << 8) | ((unsigned)b[2] << 16)) << 8);

@@ -274,7 +274,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
             const TCrawlFile& f = *Done.mFiles[i];
             if (f.mpImage) Wave.OpenForRead(f.mpImage, f.mImageSize, f.mFileName);
             else Wave.OpenForRead(f.mFileName);
-            if (Wave.SamplingRate() != Options.mSampleRate) { Done.mSkipped[i] = 1; Wave.Close(); continue; }
+            if (!Options.mResample && Wave.SamplingRate() != Options.mSampleRate) { Done.mSkipped[i] = 1; Wave.Close(); continue; }
             TDecodedSample s = Wave.DescribeSample();
             const size_t Size = Wave.SampleDataBytes();
             if (Bytes + Size + 64 > Staging.mBytes) Staging.Grow(Bytes + Size + 64, Bytes);
@@ -306,7 +306,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
           Done.mpRhythm = RhythmPool.Acquire(TSampleAnalyser::RhythmDoubles(Decoded) * sizeof(double));
           // frames are at most samples / hop + 2 per file (LoadSample pads by up to a frame)
           size_t MaxFrames = 0;
-          for (const TDecodedSample& s : Decoded) MaxFrames += (size_t)(s.mNumberOfSampleFrames / Options.mHopFrameSize) + 3;
+          for (const TDecodedSample& s : Decoded) MaxFrames += (size_t)(TSampleAnalyser::ConvertedSampleFrames(s, Options.mSampleRate) / Options.mHopFrameSize) + 3;
           size_t Capacity = MaxFrames * (size_t)TSampleAnalyser::kMaxStride;
           int Attempts = 0;
           for (;;) {

@@ -51,13 +51,15 @@ struct TCrawlOptions {
   //   throughput with ~3 instead of ~7 busy CPUs per GPU.
   int mHardwareQueues = 16;
   bool mSleepingWaits = true;
+  // files at another sampling rate than the analyser's are converted on the GPU like the reference converts them on
+  // the CPU (SampleAnalyser.cpp:563-607, libresample; afx_resample.hip); false: they are skipped and counted
+  bool mResample = true;
 };
 
 struct TCrawlStatistics {
   int64_t mFiles = 0, mFailedFiles = 0, mFrames = 0, mBatches = 0;
-  // Files at another sampling rate than the analyser's: the reference resamples them (SampleAnalyser.cpp:563-607,
-  // libresample), this library does not.  They are neither analysed nor written as failed
-  // samples -- a later crawl with a resampling front end finds them missing, not broken.
+  // Files at another sampling rate than the analyser's that were left out because TCrawlOptions::mResample is off
+  // (neither analysed nor written as failed samples: a later crawl finds them missing, not broken)
   int64_t mSkippedSampleRateFiles = 0;
   int64_t mPcmBytes = 0;            // bytes of PCM uploaded
   int64_t mResultBytes = 0;         // bytes of records + statistics downloaded

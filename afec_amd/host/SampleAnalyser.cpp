@@ -304,9 +304,15 @@ TSampleDescriptors TRecordBatch::Descriptors(int i) const {
 
 // onsets [rows][2] + scalars [n][14] + onset statistics [n][2][13]; LoadSample pads a file by at most one 2048-sample
 // frame, so it has at most samples / 128 + 17 rows
+// sample frames of a file once it is at `Rate` (NewSizeInSamples, SampleAnalyser.cpp:572-573)
+int64_t TSampleAnalyser::ConvertedSampleFrames(const TDecodedSample& File, int Rate) {
+  if (File.mSampleRate <= 0 || File.mSampleRate == Rate) return File.mNumberOfSampleFrames;
+  return (int64_t)((double)File.mNumberOfSampleFrames / ((double)File.mSampleRate / (double)Rate) + 0.5) + 1;
+}
+
 size_t TSampleAnalyser::RhythmDoubles(const std::vector<TDecodedSample>& Files) {
   size_t Rows = 0;
-  for (const TDecodedSample& f : Files) Rows += (size_t)(f.mNumberOfSampleFrames / 128) + 17;
+  for (const TDecodedSample& f : Files) Rows += (size_t)(ConvertedSampleFrames(f, 44100) / 128) + 17;
   return Rows * 2 + Files.size() * (AFX_NUM_RHYTHM_SCALARS + 2 * AFX_NUM_STATISTICS);
 }
 

@@ -73,7 +73,7 @@ struct TDecodedSample {
   const void* mpInterleavedSamples;
   int mFormat;              // AFX_RAW_I16 / AFX_RAW_I24 / AFX_RAW_F32 of include/afx.h
   int mNumberOfChannels;    // 1..8
-  int mSampleRate;          // 0 = the analyser's rate; other rates must be resampled by the caller
+  int mSampleRate;          // 0 = the analyser's rate; other rates are converted on the GPU (SampleAnalyser.cpp:563-607)
   int64_t mNumberOfSampleFrames;
   // what the file looked like before the caller resampled it (TSampleData::mOriginalSampleRate / mOriginalNumberOfSamples,
   // SampleAnalyser.cpp:464-467; the final tempo's duration heuristics use them); 0 = as given above
@@ -144,6 +144,7 @@ public:
   // when the records do not fit RecordCapacity or the rhythm results RhythmCapacity: call again with larger buffers.
   enum { kMaxStride = 134 };
   static size_t RhythmDoubles(const std::vector<TDecodedSample>& Files);
+  static int64_t ConvertedSampleFrames(const TDecodedSample& File, int Rate);   // sample frames once the file is at Rate
   bool AnalyzeToRecords(const std::vector<TDecodedSample>& Files, double* pRecords, size_t RecordCapacity,
                         double* pStatistics, double* pRhythm, size_t RhythmCapacity, TRecordBatch& Batch) const;
 

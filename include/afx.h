@@ -271,8 +271,11 @@ int afx_batch_fetch_records(afx_batch* batch, double* records, double* statistic
  * Decoded, interleaved PCM of a file in; on the GPU: conversion to the reference's "16-bit float"
  * range, mono mix-down, peak / rms, peak normalisation, -48 dB leading / trailing silence trim, and the
  * half-frame / one-frame zero padding.  The result is the double buffer TSampleData::mData holds and
- * stays in HBM as the batch's PCM arena.  Decoding the container and resampling files that are not at
- * the plan's rate stay with the caller (buffers with another sample_rate get AFX_ERR_UNSUPPORTED). */
+ * stays in HBM as the batch's PCM arena.  Files that are not at the plan's rate (afx_raw.sample_rate) are converted
+ * first, on the GPU, exactly as the reference does it on the CPU (SampleAnalyser.cpp:563-607: libresample 0.1.3,
+ * resample_open(1, f, f) + one resample_process call, f = plan rate / file rate, on the mono mix; afx_resample.hip);
+ * afx_load_info and the rhythm tracker's duration heuristics then see the file's own rate and length
+ * (TSampleData::mOriginalSampleRate / mOriginalNumberOfSamples).  Decoding the container stays with the caller. */
 enum {
   AFX_RAW_I16 = 0, /* int16                      (S16BitSignedTo16BitFloat, SampleConverter.h:446-449) */
   AFX_RAW_I24 = 1, /* packed little-endian int24 (S24BitTo16BitFloat, SampleConverter.h:474-486)       */
@@ -284,7 +287,7 @@ typedef struct {
   const void* data;    /* host pointer, interleaved by channel */
   int32_t format;      /* AFX_RAW_* */
   int32_t channels;    /* 1..8 (SampleAnalyser.cpp:472-477) */
-  int32_t sample_rate; /* 0 = the plan's rate */
+  int32_t sample_rate; /* 0 = the plan's rate; another rate: converted on the GPU */
   int32_t reserved;
   int64_t n_frames;    /* sample frames per channel */
 } afx_raw;

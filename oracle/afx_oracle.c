@@ -731,6 +731,11 @@ static float to_16bit_float(const void* pcm, int format, int64_t idx) {
 
 double* afx_oracle_load_sample(const void* pcm, int format, int channels, int64_t n_frames, int fft_size,
                                afx_oracle_load_info* info) {
+  return afx_oracle_load_sample_at(pcm, format, channels, n_frames, 44100, 44100, fft_size, info);
+}
+
+double* afx_oracle_load_sample_at(const void* pcm, int format, int channels, int64_t n_frames, int file_rate,
+                                  int analyser_rate, int fft_size, afx_oracle_load_info* info) {
   const float scale = 65536 / 2.0f;   /* sScaleFactor = M16BitSampleRange / 2.0f, SA:533 */
   float* mono = (float*)malloc(sizeof(float) * (size_t)(n_frames > 0 ? n_frames : 1));
   int64_t n, lead, trail, audible, start_pad, end_pad, size;
@@ -747,6 +752,14 @@ double* afx_oracle_load_sample(const void* pcm, int format, int channels, int64_
       d *= mix;
     }
     mono[n] = d;
+  }
+  /* resample when the file is not at the analyser's rate (SA:563-607) */
+  if ((double)file_rate / (double)analyser_rate != 1.0) {
+    int64_t n_out = 0, n_written = 0;
+    float* resampled = afx_oracle_resample(mono, n_frames, file_rate, analyser_rate, &n_out, &n_written);
+    free(mono);
+    mono = resampled;
+    n_frames = n_out;
   }
   /* rms (SA:612-619) */
   for (n = 0; n < n_frames; ++n) { const double t = (double)(mono[n] / scale); rms += t * t; }

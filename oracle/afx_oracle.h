@@ -97,6 +97,18 @@ typedef struct {
 /* returns a malloc'ed normalised mono buffer (caller frees with afx_oracle_free) */
 double* afx_oracle_load_sample(const void* pcm, int format, int channels, int64_t n_frames, int fft_size,
                                afx_oracle_load_info* info);
+
+/* ---- the sample-rate conversion of LoadSample (SA:563-607): libresample 0.1.3 as the reference calls it ----
+ * (afx_oracle_resample.c; PINNED against oracle/_ref/ref_driver `resample`, tests/golden/resample.npz, bit-exact)
+ * in: the mono "16-bit float" buffer of a file at file_rate; returns malloc'ed out[*n_out], *n_out = NewSizeInSamples,
+ * *n_written = the samples the converter produced (<= *n_out; the rest is 0). */
+float* afx_oracle_resample(const float* in, int64_t n, int file_rate, int analyser_rate, int64_t* n_out, int64_t* n_written);
+/* the filter's right wing, float[69632] (resample.c:110-124) */
+void afx_oracle_resample_filter(float* imp);
+/* afx_oracle_load_sample for a file at file_rate analysed at analyser_rate (the conversion runs on the mono mix,
+ * before rms / peak / trim, as in SA:558-610) */
+double* afx_oracle_load_sample_at(const void* pcm, int format, int channels, int64_t n_frames, int file_rate,
+                                  int analyser_rate, int fft_size, afx_oracle_load_info* info);
 void afx_oracle_free(void* p);
 
 /* ---- rhythm tracker: the 512/128 loop behind the per-frame loop (SampleAnalyser.cpp:983-1048), afx_oracle_rhythm.c ----

@@ -25,6 +25,7 @@
 // in.bin : int64 n_bufs ; per buffer: int64 n_samples, double[n_samples]
 // out.bin: int64 n_frames ; double[n_frames][kRecord]
 
+#include "libresample.h"   // 3rdParty/Resample/Dist/include: the reference's libresample 0.1.3
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -490,6 +491,34 @@ static int CmdLoad(const char* in, const char* outp) {
   return 0;
 }
 
+// The sample-rate conversion of LoadSample, SampleAnalyser.cpp:563-607: the reference's libresample driven by the call
+// sequence of those lines (restated: LoadSample is a member of TSampleAnalyser, which does not link here).
+// in:  int32 file_rate, int32 analyser_rate, int64 n, float[n]     out: int64 NewSize, int64 written, int64 used, float[NewSize]
+static int CmdResample(const char* in, const char* outp) {
+  FILE* fi = fopen(in, "rb"); if (!fi) return 1;
+  int32_t file_rate = 0, rate = 0; int64_t n = 0;
+  if (fread(&file_rate, 4, 1, fi) != 1 || fread(&rate, 4, 1, fi) != 1 || fread(&n, 8, 1, fi) != 1) return 1;
+  std::vector<float> src((size_t)n);
+  if (n > 0 && fread(src.data(), 4, (size_t)n, fi) != (size_t)n) return 1;
+  fclose(fi);
+  const double Speed = (double)file_rate / (double)rate;
+  const unsigned int OldSizeInSamples = (unsigned int)n;
+  const unsigned int NewSizeInSamples = (unsigned int)MMax(1, TMath::d2iRound((int)n / Speed));
+  std::vector<float> dst((size_t)NewSizeInSamples, 0.0f);   // the reference's buffer is uninitialised (TArray::SetSize)
+  const int HighQuality = 1;
+  void* pResampler = ::resample_open(HighQuality, 1.0 / Speed, 1.0 / Speed);
+  const int LastFlag = 1;
+  int SrcSamplesUsed = 0;
+  const int DestSamplesWritten = ::resample_process(pResampler, 1.0 / Speed, src.data(), OldSizeInSamples, LastFlag,
+                                                    &SrcSamplesUsed, dst.data(), NewSizeInSamples);
+  ::resample_close(pResampler);
+  FILE* fo = fopen(outp, "wb"); if (!fo) return 1;
+  const int64_t a = NewSizeInSamples, b = DestSamplesWritten, c = SrcSamplesUsed;
+  fwrite(&a, 8, 1, fo); fwrite(&b, 8, 1, fo); fwrite(&c, 8, 1, fo); fwrite(dst.data(), 4, dst.size(), fo);
+  fclose(fo);
+  return 0;
+}
+
 // CalcEffectiveLength (SampleAnalyser.cpp:1715-1755): private member, flow restated around the reference's
 // TAudioMath::DbToLin / SamplesToMs
 static int CmdEffectiveLength(const char* in, const char* outp) {
@@ -645,6 +674,7 @@ int main(int argc, char** argv) {
   if (argc >= 4 && !strcmp(argv[1], "neighbours")) return CmdNeighbours(argv[2], argv[3], argc >= 5 && atoi(argv[4]) != 0);
   if (argc >= 2 && !strcmp(argv[1], "peakstest")) return CmdPeaksTest();
   if (argc >= 4 && !strcmp(argv[1], "load")) return CmdLoad(argv[2], argv[3]);
+  if (argc >= 4 && !strcmp(argv[1], "resample")) return CmdResample(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "efflen")) return CmdEffectiveLength(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "msgpack")) return CmdMsgpack(argv[2], argv[3]);
   if (argc >= 4 && !strcmp(argv[1], "onsetfft")) return CmdOnsetFft(argv[2], argv[3]);

@@ -92,12 +92,13 @@ class _LoadInfo(ctypes.Structure):
                 ("silent_leading", ctypes.c_int32), ("silent_trailing", ctypes.c_int32), ("n_samples", ctypes.c_int64)]
 
 
-def load_sample(data, channels, fft=2048):
-    """oracle LoadSample: data int16 / float32 interleaved, or uint8 packed int24 -> (mono doubles, info dict)."""
+def load_sample(data, channels, fft=2048, file_rate=44100, rate=44100):
+    """oracle LoadSample: data int16 / float32 interleaved, or uint8 packed int24 -> (mono doubles, info dict).
+    file_rate != rate: the mono mix is resampled first (SA:563-607)."""
     L = lib()
-    L.afx_oracle_load_sample.restype = ctypes.c_void_p
-    L.afx_oracle_load_sample.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
-                                         ctypes.POINTER(_LoadInfo)]
+    L.afx_oracle_load_sample_at.restype = ctypes.c_void_p
+    L.afx_oracle_load_sample_at.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int64, ctypes.c_int,
+                                            ctypes.c_int, ctypes.c_int, ctypes.POINTER(_LoadInfo)]
     L.afx_oracle_free.argtypes = [ctypes.c_void_p]
     data = np.ascontiguousarray(np.asarray(data).reshape(-1))
     if data.dtype == np.int16:
@@ -112,10 +113,33 @@ def load_sample(data, channels, fft=2048):
         data = data.astype(np.float32)
         fmt, frames = 2, data.size // channels
     info = _LoadInfo()
-    p = L.afx_oracle_load_sample(data.ctypes.data, fmt, channels, frames, fft, ctypes.byref(info))
+    p = L.afx_oracle_load_sample_at(data.ctypes.data, fmt, channels, frames, file_rate, rate, fft, ctypes.byref(info))
     out = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_double)), (info.n_samples,)).copy()
     L.afx_oracle_free(p)
     return out, {k: getattr(info, k) for k, _ in _LoadInfo._fields_}
+
+
+def resample(x, file_rate, rate=44100):
+    """oracle libresample as LoadSample drives it (SA:563-607): float32 mono in -> (float32 out, samples the converter wrote)."""
+    L = lib()
+    L.afx_oracle_resample.restype = ctypes.c_void_p
+    L.afx_oracle_resample.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_int64),
+                                      ctypes.POINTER(ctypes.c_int64)]
+    L.afx_oracle_free.argtypes = [ctypes.c_void_p]
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    n_out, n_written = ctypes.c_int64(0), ctypes.c_int64(0)
+    p = L.afx_oracle_resample(x.ctypes.data, x.size, file_rate, rate, ctypes.byref(n_out), ctypes.byref(n_written))
+    out = np.ctypeslib.as_array(ctypes.cast(p, ctypes.POINTER(ctypes.c_float)), (n_out.value,)).copy()
+    L.afx_oracle_free(p)
+    return out, n_written.value
+
+
+def resample_filter():
+    L = lib()
+    imp = np.zeros(4096 * 17, dtype=np.float32)
+    L.afx_oracle_resample_filter.argtypes = [ctypes.c_void_p]
+    L.afx_oracle_resample_filter(imp.ctypes.data)
+    return imp
 
 
 class Oracle:

@@ -52,8 +52,13 @@ def make_crawl(n_files=120):
         images.append(z["wav_" + k].tobytes())
     names.append("Broken/_Not A Wavefile.wav")
     images.append(b"RIFF....this is not a wave file" * 8)
-    names.append("Broken/48k.wav")
-    images.append(wav_bytes(np.zeros(6000, np.int16), 1, 16, rate=48000))     # not at the analyser's rate: resampling stays with the caller
+    # not at the analyser's rate: converted on the GPU as the reference converts them on the CPU (SampleAnalyser.cpp:563-607)
+    for rate, stereo in ((48000, True), (22050, False), (96000, False)):
+        x, ch = synth(rng, 1.5, stereo)
+        pcm = np.round(x * 32767).astype(np.int16)
+        names.append(f"Rates/{rate}_{'stereo' if stereo else 'mono'}.wav")
+        images.append(wav_bytes(pcm, ch, 16, rate=rate))
+        decoded[names[-1]] = (pcm, ch, rate)
     return images, names, decoded
 
 
@@ -62,28 +67,27 @@ def test_crawl_into_the_descriptor_database(tmp_path):
     images, names, decoded = make_crawl()
     db = str(tmp_path / "afec-ll.db")
     st = _host.crawl(images, names, devices=(0,), workers=3, files_per_batch=16, database=db)
-    # the 48 kHz file is neither analysed nor recorded: the reference resamples such files, this library does not, and a
-    # "failed" row would claim the file is broken
-    assert st["files"] == len(images) and st["failed"] == 1 and st["skipped_sample_rate"] == 1
+    assert st["files"] == len(images) and st["failed"] == 1 and st["skipped_sample_rate"] == 0
     assert st["files_per_device"] == [len(images)]
     con = sqlite3.connect(db)
     con.row_factory = sqlite3.Row
     assert con.execute("PRAGMA user_version").fetchone()[0] == 2
     rows = {r["filename"]: r for r in con.execute("SELECT * FROM assets")}
-    assert len(rows) == len(images) - 1 and "Broken/48k.wav" not in rows
+    assert len(rows) == len(images)
     assert rows["Broken/_Not A Wavefile.wav"]["status"] == "error: Not a valid WAV file."
     assert sum(1 for r in rows.values() if r["status"] != "succeeded") == 1          # cf. UnitTests.cpp:338-350
     z = np.load(GOLD)
     ora = Oracle()
     rng = np.random.default_rng(5)
-    picks = list(rng.choice(120, 6, replace=False))
+    picks = list(rng.choice(120, 6, replace=False)) + [names.index(n) for n in names if n.startswith("Rates/")]
     for i in picks:
         name = names[i]
         r = rows[name]
-        pcm, ch = decoded[name]
-        assert (r["file_type_S"], r["file_sample_rate_R"], r["file_channel_count_R"], r["file_bit_depth_R"]) == ("wav", 44100, ch, 16)
-        assert abs(r["file_length_R"] - pcm.reshape(-1).size / ch / 44100.0) < 1e-9
-        mono, info = _oracle.load_sample(pcm, ch)
+        pcm, ch = decoded[name][:2]
+        rate = decoded[name][2] if len(decoded[name]) > 2 else 44100
+        assert (r["file_type_S"], r["file_sample_rate_R"], r["file_channel_count_R"], r["file_bit_depth_R"]) == ("wav", rate, ch, 16)
+        assert abs(r["file_length_R"] - pcm.reshape(-1).size / ch / float(rate)) < 1e-6       # SamplesToMs is float arithmetic
+        mono, info = _oracle.load_sample(pcm, ch, file_rate=rate)
         ref = ora.run(mono, cap=True)
         for field, base in DB_NAME.items():
             a, b = FIELDS[field]
@@ -102,7 +106,7 @@ def test_crawl_into_the_descriptor_database(tmp_path):
         assert abs(r["effectve_length_48dB_R"] - eff[0]) < 1e-9
         # the rhythm tracker's columns: onsets and the scalars, with the file's own duration and the
         # data offset LoadSample produced (SampleAnalyser.cpp:1001-1004)
-        rh = ora.run_rhythm(mono, original_samples=pcm.reshape(-1).size // ch, data_offset=info["data_offset"], cap=True)
+        rh = ora.run_rhythm(mono, original_rate=rate, original_samples=pcm.reshape(-1).size // ch, data_offset=info["data_offset"], cap=True)
         for t, kind in enumerate(("rhythm_complex", "rhythm_percussive")):
             got = np.array(msgpack.unpackb(r[kind + "_onsets_VR"]), dtype=np.float64)
             assert got.shape == rh["onsets"][t].shape
@@ -130,7 +134,7 @@ def test_crawl_without_a_database_and_small_batches():
     b = _host.crawl(images, names, devices=(0,), workers=4, files_per_batch=3)
     for k in ("files", "failed", "frames", "pcm_bytes", "result_bytes"):
         assert a[k] == b[k], k
-    assert a["failed"] == 1 and a["skipped_sample_rate"] == 1 and a["frames"] > 0 and a["writer_seconds"] == 0.0
+    assert a["failed"] == 1 and a["skipped_sample_rate"] == 0 and a["frames"] > 0 and a["writer_seconds"] == 0.0
 
 
 def test_batches_end_at_the_byte_budget():
@@ -179,7 +183,7 @@ def test_crawler_persists_between_crawls_and_can_be_released(tmp_path):
     hostlib.release()
     _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=64, database=dbs[2])     # a fresh crawler again
     a, b, c = (rows_of(d) for d in dbs)
-    assert len(a) == len(images) - 1 and a == b == c      # all but the 48 kHz file
+    assert len(a) == len(images) and a == b == c
 
 
 def rows_by_hash(db):
@@ -214,7 +218,7 @@ def test_several_shards_on_one_device(tmp_path, shards):
     for k in ("files", "failed", "frames", "pcm_bytes", "skipped_sample_rate"):
         assert one[k] == many[k], k
     a, b = rows_by_hash(dbs[0]), rows_by_hash(dbs[1])
-    assert len(a) == len(images) - 1 and a == b
+    assert len(a) == len(images) and a == b
     assert many["cpu_seconds"] > 0 and many["seconds"] > 0
 
 
@@ -245,7 +249,7 @@ def test_database_pragmas_change_how_sqlite_writes_not_what(tmp_path):
     finally:
         hostlib.set_database_pragmas("")
     a, b = rows_by_hash(dbs[0]), rows_by_hash(dbs[1])
-    assert len(a) == len(images) - 1 and a == b
+    assert len(a) == len(images) and a == b
     con = sqlite3.connect(dbs[1])
     assert con.execute("PRAGMA page_size").fetchone()[0] == 65536 and con.execute("PRAGMA user_version").fetchone()[0] == 2
     con.close()
@@ -270,7 +274,7 @@ def test_files_on_disk_give_the_rows_of_their_images(tmp_path):
         assert from_disk[k] == from_images[k], k
     a, b = rows_by_hash(dbs[0]), rows_by_hash(dbs[1])
     gone = b.pop(str(tmp_path / "files" / "gone.wav"))
-    assert gone and a == b and len(a) == len(images) - 1
+    assert gone and a == b and len(a) == len(images)
     con = sqlite3.connect(dbs[1])
     status = con.execute("SELECT status FROM assets WHERE filename = ?", (str(tmp_path / "files" / "gone.wav"),)).fetchone()[0]
     con.close()

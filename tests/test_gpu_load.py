@@ -95,10 +95,10 @@ def test_load_front_end_rejects_bad_files_individually():
     rng = np.random.default_rng(32)
     good = (rng.uniform(-1, 1, 5000) * 20000).astype(np.int16)
     plan = afx.Plan()
-    batch, infos = plan.batch_from_raw([(good, 1), (good, 9), (good, 1, 48000), (good, 1)], afx.D_MFCC)
+    batch, infos = plan.batch_from_raw([(good, 1), (good, 9), (good, 1, -5), (good, 1)], afx.D_MFCC)
     batch.run()
     res = batch.fetch()
-    assert res["buf_status"].tolist() == [0, -6, -2, 0]     # 9 channels: bad buffer; 48 kHz: needs resampling
+    assert res["buf_status"].tolist() == [0, -6, -6, 0]     # 9 channels, a negative sampling rate: bad buffers
     assert res["frame_offset"].tolist() == [0, 4, 4, 4, 8]   # 5000 audible + 1024 end pad -> 4 frames
     np.testing.assert_array_equal(res["mfcc"][:4], res["mfcc"][4:])
     batch.close()

@@ -1298,7 +1298,7 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
   // at factor 1 / Speed and fills NewSizeInSamples = max(1, d2iRound(n / Speed)) samples.  The mono mix and the converted
   // samples of such a file live behind the decoded PCM of the batch in the raw arena; the LoadSample kernels then read
   // the converted samples as a mono file of "16-bit floats".
-  int64_t conv_bytes = 0, group_slots = 0, conv_max_in = 0;
+  int64_t conv_bytes = 0, group_slots = 0, conv_blocks = 0, conv_max_in = 0;
   for (int i = 0; i < n_bufs; ++i) {
     const afx_raw& r = raws[i];
     if (status[i] != AFX_OK || r.sample_rate == 0 || r.sample_rate == plan->desc.sample_rate) continue;
@@ -1307,23 +1307,19 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     if (speed == 1.0) continue;
     const double factor = 1.0 / speed, scaled = (double)(int)r.n_frames / speed;
     const double n_out_d = std::floor(scaled + 0.5);               // TMath::d2iRound of a positive value (InlineMath.inl:823-826)
-    // libresample's window must hold the filter's reach: factors below ~1/100 are outside what its 4096-sample buffer and
-    // this restatement of its bookkeeping cover (a 4.4 MHz file)
-    if (n_out_d >= 2147483647.0 || factor < 0.01) { status[i] = AFX_ERR_UNSUPPORTED; files[i] = afx::LoadFile{0, 0, 0, 0}; continue; }
+    // files above 16 x the analyser's rate (705.6 kHz) are outside what the kernels' zero margins cover
+    if (n_out_d >= 2147483647.0 || factor < 1.0 / 16.0 || conv_blocks > 0x7FFFFFF0) { status[i] = AFX_ERR_UNSUPPORTED; files[i] = afx::LoadFile{0, 0, 0, 0}; continue; }
     afx::ResampleFile c{};
     c.raw_off = files[i].raw_off; c.n_in = r.n_frames; c.channels = r.channels; c.format = r.format; c.factor = factor;
     c.n_out = std::max<int64_t>(1, (int64_t)n_out_d);
     c.mono_off = raw_bytes + conv_bytes;
-    conv_bytes += (c.n_in * 4 + 15) & ~(int64_t)15;
+    conv_bytes += ((c.n_in + 2 * afx::kResampleMargin) * 4 + 15) & ~(int64_t)15;
     c.out_off = raw_bytes + conv_bytes;
     conv_bytes += (c.n_out * 4 + 15) & ~(int64_t)15;
-    // group records: one per 16 output samples and one more per input window (resample.c:133-142: Xoff, XSize)
-    const unsigned xoff = (unsigned)(((35 + 1) / 2.0) * std::max(1.0, 1.0 / factor) + 10);
-    const unsigned xsize = std::max(2 * xoff + 10, 4096u);
-    const int64_t per_window = std::max<int64_t>(1, (int64_t)xsize - 2 * (int64_t)xoff - 16);
-    c.group_cap = (int32_t)std::min<int64_t>(c.n_out / 16 + c.n_in / per_window + 4, 0x7FFFFFFF);
-    c.group_off = group_slots;
-    group_slots += c.group_cap;
+    c.group_off = group_slots;                      // one record per 16 output samples
+    group_slots += (c.n_out + 15) / 16;
+    c.block_off = conv_blocks;
+    conv_blocks += afx::resample_blocks(c.n_out);
     conv_max_in = std::max(conv_max_in, c.n_in);
     conv.push_back(c);
     conv_buf.push_back(i);
@@ -1375,11 +1371,10 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
       if ((e = resample_filter_table(plan)) != hipSuccess) return bail(hip_fail(e, "resample filter"));
       if ((e = ws_reserve(ws->rs_files, conv.size() * sizeof(afx::ResampleFile))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(resample files)"));
       if ((e = ws_reserve(ws->rs_groups, (size_t)group_slots * sizeof(afx::ResampleGroup))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(resample groups)"));
-      if ((e = ws_reserve(ws->rs_ngroups, conv.size() * sizeof(int32_t))) != hipSuccess) return bail(hip_fail(e, "hipMalloc(resample counts)"));
       // (pageable source: the copy has left `conv` when the call returns)
       if ((e = hipMemcpyAsync(ws->rs_files.p, conv.data(), conv.size() * sizeof(afx::ResampleFile), hipMemcpyHostToDevice, s)) != hipSuccess) return bail(hip_fail(e, "hipMemcpy(resample files)"));
-      if ((e = afx::launch_resample(d_raw, (const afx::ResampleFile*)ws->rs_files.p, (int)conv.size(), group_slots, conv_max_in,
-                                    (afx::ResampleGroup*)ws->rs_groups.p, (int32_t*)ws->rs_ngroups.p, plan->dev.rs_filter, s)) != hipSuccess)
+      if ((e = afx::launch_resample(d_raw, (const afx::ResampleFile*)ws->rs_files.p, (int)conv.size(), conv_blocks, conv_max_in,
+                                    (afx::ResampleGroup*)ws->rs_groups.p, plan->dev.rs_filter, s)) != hipSuccess)
         return bail(hip_fail(e, "resample"));
       for (size_t k = 0; k < conv.size(); ++k)
         files[(size_t)conv_buf[k]] = afx::LoadFile{conv[k].out_off, conv[k].n_out, 1, afx::kRawMonoFloat};

@@ -283,22 +283,27 @@ hipError_t launch_load_write(const unsigned char* raw, const LoadFile* files, co
                              double* arena, hipStream_t stream);
 
 // ---- sample-rate conversion in front of the LoadSample kernels (SampleAnalyser.cpp:563-607 -> libresample; afx_resample.hip) ----
+// zero samples on either side of a file's mono mix: the filter's reach at the smallest supported factor (1/16: 18 x 16
+// input samples a wing, + the converter's creep)
+constexpr int kResampleMargin = 320;
 struct ResampleFile {
   int64_t raw_off;    // the file's decoded PCM in the raw arena (bytes)
-  int64_t mono_off;   // its mono mix, n_in floats (bytes from the arena's start, 16-byte aligned)
+  int64_t mono_off;   // its mono mix, kResampleMargin + n_in + kResampleMargin floats (bytes from the arena's start, 16-byte aligned)
   int64_t out_off;    // the converted samples, n_out floats
-  int64_t group_off;  // the file's first group record
+  int64_t group_off;  // the file's first record (one per 16 output samples)
+  int64_t block_off;  // the file's first workgroup of the filter kernel
   int64_t n_in, n_out;
   int32_t channels, format;
-  int32_t group_cap, pad;
   double factor;      // analyser rate / file rate = 1 / Speed
 };
-struct ResampleGroup {   // up to 16 consecutive output samples of one input window
-  double t0;             // the converter's time at the first of them, relative to the window
-  int32_t base;          // input sample the window starts at
-  int32_t out0, count, pad;
+struct ResampleGroup {   // output samples 16 r .. 16 r + 15 of a file
+  double t0, t1;         // the converter's time (relative to its input window) at the first sample; at sample `cut`
+  int32_t base0, base1;  // input sample the window starts at, for samples < cut and >= cut
+  int32_t cut;           // 16: one window; 1..15: a new window starts at this sample
+  int32_t pad;           // 0: all 16 produced; 1: none; 2 + k: the first k (the converter ended early, SA:596-597)
 };
-hipError_t launch_resample(unsigned char* raw, const ResampleFile* files, int n_files, int64_t group_slots, int64_t max_n_in,
-                           ResampleGroup* groups, int32_t* n_groups, const float* filter, hipStream_t stream);
+int64_t resample_blocks(int64_t n_out);   // workgroups of the filter kernel for a file of n_out converted samples
+hipError_t launch_resample(unsigned char* raw, const ResampleFile* files, int n_files, int64_t n_blocks, int64_t max_n_in,
+                           ResampleGroup* groups, const float* filter, hipStream_t stream);
 
 }  // namespace afx

@@ -113,15 +113,16 @@ def wav_image(pcm_i16, channels, rate=44100):
     return b"RIFF" + struct.pack("<I", len(body)) + body
 
 
-def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=3, files_per_batch=512, files_dir=None):
+def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=3, files_per_batch=512, files_dir=None, rate=44100):
     """The streaming host driver (afec_amd/host/Crawler.cpp) on this rank's share of the crawl: files/s and frames/s
     with every transfer inside the timed region.  The crawler (plans, device workspaces, page-locked buffers) persists
     between the repeats: the first one is the cold crawl ("cold_seconds"), the best one the warm rate.
-    files_dir: the files are written there first (untimed) and the crawler reads them from disk itself."""
+    files_dir: the files are written there first (untimed) and the crawler reads them from disk itself.
+    rate: the sampling rate the files claim (another one than 44 100: converted on the GPU, SampleAnalyser.cpp:563-607)."""
     from afec_amd import hostlib
     files = make_c3_files(64, seed) if workload == "c3" else make_c4_files(64, seed)
     channels = 1 if workload == "c3" else 2
-    pool = [wav_image(f, channels) for f in files]
+    pool = [wav_image(f, channels, rate) for f in files]
     images = [pool[i % len(pool)] for i in range(n_files)]
     names = None
     if files_dir is not None:
@@ -416,6 +417,10 @@ def main():
                 sf = end_to_end("c4", 12500, device, 8, 99, repeats=3, files_per_batch=512, files_dir=td)
                 e2e["files_per_s_from_files_on_tmpfs"] = sf["files"] / sf["seconds"]
                 e2e["busy_host_cpus_from_files_on_tmpfs"] = sf["cpu_seconds"] / sf["seconds"]
+            # the same 12 500 files labelled 48 kHz: every one goes through the sample-rate conversion on the GPU first
+            # (libresample's arithmetic, afx_resample.hip), then the same pipeline on 0.92 x the samples
+            sr = end_to_end("c4", 12500, device, 8, 99, repeats=3, files_per_batch=512, rate=48000)
+            e2e["files_per_s_at_48_kHz"] = sr["files"] / sr["seconds"]
         except Exception as e:  # noqa: BLE001  (the headline must not depend on the host library)
             e2e = dict(e2e or {}, error=str(e))
 

@@ -93,6 +93,69 @@ int main() {
   }
   std::printf("wav: %d parsed, %d rejected\n", Parsed, Rejected);
 
+  // ---- WAV reader on files (head parsed from the first 4 KiB, data chunk by pread): the same mutations, written to disk ----
+  {
+    int FromDisk = 0, RejectedOnDisk = 0, Differ = 0;
+    const std::string Path = "/tmp/afx_san/mutated.wav";
+    for (int Trial = 0; Trial < 3000; ++Trial) {
+      // every third file has a large chunk in front of the data chunk: the data lies behind the 4 KiB head
+      std::vector<unsigned char> Image = MakeWav(1 + Trial % 2, 44100, (Trial % 5 == 0) ? 8 : 16, 1, 50 + Gen() % 4000, Gen, Trial % 3 == 0);
+      if (Trial % 3 == 0) {
+        std::vector<unsigned char> Big(Image.begin(), Image.begin() + 12);
+        const unsigned char Junk[8] = {'J', 'U', 'N', 'K', 0x00, 0x20, 0x00, 0x00};   // 8192 bytes
+        Big.insert(Big.end(), Junk, Junk + 8);
+        Big.resize(Big.size() + 8192, 0x55);
+        Big.insert(Big.end(), Image.begin() + 12, Image.end());
+        Image.swap(Big);
+      }
+      const int Kind = Trial % 4;
+      if (Kind == 1) Image.resize(Gen() % (Image.size() + 1));
+      else if (Kind == 2) for (int k = 0; k < 3; ++k) Image[Gen() % 80 % Image.size()] = (unsigned char)Gen();
+      FILE* f = std::fopen(Path.c_str(), "wb");
+      if (!f) { std::printf("cannot write %s\n", Path.c_str()); return 1; }
+      if (!Image.empty()) std::fwrite(Image.data(), 1, Image.size(), f);
+      std::fclose(f);
+      std::string FromImage, FromFile;
+      std::vector<unsigned char> A, B;
+      try {
+        afec::TWaveFile Wave;
+        Wave.OpenForRead(Image.data(), Image.size());
+        A.resize(Wave.SampleDataBytes());
+        Wave.ReadSampleData(A.data());
+      } catch (const afec::TReadableException& e) { FromImage = e.what(); }
+      try {
+        afec::TWaveFile Wave;
+        Wave.OpenForRead(Path);
+        unsigned char* Exact = (unsigned char*)std::malloc(Wave.SampleDataBytes() ? Wave.SampleDataBytes() : 1);   // a write past the end is an ASan error
+        Wave.ReadSampleData(Exact);
+        B.assign(Exact, Exact + Wave.SampleDataBytes());
+        std::free(Exact);
+        ++FromDisk;
+      } catch (const afec::TReadableException& e) { FromFile = e.what(); ++RejectedOnDisk; }
+      if (FromImage != FromFile || A != B) ++Differ;
+    }
+    std::remove(Path.c_str());
+    std::printf("wav files: %d read, %d rejected, %d differ from their images\n", FromDisk, RejectedOnDisk, Differ);
+    if (Differ) return 1;
+  }
+
+  // ---- the oracle's sample-rate conversion (exactly sized input: any read outside [0, n) is an ASan error) ----
+  {
+    size_t Total = 0;
+    for (int Rate : {8000, 11025, 22050, 32000, 44099, 48000, 88200, 96000, 192000, 400000})
+      for (int64_t n : {1, 2, 30, 4039, 4040, 4041, 4096, 9001}) {
+        float* In = (float*)std::malloc(sizeof(float) * (size_t)n);
+        for (int64_t i = 0; i < n; ++i) In[i] = (float)((int)(Gen() % 60001) - 30000);
+        int64_t NOut = 0, NWritten = 0;
+        float* Out = afx_oracle_resample(In, n, Rate, 44100, &NOut, &NWritten);
+        if (NOut < 1 || NWritten > NOut) { std::printf("resample: bad sizes\n"); return 1; }
+        Total += (size_t)NOut;
+        afx_oracle_free(Out);
+        std::free(In);
+      }
+    std::printf("resample: %zu samples out\n", Total);
+  }
+
   // ---- column encoder ----
   {
     std::vector<double> v(70000);

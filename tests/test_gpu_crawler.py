@@ -279,3 +279,46 @@ def test_files_on_disk_give_the_rows_of_their_images(tmp_path):
     status = con.execute("SELECT status FROM assets WHERE filename = ?", (str(tmp_path / "files" / "gone.wav"),)).fetchone()[0]
     con.close()
     assert "Failed to open the file" in status
+
+
+def test_the_c4_share_at_its_full_size(tmp_path):
+    """BASELINE.json configs[3]'s per-GPU share at its real size: 12 500 stereo one-second files (64 different contents,
+    cycled) through the crawler into the database.  Size-independent properties: every file is there, files with the
+    same bytes have the same row whatever batch, worker and position they were analysed in, and a sample of the
+    contents equals the oracle."""
+    import hashlib
+    import msgpack
+    import bench
+    contents = bench.make_c4_files(64, 99)
+    pool = [bench.wav_image(f, 2) for f in contents]
+    n = 12500
+    images = [pool[i % 64] for i in range(n)]
+    names = [f"share/{i // 500:02d}/file{i:05d}.wav" for i in range(n)]
+    db = str(tmp_path / "c4.db")
+    st = _host.crawl(images, names, workers=8, files_per_batch=512, database=db)
+    assert st["files"] == n and st["failed"] == 0 and st["batches"] >= n // 512
+    con = sqlite3.connect(db)
+    cols = [r[1] for r in con.execute("PRAGMA table_info(assets)")]
+    skip = {cols.index("filename"), cols.index("modtime")}
+    digest, count = {}, 0
+    for r in con.execute("SELECT * FROM assets"):
+        count += 1
+        h = hashlib.sha256()
+        for k, v in enumerate(r):
+            if k not in skip:
+                h.update(v if isinstance(v, bytes) else repr(v).encode())
+        i = int(r[0][-9:-4])
+        digest.setdefault(i % 64, set()).add(h.hexdigest())
+    assert count == n and len(digest) == 64
+    assert all(len(v) == 1 for v in digest.values()), [k for k, v in digest.items() if len(v) != 1]
+    con.row_factory = sqlite3.Row
+    ora = Oracle()
+    for k in (0, 17, 63):
+        r = con.execute("SELECT * FROM assets WHERE filename = ?", (names[64 * 100 + k],)).fetchone()
+        mono, _ = _oracle.load_sample(contents[k], 2)
+        ref = ora.run(mono, cap=True)
+        a, b = FIELDS["mfcc"]
+        got = np.array(msgpack.unpackb(r["cepstrum_bands_VVR"]), dtype=np.float64).reshape(ref.shape[0], -1)
+        _tol.check("mfcc", got, ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"content {k} ")
+        assert r["status"] == "succeeded" and r["file_channel_count_R"] == 2
+    con.close()

@@ -17,3 +17,5 @@ bash tools/prof_pmc.sh c2hw frames32 > /dev/null 2>&1
 bash tools/prof_rhythm.sh | grep -v stats_kernel
 bash tools/prof_rhythm_pmc.sh short
 python tools/rhythm_report.py > /dev/null 2>&1      # last: the profiled runs above overwrite the report with partial ones
+bash tools/prof_resample.sh 12500 1.0 48000 96000 22050 | tail -12      # sample-rate conversion: call times + per-kernel times
+AFEC_CRAWL_TIMING=1 timeout 300 python tools/e2e_sweep.py 12500 8:512 6:512 > $O/e2e_cpu_accounting.txt 2>&1; grep -v "round trip =" $O/e2e_cpu_accounting.txt | tail -6

@@ -442,7 +442,8 @@ extern "C" void afec_crawl_release(void) {
 
 extern "C" void afec_crawl_set_bytes_per_batch(int64_t bytes) { gBytesPerBatch = bytes; }
 
-namespace { std::mutex gPragmaMutex; std::string gDatabasePragmas; }
+namespace { std::mutex gPragmaMutex; std::string gDatabasePragmas; std::atomic<bool> gResample(true); }
+extern "C" void afec_crawl_set_resample(int32_t resample) { gResample = resample != 0; }
 extern "C" void afec_crawl_set_database_pragmas(const char* pragmas) {
   std::lock_guard<std::mutex> Lock(gPragmaMutex);
   gDatabasePragmas = pragmas ? pragmas : "";
@@ -466,6 +467,7 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     if (files_per_batch > 0) Options.mFilesPerBatch = files_per_batch;
     if (database_path) Options.mDatabasePath = database_path;
     if (gBytesPerBatch > 0) Options.mBytesPerBatch = gBytesPerBatch;
+    Options.mResample = gResample;
     {
       std::lock_guard<std::mutex> Lock(gPragmaMutex);
       Options.mDatabasePragmas = gDatabasePragmas;

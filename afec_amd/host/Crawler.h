@@ -118,4 +118,6 @@ void afec_crawl_release(void);
 void afec_crawl_set_bytes_per_batch(int64_t bytes);
 // TCrawlOptions::mDatabasePragmas of the crawls that follow (NULL or "": none)
 void afec_crawl_set_database_pragmas(const char* pragmas);
+// TCrawlOptions::mResample of the crawls that follow (0: files at another rate than the analyser's are skipped and counted)
+void afec_crawl_set_resample(int32_t resample);
 }

@@ -106,3 +106,11 @@ def set_database_pragmas(pragmas):
     L.afec_crawl_set_database_pragmas.restype = None
     L.afec_crawl_set_database_pragmas.argtypes = [ctypes.c_char_p]
     L.afec_crawl_set_database_pragmas(pragmas.encode() if pragmas else None)
+
+
+def set_resample(on):
+    """TCrawlOptions::mResample of the crawls that follow (False: files at another rate than the analyser's are skipped and counted)."""
+    L = lib()
+    L.afec_crawl_set_resample.restype = None
+    L.afec_crawl_set_resample.argtypes = [ctypes.c_int32]
+    L.afec_crawl_set_resample(1 if on else 0)

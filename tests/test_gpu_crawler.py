@@ -322,3 +322,17 @@ def test_the_c4_share_at_its_full_size(tmp_path):
         _tol.check("mfcc", got, ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"content {k} ")
         assert r["status"] == "succeeded" and r["file_channel_count_R"] == 2
     con.close()
+
+
+def test_conversion_can_be_switched_off():
+    """TCrawlOptions::mResample = false: files at another rate are skipped and counted, not analysed, not failed."""
+    from afec_amd import hostlib
+    images, names, _ = make_crawl(20)
+    on = _host.crawl(images, names, workers=2, files_per_batch=8)
+    try:
+        hostlib.set_resample(False)
+        off = _host.crawl(images, names, workers=2, files_per_batch=8)
+    finally:
+        hostlib.set_resample(True)
+    assert on["skipped_sample_rate"] == 0 and off["skipped_sample_rate"] == 3
+    assert off["files"] == on["files"] and off["failed"] == on["failed"] == 1 and off["frames"] < on["frames"]

@@ -83,6 +83,63 @@ __device__ __forceinline__ void load2(const double* p, double& a, double& b) {
   a = v.x; b = v.y;
 }
 
+// atan2 and sqrt of the polar spectrum.  TAudioMath::Phase / Magnitude are the double libm calls rounded to float
+// (AudioMath.cpp:497-503, 637-643).  The device library's double atan2 is 104 instructions (division with scaling,
+// a degree-19 polynomial, inf / nan handling) and was 40 % of the onset kernel; this one is 43: the ratio of the smaller to
+// the larger magnitude is reduced against the nearest c = k / 16, t = (mn - c mx) / (mx + c mn) with |t| <= 1 / 32, atan t
+// as five Taylor terms (the next one is 7e-20 relative), atan c from a table, then the octant.  2 ulp of a double at
+// worst; rounded to float it equalled glibc's atan2 on 60 000 000 arguments of mixed magnitudes, octants and signed
+// zeros (a CPU restatement with the same operations).  Inputs are finite (FFT outputs).
+__device__ const double kAtanOfSixteenths[17] = {
+    0x0.0p+0, 0x1.ff55bb72cfdeap-5, 0x1.fd5ba9aac2f6ep-4, 0x1.7b97b4bce5b02p-3, 0x1.f5b75f92c80ddp-3, 0x1.362773707ebccp-2,
+    0x1.6f61941e4def1p-2, 0x1.a64eec3cc23fdp-2, 0x1.dac670561bb4fp-2, 0x1.0657e94db30d0p-1, 0x1.1e00babdefeb4p-1,
+    0x1.345f01cce37bbp-1, 0x1.4978fa3269ee1p-1, 0x1.5d58987169b18p-1, 0x1.700a7c5784634p-1, 0x1.819d0b7158a4dp-1,
+    0x1.921fb54442d18p-1};
+
+__device__ __forceinline__ double polar_atan2(double y, double x) {
+  const double ax = fabs(x), ay = fabs(y);
+  const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+  const double xa = mn * __builtin_amdgcn_rcp(mx);          // 0 / 0: nan, converted to k = 0
+  int k = (int)fma(xa, 16.0, 0.5);
+  k = k > 16 ? 16 : k;
+  const double c = (double)k * 0.0625;
+  const double num = fma(-c, mx, mn);
+  double den = fma(c, mn, mx);
+  den = (mx == 0.0) ? 1.0 : den;
+  double r = __builtin_amdgcn_rcp(den);
+  double e = fma(-den, r, 1.0);
+  r = fma(e, r, r);
+  e = fma(-den, r, 1.0);
+  r = fma(e, r, r);
+  double t = num * r;
+  e = fma(-den, t, num);
+  t = fma(e, r, t);
+  const double t2 = t * t;
+  double p = -1.0 / 11.0;
+  p = fma(p, t2, 1.0 / 9.0);
+  p = fma(p, t2, -1.0 / 7.0);
+  p = fma(p, t2, 1.0 / 5.0);
+  p = fma(p, t2, -1.0 / 3.0);
+  const double s = (t * t2) * p;
+  double a = kAtanOfSixteenths[k] + (t + s);
+  if (ay > ax) a = (0x1.921fb54442d18p+0 - a) + 0x1.1a62633145c07p-54;     // pi / 2 in two parts
+  if (__builtin_signbit(x)) a = (0x1.921fb54442d18p+1 - a) + 0x1.1a62633145c07p-53;
+  return __builtin_copysign(a, y);
+}
+
+// sqrt(s), s >= 0 finite and far from the ends of the exponent range: reciprocal square root + two coupled Newton steps
+// (the device library's sequence without its rescaling and special cases)
+__device__ __forceinline__ double polar_sqrt(double s) {
+  const double r0 = __builtin_amdgcn_rsq(s);
+  double g = s * r0, h = 0.5 * r0;
+  double e = fma(-h, g, 0.5);
+  g = fma(g, e, g);
+  h = fma(h, e, h);
+  e = fma(-g, g, s);
+  g = fma(e, h, g);
+  return (s == 0.0) ? 0.0 : g;
+}
+
 // natural-order 16-point forward DFT of v (first radix-4 stage + the rest, afx_fft32.h)
 __device__ __forceinline__ void dft16(C (&v)[16]) {
 #pragma unroll
@@ -145,16 +202,26 @@ __device__ __forceinline__ void onset_polar_frame(const PCM* xf, double* xg, con
   wave_lds_fence();
 #pragma unroll
   for (int r = 0; r < 16; ++r) p[r].im = xg[(256 - (q + 16 * r)) & 255];
+  // AFX_POLAR_GROUP bins at a time (scheduling barriers in between): all sixteen interleaved keep more values alive than
+  // there are registers at three waves per SIMD (116 B of scratch).  onset_function_kernel on the C4 share: device library's
+  // atan2 / sqrt 8.60 ms; these with groups of 16 / 8 / 4 / 2 bins: 8.31 / 7.90 / 7.88 / 7.73 ms (tools/ab_rhythm.sh)
+#ifndef AFX_POLAR_GROUP
+#define AFX_POLAR_GROUP 2
+#endif
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const C A = u[r], B = p[r], w = ut[r * 16 + q];
-    const double er = A.re + B.re, ei = A.im - B.im, orr = A.im + B.im, oi = B.re - A.re;
-    const double re = er + (w.re * orr - w.im * oi);
-    // the reference transform is e^{+i} (ooura_cdft(.., 1, ..), Fourier.cpp:243-262): conjugate of this one
-    double im = -(ei + (w.re * oi + w.im * orr));
-    if (q + 16 * r == 0) im = 0.0;                          // Im[0] of a real frame is +0
-    magf[r] = (float)sqrt(re * re + im * im);               // TAudioMath::Magnitude, AudioMath.cpp:497-503
-    phf[r] = (float)atan2(im, re);                          // TAudioMath::Phase, AudioMath.cpp:637-643
+  for (int r0 = 0; r0 < 16; r0 += AFX_POLAR_GROUP) {
+#pragma unroll
+    for (int r = r0; r < r0 + AFX_POLAR_GROUP; ++r) {
+      const C A = u[r], B = p[r], w = ut[r * 16 + q];
+      const double er = A.re + B.re, ei = A.im - B.im, orr = A.im + B.im, oi = B.re - A.re;
+      const double re = er + (w.re * orr - w.im * oi);
+      // the reference transform is e^{+i} (ooura_cdft(.., 1, ..), Fourier.cpp:243-262): conjugate of this one
+      double im = -(ei + (w.re * oi + w.im * orr));
+      if (q + 16 * r == 0) im = 0.0;                          // Im[0] of a real frame is +0
+      magf[r] = (float)polar_sqrt(re * re + im * im);         // TAudioMath::Magnitude, AudioMath.cpp:497-503
+      phf[r] = (float)polar_atan2(im, re);                    // TAudioMath::Phase, AudioMath.cpp:637-643
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(kRsThreads, AFX_RS_OCC) void resample_filter_kernel
     int w_lo = (int)((double)i * dh) - 2;
     int w_hi = (int)((double)(i + 1) * dh) + 3;
     w_lo = (w_lo < 0 ? 0 : w_lo) & ~3;                              // 16-byte steps: the window is staged four values at a time
+    w_lo = w_lo > kNwing - 4 ? kNwing - 4 : w_lo;                   // (the last, spare tap lies behind the table: nothing picks from it)
     w_hi = w_hi > kNwing ? kNwing : w_hi;
     const int w_last = w_hi - w_lo - 1;
     __syncthreads();

@@ -25,7 +25,7 @@ extern "C" {
 enum {
   AFX_OK = 0,
   AFX_ERR_INVALID_ARG = -1,
-  AFX_ERR_UNSUPPORTED = -2, /* plan geometry the HIP kernels are not specialised for        */
+  AFX_ERR_UNSUPPORTED = -2, /* plan geometry the HIP kernels are not specialised for; a file's rate */
   AFX_ERR_NO_DEVICE = -3,   /* no HIP device / device ordinal out of range                  */
   AFX_ERR_OUT_OF_MEMORY = -4,
   AFX_ERR_HIP = -5,         /* a HIP runtime call failed; afx_last_error() has the text      */
@@ -275,7 +275,8 @@ int afx_batch_fetch_records(afx_batch* batch, double* records, double* statistic
  * first, on the GPU, exactly as the reference does it on the CPU (SampleAnalyser.cpp:563-607: libresample 0.1.3,
  * resample_open(1, f, f) + one resample_process call, f = plan rate / file rate, on the mono mix; afx_resample.hip);
  * afx_load_info and the rhythm tracker's duration heuristics then see the file's own rate and length
- * (TSampleData::mOriginalSampleRate / mOriginalNumberOfSamples).  Decoding the container stays with the caller. */
+ * (TSampleData::mOriginalSampleRate / mOriginalNumberOfSamples).  A file above 16 x the plan's rate gets
+ * AFX_ERR_UNSUPPORTED in its buf_status.  Decoding the container stays with the caller. */
 enum {
   AFX_RAW_I16 = 0, /* int16                      (S16BitSignedTo16BitFloat, SampleConverter.h:446-449) */
   AFX_RAW_I24 = 1, /* packed little-endian int24 (S24BitTo16BitFloat, SampleConverter.h:474-486)       */

@@ -22,7 +22,9 @@ for i, x in enumerate(base):
     n = int(rng.integers(3000, len(x)))
     stereo = i % 3 == 0
     pcm = np.stack([x[:n], x[:n] // 2], axis=1).reshape(-1) if stereo else x[:n]
-    pool.append(bench.wav_image(pcm, 2 if stereo else 1))
+    # every fifth file at another sampling rate: converted on the GPU in front of LoadSample
+    rate = [48000, 22050, 96000, 32000][(i // 5) % 4] if i % 5 == 1 else 44100
+    pool.append(bench.wav_image(pcm, 2 if stereo else 1, rate))
 pool.append(b"RIFF....not a wave file" * 4)
 deadline = [time.time() + 60.0]
 

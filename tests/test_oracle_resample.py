@@ -74,3 +74,19 @@ def test_filter_table():
     imp = _oracle.resample_filter()
     assert imp.size == 4096 * 17 and abs(float(imp[0]) - 0.9) < 1e-7          # c[0] = 2 frq = 0.9 (filterkit.c:88)
     assert np.all(np.abs(imp) <= imp[0]) and abs(imp[-1]) < 1e-3
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "ref_driver")),
+                    reason="needs oracle/_ref/ref_driver (make -C oracle ref; only in the build container)")
+def test_oracle_equals_the_references_libresample_on_random_cases():
+    """Beyond the committed goldens: random rates and lengths through the reference's libresample on the spot."""
+    from tests.golden.make_golden_resample import run_ref_resample
+    rng = np.random.default_rng(2026)
+    for _ in range(60):
+        rate = int(rng.choice([8000, 11025, 16000, 22050, 32000, 48000, 88200, 96000, 176400, 192000])) if rng.random() < 0.5 else int(rng.integers(3000, 400000))
+        n = int(rng.choice([1, 2, 3, 4039, 4040, 4041])) if rng.random() < 0.2 else int(np.exp(rng.uniform(np.log(5), np.log(60000))))
+        x = np.round(rng.uniform(-30000, 30000, n)).astype(np.float32)
+        want, written, used = run_ref_resample(x, rate)
+        got, got_written = _oracle.resample(x, rate)
+        assert got.size == want.size and got_written == written and used == n, (rate, n)
+        np.testing.assert_array_equal(got.view(np.uint32), want.view(np.uint32), err_msg=f"{rate} Hz, {n} samples")

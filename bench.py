@@ -3,8 +3,11 @@
 
 Workload (BASELINE.json configs[1], "C2"): 2048/1024 STFT + 14-coefficient MFCC on synthetic
 44.1 kHz mono float32 PCM, U(-1,1) from MT19937(1234 + rank): `--buffers` buffers of exactly
-10 000 frames each per GPU.  One *step* = one pass of the HIP path over that whole batch, PCM
-already resident in HBM.  N>1: one process per GPU (torchrun), every rank owns its own batch
+10 000 frames each per GPU (512 by default: 5.12 M frames, 21 GB of PCM resident in HBM; 64 of them are generated,
+larger batches tile those -- every copy has its own place in HBM).  One *step* = one pass of the HIP path over that
+whole batch, PCM already resident in HBM.  The batch is sized so that a step takes ~10 ms: from an idle GPU the clocks
+need ~30 ms of load to settle (the first 25 launches of a 1.3 ms step run 5-15 % slower, profiles/r03/clock_ramp.txt),
+and a handful of warm-up steps must cover that.  N>1: one process per GPU (torchrun), every rank owns its own batch
 (files are sharded, no data-path collective) -> weak scaling; value = frames all ranks processed
 / max-over-ranks time.
 
@@ -42,7 +45,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--buffers", type=int, default=64, help="10k-frame buffers per GPU per step")
+    ap.add_argument("--buffers", type=int, default=512, help="10k-frame buffers per GPU per step")
     ap.add_argument("--precision", choices=["f64"], default="f64", help="the arithmetic the path computes in (the reference's)")
     ap.add_argument("--mask", default="c2", choices=["c2", "star", "stats", "all", "frame", "neighbours", "everything"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c3", "c4"],
@@ -62,16 +65,19 @@ def parse_args():
     return ap.parse_args()
 
 
+DISTINCT_BUFFERS = 64   # MT19937 buffers generated on the host; larger batches tile them (every copy has its own place in HBM)
+
+
 def make_buffers(n_buffers, seed):
     n = (FRAMES_PER_BUFFER - 1) * 1024 + 2048
     rng = np.random.Generator(np.random.MT19937(seed))
     bufs = []
-    for _ in range(n_buffers):
+    for _ in range(min(n_buffers, DISTINCT_BUFFERS)):
         x = rng.random(n, dtype=np.float32)
         x *= 2.0
         x -= 1.0
         bufs.append(x)
-    return bufs
+    return [bufs[i % len(bufs)] for i in range(n_buffers)]
 
 
 def make_c3_files(n_files, seed):

@@ -14,8 +14,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
-CLOCK_GHZ = 1.88   # measured in-kernel (s_memtime / s_memrealtime, stamps build) under the f64 load: 1.82-1.90 over boxes
-LIMITER = {"c2_f64": "f64 VALU work under the chip's power limit (clock 1.8-1.9 of 2.4 GHz); LDS ~70 % busy beside it"}
+CLOCK_GHZ = 2.0    # in-kernel (s_memtime / s_memrealtime, stamps build) at steady state under the f64 load: 1.92-2.07 over boxes
+                   # (profiles/r03/clock_ramp.txt; 1.8-1.9 during the first ~30 ms from an idle GPU)
+LIMITER = {"c2_f64": "f64 VALU work; sustained clock 1.9-2.1 of 2.4 GHz under this f64 + LDS + HBM load; LDS ~70 % busy beside it"}
 
 os.makedirs(DST, exist_ok=True)
 out = {"_comment": "Per bench configuration, from rocprofv3 passes on MI355X (tools/profile_config.py; raw summaries "

@@ -10,7 +10,7 @@ python tools/profile_config.py c2_f64
 python tools/profile_config.py star_f64 --mask star
 python tools/profile_config.py all_f64 --mask all
 python tools/profile_config.py frame_f64 --mask frame
-python tools/profile_config.py c3 --workload c3 --mask frame
+AFX_PROF_WARMUP=12 AFX_PROF_STEPS=20 python tools/profile_config.py c3 --workload c3 --mask frame
 python tools/profile_config.py c4 --workload c4 --mask frame
 python tools/profile_config.py c4_everything --workload c4 --mask everything
 bash tools/prof_pmc.sh c2hw frames32 > /dev/null 2>&1

@@ -2,7 +2,7 @@
 """Soak of the streaming host driver: crawls with random worker counts, batch sizes, byte budgets and file sets for a
 given time; every crawl of the same file set must report the same files / failed / frames / bytes.  A watchdog ends the
 process (exit code 3) when one crawl takes longer than a minute.
-usage: crawl_soak.py [seconds]"""
+usage: crawl_soak.py [seconds] [disk]      (disk: the pool is written to a temporary directory and the crawler reads the files itself)"""
 import os
 import sys
 import threading
@@ -15,6 +15,7 @@ import bench  # noqa: E402
 from afec_amd import hostlib  # noqa: E402
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+from_disk = len(sys.argv) > 2 and sys.argv[2] == "disk"
 rng = np.random.default_rng(2026)
 base = bench.make_c3_files(48, 5)
 pool = []
@@ -26,6 +27,20 @@ for i, x in enumerate(base):
     rate = [48000, 22050, 96000, 32000][(i // 5) % 4] if i % 5 == 1 else 44100
     pool.append(bench.wav_image(pcm, 2 if stereo else 1, rate))
 pool.append(b"RIFF....not a wave file" * 4)
+paths = None
+if from_disk:
+    import atexit
+    import shutil
+    import tempfile
+    root = tempfile.mkdtemp(dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    atexit.register(shutil.rmtree, root, True)
+    paths = []
+    for i, image in enumerate(pool):
+        paths.append(os.path.join(root, f"pool{i:03d}.wav"))
+        with open(paths[-1], "wb") as f:
+            f.write(image)
+    paths.append(os.path.join(root, "missing.wav"))          # a path that does not exist: a failed sample
+    pool.append(None)
 deadline = [time.time() + 60.0]
 
 
@@ -51,7 +66,10 @@ while time.time() < t_end:
     if rng.random() < 0.05:
         hostlib.release()
     deadline[0] = time.time() + 60.0
-    st = hostlib.crawl(images, workers=w, files_per_batch=b)
+    if from_disk:
+        st = hostlib.crawl(None, [paths[(first + i) % len(pool)] for i in range(n)], workers=w, files_per_batch=b)
+    else:
+        st = hostlib.crawl(images, workers=w, files_per_batch=b)
     key = (n, first)
     sig = tuple(st[k] for k in ("files", "failed", "frames", "pcm_bytes", "result_bytes"))
     if expected.setdefault(key, sig) != sig:
@@ -60,4 +78,4 @@ while time.time() < t_end:
     crawls += 1
     files += n
 hostlib.set_bytes_per_batch(0)
-print(f"crawl soak: {crawls} crawls, {files} files in {seconds:.0f} s, no mismatch, no hang")
+print(f"crawl soak{' (files on disk)' if from_disk else ''}: {crawls} crawls, {files} files in {seconds:.0f} s, no mismatch, no hang")

@@ -135,3 +135,48 @@ def test_a_long_file_and_a_lone_sample():
     check_file(batch, 2, infos[2], np.array([-5, 9000], np.int16), 1, 8000, "two samples")
     batch.close()
     plan.close()
+
+
+def test_real_audio_at_another_rate_through_the_crawler(tmp_path):
+    """The reference's own fixture WAVs (tests/golden/wav/) with their headers relabelled 48 kHz and 32 kHz: crawled into
+    the database, the per-frame series of the converted audio against the oracle chain (its converter is pinned on the
+    reference's libresample), the file properties against the file."""
+    import glob
+    import os
+    import sqlite3
+    import struct
+
+    import msgpack
+
+    from tests import _host
+    from tests._wav import parse_wav
+    wavs = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "wav", "*.wav")) if not os.path.basename(p).startswith("_"))
+    assert len(wavs) >= 10
+    images, names, want = [], [], {}
+    for k, path in enumerate(wavs):
+        image = bytearray(open(path, "rb").read())
+        channels, rate, bits, frames, payload = parse_wav(bytes(image))
+        new_rate = (48000, 32000)[k % 2]
+        at = bytes(image).index(b"fmt ") + 8
+        struct.pack_into("<II", image, at + 4, new_rate, new_rate * channels * bits // 8)     # nSamplesPerSec, nAvgBytesPerSec
+        name = f"relabelled/{new_rate}/{os.path.basename(path)}"
+        images.append(bytes(image)); names.append(name)
+        want[name] = (np.frombuffer(payload, dtype=np.int16 if bits == 16 else np.uint8), channels, bits, new_rate, frames)
+    db = str(tmp_path / "relabelled.db")
+    st = _host.crawl(images, names, workers=2, files_per_batch=5, database=db)
+    assert st["files"] == len(images) and st["failed"] == 0 and st["skipped_sample_rate"] == 0
+    con = sqlite3.connect(db)
+    con.row_factory = sqlite3.Row
+    ora = Oracle()
+    for name, (data, channels, bits, rate, frames) in want.items():
+        r = con.execute("SELECT * FROM assets WHERE filename = ?", (name,)).fetchone()
+        assert r["status"] == "succeeded" and (r["file_sample_rate_R"], r["file_channel_count_R"], r["file_bit_depth_R"]) == (rate, channels, bits)
+        assert abs(r["file_length_R"] - frames / float(rate)) < 1e-6
+        mono, info = _oracle.load_sample(data, channels, file_rate=rate)
+        ref = ora.run(mono, cap=True)
+        for field, col in (("mfcc", "cepstrum_bands_VVR"), ("spectral_centroid", "spectral_centroid_VR"), ("spectrum_bands", "frequency_bands_VVR"),
+                           ("amplitude_peak", "amplitude_peak_VR")):
+            a, b = FIELDS[field]
+            got = np.array(msgpack.unpackb(r[col]), dtype=np.float64).reshape(ref.shape[0], -1)
+            _tol.check(field, got, ref[:, a:b], *_tol.GPU_TOL[field], what=f"{name} {col} ")
+    con.close()

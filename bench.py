@@ -382,8 +382,11 @@ def main():
     # for the star set, 640 000: 293 M)
     star_rate = all_rate = None
     if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
-        star_rate = secondary_rate(plan, star, args.buffers)
-        all_rate = secondary_rate(plan, afx.D_ALL_LOW_LEVEL, args.buffers)
+        try:   # (the headline line must not depend on the secondary batches: the full set keeps 8 KiB of magnitudes per frame)
+            star_rate = secondary_rate(plan, star, args.buffers)
+            all_rate = secondary_rate(plan, afx.D_ALL_LOW_LEVEL, args.buffers)
+        except Exception as e:  # noqa: BLE001
+            print(f"warning: secondary rates not measured: {e}", file=sys.stderr)
 
     # the streaming host driver on C4's per-GPU share, every transfer inside the timed region (secondary number)
     e2e = None

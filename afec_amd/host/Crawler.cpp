@@ -103,6 +103,32 @@ private:
 };
 
 // what a worker hands to the writer: one analysed batch (its result buffers travel with it)
+// The column values of a batch's files (461 per file, ~68 KB of msgpack for a one-second file), built by the worker that
+// analysed the batch so that the one writer thread only binds and steps; recycled between batches: names and BLOB
+// capacities persist (RefillLowLevelColumns)
+struct TRowSet {
+  std::vector<std::vector<TColumn>> mRows;
+};
+class TRowSetPool {
+public:
+  std::unique_ptr<TRowSet> Acquire() {
+    std::lock_guard<std::mutex> Lock(mMutex);
+    if (mFree.empty()) return std::unique_ptr<TRowSet>(new TRowSet);
+    std::unique_ptr<TRowSet> p = std::move(mFree.back());
+    mFree.pop_back();
+    return p;
+  }
+  void Release(std::unique_ptr<TRowSet> p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> Lock(mMutex);
+    if (mFree.size() < 32) mFree.push_back(std::move(p));
+  }
+
+private:
+  std::mutex mMutex;
+  std::vector<std::unique_ptr<TRowSet>> mFree;
+};
+
 struct TFinishedBatch {
   std::vector<const TCrawlFile*> mFiles;
   std::vector<TFileProperties> mProperties;
@@ -111,6 +137,7 @@ struct TFinishedBatch {
   std::vector<int> mBatchIndex;              // file -> index inside mResults, -1 for files that never reached the GPU
   TRecordBatch mResults;
   std::unique_ptr<TPinned> mpRecords, mpStatistics, mpRhythm;
+  std::unique_ptr<TRowSet> mpRows;           // with a database: mRows[k] = the column values of batch file k
 };
 
 class TBoundedQueue {
@@ -155,6 +182,7 @@ struct TCrawler::TImpl {
   int mSampleRate, mFftFrameSize, mHopFrameSize;
   std::vector<std::unique_ptr<TSampleAnalyser>> mAnalysers;
   TPinnedPool mRecordPool, mStatisticsPool, mRhythmPool, mStagingPool;   // one pool per kind of buffer: nothing regrows
+  TRowSetPool mRowPool;
 };
 
 TCrawler::TCrawler(const TCrawlOptions& Options) : mpImpl(new TImpl) {
@@ -196,6 +224,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   TPinnedPool& StatisticsPool = mpImpl->mStatisticsPool;
   TPinnedPool& RhythmPool = mpImpl->mRhythmPool;
   TPinnedPool& StagingPool = mpImpl->mStagingPool;
+  TRowSetPool& RowPool = mpImpl->mRowPool;
   std::unique_ptr<TSqliteSampleDescriptorPool> pPool;
   if (!Options.mDatabasePath.empty()) pPool.reset(new TSqliteSampleDescriptorPool(Options.mDatabasePath, Options.mDatabasePragmas));
 
@@ -328,6 +357,17 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
             if (k >= 0 && Done.mResults.mStatus[(size_t)k] != AFX_OK)
               Done.mFailed[i] = std::string(afx_status_str(Done.mResults.mStatus[(size_t)k]));
           }
+          // with a database: the rows' column values are built here, by the eight workers, not by the one writer
+          if (pPool && Options.mPrepareRowsInWorkers) {
+            Done.mpRows = RowPool.Acquire();
+            if (Done.mpRows->mRows.size() < Decoded.size()) Done.mpRows->mRows.resize(Decoded.size());
+            for (size_t i = 0; i < n; ++i) {
+              const int k = Done.mBatchIndex[i];
+              if (k < 0 || !Done.mFailed[i].empty()) continue;
+              const TSampleDescriptors Results = Done.mResults.Descriptors(k);
+              RefillLowLevelColumns(Done.mpRows->mRows[(size_t)k], Results, &Done.mResults.mInfo[(size_t)k]);
+            }
+          }
         }
         const double tGpu1 = Now(), cGpu1 = ThreadCpuSeconds();
         {
@@ -375,8 +415,12 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
             if (pPool) pPool->InsertFailedSample(f.mFileName, f.mModificationTime, p->mFailed[i]);
           } else if (pPool) {
             const int k = p->mBatchIndex[i];
-            const TSampleDescriptors Results = p->mResults.Descriptors(k);
-            pPool->InsertSample(f.mFileName, f.mModificationTime, p->mProperties[i], Results, &p->mResults.mInfo[(size_t)k]);
+            if (p->mpRows) {
+              pPool->InsertColumns(f.mFileName, f.mModificationTime, p->mProperties[i], p->mpRows->mRows[(size_t)k]);
+            } else {
+              const TSampleDescriptors Results = p->mResults.Descriptors(k);
+              pPool->InsertSample(f.mFileName, f.mModificationTime, p->mProperties[i], Results, &p->mResults.mInfo[(size_t)k]);
+            }
           }
         } catch (const std::exception& e) {
           std::lock_guard<std::mutex> Lock(StatMutex);
@@ -394,6 +438,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
       Pool.Release(std::move(p->mpRecords));
       StatisticsPool.Release(std::move(p->mpStatistics));
       RhythmPool.Release(std::move(p->mpRhythm));
+      RowPool.Release(std::move(p->mpRows));
       std::lock_guard<std::mutex> Lock(StatMutex);
       Total.mFailedFiles += Failed;
       Total.mSkippedSampleRateFiles += Skipped;

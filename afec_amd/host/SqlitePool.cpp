@@ -167,8 +167,13 @@ void TSqliteSampleDescriptorPool::CommitTransaction() {
 void TSqliteSampleDescriptorPool::InsertSample(const std::string& FileName, int ModificationTime,
                                                const TFileProperties& File, const TSampleDescriptors& Results,
                                                const TSampleDataInfo* pInfo) {
+  RefillLowLevelColumns(mpImpl->mValues, Results, pInfo);
+  InsertColumns(FileName, ModificationTime, File, mpImpl->mValues);
+}
+
+void TSqliteSampleDescriptorPool::InsertColumns(const std::string& FileName, int ModificationTime, const TFileProperties& File,
+                                                const std::vector<TColumn>& Values) {
   TImpl& I = *mpImpl;
-  RefillLowLevelColumns(I.mValues, Results, pInfo);
   if (!I.mpInsert) {
     // SqliteSampleDescriptorPool.cpp:1591-1640: all keys, INSERT OR REPLACE
     std::string Sql = "INSERT OR REPLACE into assets(filename,modtime,status";
@@ -178,9 +183,9 @@ void TSqliteSampleDescriptorPool::InsertSample(const std::string& FileName, int 
     Sql += ")";
     I.Check(I.mApi.prepare_v2(I.mpDatabase, Sql.c_str(), -1, &I.mpInsert, nullptr), "prepare");
   }
-  if (I.mBoundColumnCount != I.mValues.size()) {
+  if (I.mBoundColumnCount != Values.size()) {
     std::unordered_map<std::string, int> ByName;
-    for (size_t i = 0; i < I.mValues.size(); ++i) ByName[I.mValues[i].mName] = (int)i;
+    for (size_t i = 0; i < Values.size(); ++i) ByName[Values[i].mName] = (int)i;
     I.mBindings.clear();
     for (const TColumnSpec& c : I.mSchema) {
       const auto Found = ByName.find(c.mName);
@@ -201,7 +206,7 @@ void TSqliteSampleDescriptorPool::InsertSample(const std::string& FileName, int 
       }
       I.mBindings.push_back(b);
     }
-    I.mBoundColumnCount = I.mValues.size();
+    I.mBoundColumnCount = Values.size();
   }
   // one transaction per file (SqliteSampleDescriptorPool.cpp:1591-1640) unless the caller has opened one around a
   // batch of files: the rows are the same either way
@@ -219,7 +224,7 @@ void TSqliteSampleDescriptorPool::InsertSample(const std::string& FileName, int 
       int r = kSqliteOk;
       switch (b.mSource) {
         case TImpl::kValue: {
-          const TColumn& v = I.mValues[(size_t)b.mValueIndex];
+          const TColumn& v = Values[(size_t)b.mValueIndex];
           r = (v.mType == TColumn::kReal) ? I.mApi.bind_double(pStatement, Index, v.mReal)
                                           : I.mApi.bind_blob(pStatement, Index, v.mBlob.data(), (int)v.mBlob.size(), nullptr);
           break;

@@ -44,6 +44,11 @@ public:
   // INSERT OR REPLACE of one analysed file (in its own transaction unless one is open), status "succeeded"
   void InsertSample(const std::string& FileName, int ModificationTime, const TFileProperties& File,
                     const TSampleDescriptors& Results, const TSampleDataInfo* pInfo = nullptr);
+  // The same in two steps, for pipelines whose worker threads build the column values (msgpack BLOBs, statistics) so
+  // that the one writer thread only binds and steps: Values = RefillLowLevelColumns / LowLevelColumns of the file's
+  // descriptors (DescriptorColumns.h; any thread), then InsertColumns on the writer.  The row is InsertSample's.
+  void InsertColumns(const std::string& FileName, int ModificationTime, const TFileProperties& File,
+                     const std::vector<TColumn>& Values);
   // the row of a file that could not be analysed: status "error: <Reason>", every descriptor NULL
   void InsertFailedSample(const std::string& FileName, int ModificationTime, const std::string& Reason);
 

@@ -125,6 +125,13 @@ static int WriteDatabase(const char* pPath) {
   Pool.InsertFailedSample("Batch/broken.wav", 1700000005, "could not decode");
   Pool.InsertSample("Batch/noinfo.wav", 1700000006, File, D, nullptr);
   Pool.InsertSample("Batch/again.wav", 1700000007, File, D, &Info);
+  // the two-step form the crawler's workers / writer use: values built elsewhere, bound here -- the same row
+  {
+    std::vector<afec::TColumn> Values;
+    afec::RefillLowLevelColumns(Values, Long, &Info);      // a buffer that held another file before
+    afec::RefillLowLevelColumns(Values, D, &Info);
+    Pool.InsertColumns("Batch/prepared.wav", 1700000007, File, Values);
+  }
   Pool.CommitTransaction();
   return 0;
 }

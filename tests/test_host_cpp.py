@@ -174,7 +174,12 @@ def test_descriptor_database_is_the_references_schema(tmp_path):
     # the rows written inside one transaction through the refilled column vector: each carries its own values
     batch = {r[0]: r for r in con.execute("SELECT filename, status, spectral_centroid_VR, cepstrum_bands_VVR, analyzation_offset_R, "
                                           "effectve_length_24dB_R FROM assets WHERE filename LIKE 'Batch/%'")}
-    assert sorted(batch) == ["Batch/again.wav", "Batch/broken.wav", "Batch/long.wav", "Batch/noinfo.wav", "Batch/short.wav"]
+    assert sorted(batch) == ["Batch/again.wav", "Batch/broken.wav", "Batch/long.wav", "Batch/noinfo.wav", "Batch/prepared.wav", "Batch/short.wav"]
+    # InsertColumns (values built by another thread in the crawler) writes InsertSample's row
+    cols = [r[1] for r in con.execute("PRAGMA table_info(assets)") if r[1] != "filename"]
+    a_row = con.execute("SELECT %s FROM assets WHERE filename = 'Batch/again.wav'" % ", ".join(cols)).fetchone()
+    p_row = con.execute("SELECT %s FROM assets WHERE filename = 'Batch/prepared.wav'" % ", ".join(cols)).fetchone()
+    assert a_row == p_row
     assert batch["Batch/broken.wav"][1] == "error: could not decode" and batch["Batch/broken.wav"][2] is None
     assert msgpack.unpackb(batch["Batch/long.wav"][2]) == [0.5] * 40 and len(msgpack.unpackb(batch["Batch/long.wav"][3])) == 40
     assert msgpack.unpackb(batch["Batch/short.wav"][2]) == [7.0] and msgpack.unpackb(batch["Batch/short.wav"][3]) == []
@@ -244,7 +249,7 @@ def test_descriptor_database_version_rules(tmp_path):
     out = subprocess.run([BIN, "sqlite", older], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     con = sqlite3.connect(older)
-    assert con.execute("SELECT count(*) FROM assets").fetchone()[0] == 7      # INSERT OR REPLACE: the same 7 files
+    assert con.execute("SELECT count(*) FROM assets").fetchone()[0] == 8      # INSERT OR REPLACE: the same 8 files
     con.close()
 
 

@@ -12,4 +12,5 @@ from .capi import (  # noqa: F401
     D_AMPLITUDE_SILENCE, D_AMPLITUDE_ENVELOPE, D_SPECTRAL_COMPLEXITY, D_AUTO_CORRELATION, D_F0,
     D_SPECTRAL_INHARMONICITY, D_TRISTIMULUS, D_EFFECTIVE_LENGTH, D_RHYTHM, RHYTHM_SCALARS, D_NEIGHBOURS, D_ALL_PER_FRAME,
     D_C2, D_SPECTRAL_STATS, D_ALL_LOW_LEVEL, PRECISION_F64, PRECISION_F32, PCM_F32, PCM_F64,
+    FRAME_KERNEL_AUTO, FRAME_KERNEL_WAVE64, FRAME_KERNEL_HALFWAVE, PLAN_NO_SIDE_STREAM,
 )

@@ -51,6 +51,8 @@ D_NEIGHBOURS = 0x3F8000
 D_ALL_PER_FRAME = D_ALL_LOW_LEVEL | D_NEIGHBOURS
 PRECISION_F64, PRECISION_F32 = 0, 1
 PCM_F32, PCM_F64 = 0, 1
+FRAME_KERNEL_AUTO, FRAME_KERNEL_WAVE64, FRAME_KERNEL_HALFWAVE = 0, 1, 2   # afx_plan_desc.frame_kernel
+PLAN_NO_SIDE_STREAM = 1                                                   # afx_plan_desc.flags
 
 # every symbol include/afx.h declares (tests check the library exports exactly these)
 EXPORTS = [
@@ -61,7 +63,7 @@ EXPORTS = [
     "afx_algorithmic_bytes_per_frame", "afx_batch_create_from_raw", "afx_batch_fetch_samples",
     "afx_host_alloc", "afx_host_free", "afx_batch_record_layout", "afx_batch_fetch_records",
     "afx_batch_set_file_info", "afx_batch_rhythm_frames", "afx_batch_fetch_rhythm", "afx_batch_fetch_onset_functions",
-    "afx_plan_set_blocking_wait",
+    "afx_plan_set_blocking_wait", "afx_batch_get_info", "afx_plan_probe_device",
 ]
 RAW_I16, RAW_I24, RAW_F32, RAW_I32, RAW_F64 = 0, 1, 2, 3, 4
 
@@ -102,7 +104,14 @@ class AfxError(RuntimeError):
 class _PlanDesc(ctypes.Structure):
     _fields_ = [("sample_rate", ctypes.c_int32), ("fft_size", ctypes.c_int32),
                 ("hop_size", ctypes.c_int32), ("device", ctypes.c_int32),
-                ("precision", ctypes.c_int32), ("max_analysis_ms", ctypes.c_int32)]
+                ("precision", ctypes.c_int32), ("max_analysis_ms", ctypes.c_int32),
+                ("frame_kernel", ctypes.c_int32), ("flags", ctypes.c_int32)]
+
+
+class _BatchInfo(ctypes.Structure):
+    _fields_ = [("frame_kernel", ctypes.c_int32), ("feature_class", ctypes.c_int32), ("pcm_kind", ctypes.c_int32),
+                ("chunk_frames", ctypes.c_int32), ("n_chunks", ctypes.c_int32), ("grid_blocks", ctypes.c_int32),
+                ("arena_bytes", ctypes.c_int64)]
 
 
 class _Buf(ctypes.Structure):
@@ -199,6 +208,7 @@ def load_library():
     L.afx_batch_rhythm_frames.restype = i64
     L.afx_batch_rhythm_frames.argtypes = [vp, vp]
     L.afx_batch_fetch_rhythm.argtypes = [vp, vp, vp, vp]
+    L.afx_batch_get_info.argtypes = [vp, ctypes.POINTER(_BatchInfo)]
     L.afx_batch_fetch_onset_functions.argtypes = [vp, vp]
     L.afx_algorithmic_bytes_per_frame.restype = i64
     L.afx_algorithmic_bytes_per_frame.argtypes = [vp, u32, i32]
@@ -273,9 +283,9 @@ class Plan:
     """afx_plan: the analogue of constructing TSampleAnalyser(44100, 2048, 1024)."""
 
     def __init__(self, sample_rate=44100, fft_size=2048, hop_size=1024, device=0,
-                 precision=PRECISION_F64, max_analysis_ms=20000):
+                 precision=PRECISION_F64, max_analysis_ms=20000, frame_kernel=FRAME_KERNEL_AUTO, flags=0):
         self.L = load_library()
-        d = _PlanDesc(sample_rate, fft_size, hop_size, device, precision, max_analysis_ms)
+        d = _PlanDesc(sample_rate, fft_size, hop_size, device, precision, max_analysis_ms, frame_kernel, flags)
         h = ctypes.c_void_p()
         _check(self.L, self.L.afx_plan_create(ctypes.byref(d), ctypes.byref(h)))
         self.h = h
@@ -376,6 +386,12 @@ class Batch:
 
     def run(self):
         _check(self.L, self.L.afx_batch_run(self.h))
+
+    def info(self):
+        """afx_batch_get_info: which STFT kernel the batch launches, its chunking, the PCM kept in HBM."""
+        i = _BatchInfo()
+        _check(self.L, self.L.afx_batch_get_info(self.h, ctypes.byref(i)))
+        return {n: int(getattr(i, n)) for n, _ in _BatchInfo._fields_}
 
     def sync(self):
         _check(self.L, self.L.afx_batch_sync(self.h))

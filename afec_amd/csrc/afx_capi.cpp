@@ -41,7 +41,8 @@ int fail(int status, const std::string& msg) {
   return status;
 }
 int hip_fail(hipError_t e, const char* what) {
-  return fail(AFX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+  (void)hipGetLastError();   // the runtime keeps the last error per thread: a later hipGetLastError() check must not see this one
+  return fail(e == hipErrorOutOfMemory ? AFX_ERR_OUT_OF_MEMORY : AFX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
 }
 #define HIP_TRY(expr)                                  \
   do {                                                 \
@@ -196,18 +197,18 @@ struct afx_plan {
   // that each upload and download collapse to 16 + 16 GB/s (the copy engines are re-assigned back and forth).
   std::mutex up_mutex, down_mutex;
   hipStream_t up_stream = nullptr, down_stream = nullptr;
-  // AFX_HALFWAVE in the environment when the plan is created: 0 = 64-lane frame kernels only (A/B timing),
-  // 1 = by batch size (default), 2 = half-wave kernel for every batch it supports (tests)
+  // afx_plan_desc.frame_kernel: 0 = 64-lane frame kernels only (A/B timing), 1 = by batch size (default),
+  // 2 = half-wave kernel for every batch it supports (tests)
   int halfwave = 1;
-  // AFX_SIDE_STREAM=0 in the environment when the plan is created: the rhythm tracker's kernels are enqueued on the
-  // batch's own stream instead of its side stream (per-kernel durations of a profile are then not inflated by overlap)
+  // afx_plan_desc.flags & AFX_PLAN_NO_SIDE_STREAM: the rhythm tracker's kernels are enqueued on the batch's own stream
+  // instead of its side stream (per-kernel durations of a profile are then not inflated by overlap)
   bool side_stream = true;
 };
 
 struct afx_batch {
   afx_plan* plan = nullptr;
   uint32_t mask = 0;
-  int pcm_dtype = AFX_PCM_F32;
+  int pcm_dtype = afx::kPcmF32;   // afx::kPcm*: the ABI's AFX_PCM_F32 / AFX_PCM_F64, or kPcmScaledF32 behind the LoadSample front end
   int32_t n_bufs = 0;
   std::vector<int64_t> frame_offset;  // [n_bufs+1]
   std::vector<int32_t> buf_status;    // [n_bufs]
@@ -233,6 +234,7 @@ struct afx_batch {
   unsigned* d_queue = nullptr;   // work-queue counter of the half-wave frame kernel (lives in the workspace)
   double* d_stat_tmp = nullptr;  // half-wave statistics class: raw sums per frame
   std::vector<int64_t> arena_off, used;  // per buffer: start and length (samples) of its analysed prefix in d_pcm
+  std::vector<double> buf_scale;         // kPcmScaledF32: FinalScaling per buffer (empty otherwise)
   // rhythm tracker (AFX_D_RHYTHM)
   std::vector<int64_t> rt_offset;          // [n_bufs+1]: rows of the 512/128 frames
   std::vector<afx::RhythmFile> rt_files;   // [n_bufs]
@@ -591,7 +593,7 @@ const char* afx_build_info(void) {
 #ifndef AFX_SRC_HASH
 #define AFX_SRC_HASH "unknown"
 #endif
-  return "afx abi=" "4" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL " src=" AFX_SRC_HASH;
+  return "afx abi=" "5" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL " src=" AFX_SRC_HASH;
 }
 
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
@@ -599,7 +601,9 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   *out_plan = nullptr;
   if (desc->sample_rate <= 0 || desc->fft_size <= 0 || desc->hop_size <= 0 ||
       (desc->fft_size & (desc->fft_size - 1)) || desc->max_analysis_ms < 0 ||
-      (desc->precision != AFX_PRECISION_F64 && desc->precision != AFX_PRECISION_F32))
+      (desc->precision != AFX_PRECISION_F64 && desc->precision != AFX_PRECISION_F32) ||
+      desc->frame_kernel < AFX_FRAME_KERNEL_AUTO || desc->frame_kernel > AFX_FRAME_KERNEL_HALFWAVE ||
+      (desc->flags & ~(int32_t)AFX_PLAN_NO_SIDE_STREAM))
     return fail(AFX_ERR_INVALID_ARG, "bad plan descriptor");
   if (desc->precision == AFX_PRECISION_F32)
     return fail(AFX_ERR_UNSUPPORTED,
@@ -649,8 +653,8 @@ int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
   if (e != hipSuccess) { delete p; return hip_fail(e, "hipSetDevice"); }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, desc->device) == hipSuccess) p->cu_count = prop.multiProcessorCount;
-  if (const char* hw = std::getenv("AFX_HALFWAVE")) p->halfwave = (hw[0] == '0') ? 0 : (hw[0] == '2' ? 2 : 1);
-  if (const char* ss = std::getenv("AFX_SIDE_STREAM")) p->side_stream = ss[0] != '0';
+  p->halfwave = (desc->frame_kernel == AFX_FRAME_KERNEL_WAVE64) ? 0 : (desc->frame_kernel == AFX_FRAME_KERNEL_HALFWAVE ? 2 : 1);
+  p->side_stream = !(desc->flags & AFX_PLAN_NO_SIDE_STREAM);
   const int st = upload_tables(p);
   if (st != AFX_OK) { free_tables(p); delete p; return st; }
   if (hipStreamCreateWithFlags(&p->up_stream, hipStreamNonBlocking) != hipSuccess ||
@@ -737,7 +741,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
                 const std::vector<int32_t>& status, bool zero_arena, Fill fill, afx_batch** out_batch,
                 Workspace* acquired = nullptr, const std::vector<int64_t>* file_samples = nullptr,
                 const std::vector<int32_t>* file_offset = nullptr, bool wait_for_uploads = true,
-                const std::vector<int32_t>* file_rate = nullptr) {
+                const std::vector<int32_t>* file_rate = nullptr, const std::vector<double>* scales = nullptr) {
   const bool want_stats = (mask & AFX_D_STATISTICS) != 0;
   mask &= ~(uint32_t)AFX_D_STATISTICS;   // the kernels see the descriptor bits only
 
@@ -758,7 +762,11 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   b->frame_offset.assign((size_t)n_bufs + 1, 0);
   b->buf_status = status;
   b->pcm_dtype = dtype;
-  const size_t esz = (dtype == AFX_PCM_F64) ? 8 : 4;
+  const size_t esz = (dtype == afx::kPcmF64) ? 8 : 4;
+  // kPcmScaledF32 (the LoadSample front end): the arena holds the float mono signal, the buffer's FinalScaling rides
+  // along in the chunk table / buffer spans / rhythm file records
+  auto scale_of = [&](int i) { return scales ? (*scales)[(size_t)i] : 1.0; };
+  if (scales) b->buf_scale = *scales;
 
   // arena offsets: every buffer starts on a 16-byte boundary and only the analysed prefix
   // (SampleAnalyser.cpp:760-764) of buffers that yield at least one frame is kept
@@ -839,6 +847,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
       c.frame0 = (int32_t)(b->frame_offset[i] + f0);
       c.nframes = (int16_t)std::min<int64_t>(k, f - f0);
       c.flags = (int16_t)(first ? afx::kChunkFirstOfBuffer : 0);
+      c.scale = scale_of(i);
       chunks.push_back(c);
       f0 += k;
     }
@@ -899,7 +908,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   if (n_bufs > 0 && (mask & AFX_D_EFFECTIVE_LENGTH)) {
     std::vector<afx::BufSpan>& spans = b->h_spans;
     spans.resize((size_t)n_bufs);
-    for (int i = 0; i < n_bufs; ++i) spans[(size_t)i] = afx::BufSpan{b->arena_off[i], b->used[i]};
+    for (int i = 0; i < n_bufs; ++i) spans[(size_t)i] = afx::BufSpan{b->arena_off[i], b->used[i], scale_of(i)};
     if ((e = ws_reserve(w.spans, spans.size() * sizeof(afx::BufSpan))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(spans)"));
     b->d_spans = (afx::BufSpan*)w.spans.p;
     if ((e = hipMemcpyAsync(b->d_spans, spans.data(), spans.size() * sizeof(afx::BufSpan), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(spans)"));
@@ -935,6 +944,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
       b->rt_offset[(size_t)i] = rows;
       afx::RhythmFile& rf = b->rt_files[(size_t)i];
       rf.sample_off = b->arena_off[i];
+      rf.scale = scale_of(i);
       rf.frame0 = rows;
       const int64_t len = (b->buf_status[i] == AFX_OK) ? std::min(analysed_length(plan, lengths[i]), b->used[i]) : 0;
       rf.frames = (len >= 512) ? (int32_t)((len - 512) / 128 + 1) : 0;
@@ -1307,8 +1317,10 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     if (speed == 1.0) continue;
     const double factor = 1.0 / speed, scaled = (double)(int)r.n_frames / speed;
     const double n_out_d = std::floor(scaled + 0.5);               // TMath::d2iRound of a positive value (InlineMath.inl:823-826)
-    // files above 16 x the analyser's rate (705.6 kHz) are outside what the kernels' zero margins cover
-    if (n_out_d >= 2147483647.0 || factor < 1.0 / 16.0 || conv_blocks > 0x7FFFFFF0) { status[i] = AFX_ERR_UNSUPPORTED; files[i] = afx::LoadFile{0, 0, 0, 0}; continue; }
+    // files above 16 x the analyser's rate (705.6 kHz) are outside what the kernels' zero margins cover; a file whose
+    // conversion would blow it up beyond reason (a header claiming a rate below the analyser's / 64, or more than 2^28
+    // converted samples = 1.7 hours) fails alone instead of exhausting the device for its whole batch
+    if (n_out_d >= 268435456.0 || factor < 1.0 / 16.0 || factor > 64.0 || conv_blocks > 0x7FFFFFF0) { status[i] = AFX_ERR_UNSUPPORTED; files[i] = afx::LoadFile{0, 0, 0, 0}; continue; }
     afx::ResampleFile c{};
     c.raw_off = files[i].raw_off; c.n_in = r.n_frames; c.channels = r.channels; c.format = r.format; c.factor = factor;
     c.n_out = std::max<int64_t>(1, (int64_t)n_out_d);
@@ -1421,21 +1433,25 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
     afx::LoadPlace* d_place = (afx::LoadPlace*)ws->place.p;
     b->h_place = place;   // the batch's own copy: the upload and the write kernel need not be waited for here
     e2 = hipMemcpyAsync(d_place, b->h_place.data(), b->h_place.size() * sizeof(afx::LoadPlace), hipMemcpyHostToDevice, b->stream);
-    if (e2 == hipSuccess) e2 = afx::launch_load_write(d_raw, d_files, d_place, n_bufs, (double*)b->d_pcm, b->stream);
+    if (e2 == hipSuccess) e2 = afx::launch_load_write(d_raw, d_files, d_place, n_bufs, (float*)b->d_pcm, b->stream);
     return e2 == hipSuccess ? AFX_OK : hip_fail(e2, "load_write");
   };
   // the workspace (with the staged PCM in it) moves into the batch; build_batch releases it on failure
   std::vector<int64_t> file_samples((size_t)n_bufs, 0);
   std::vector<int32_t> file_offset((size_t)n_bufs, 0);
+  // the arena keeps LoadSample's float signal; a sample of TSampleData::mData is (double)float * FinalScaling
+  // (SampleAnalyser.cpp:710-718), formed by the kernels as they load it
+  std::vector<double> scales((size_t)n_bufs, 1.0);
   for (int i = 0; i < n_bufs; ++i)
     if (status[i] == AFX_OK) {
+      scales[(size_t)i] = place[i].scaling;
       file_samples[(size_t)i] = raws[i].n_frames;                                 // mOriginalNumberOfSamples, SampleAnalyser.cpp:464 (before the conversion)
       file_offset[(size_t)i] = (int32_t)(-place[i].lead + place[i].start_pad);    // mDataOffset, SampleAnalyser.cpp:701
     }
   const long long t_placed = now_ns();
   // the decoded PCM has arrived (the scan was waited for): nothing of the caller's is read after this point
-  const int st = build_batch(plan, n_bufs, mask, AFX_PCM_F64, lengths, status, /*zero_arena=*/false, fill, out_batch, ws, &file_samples,
-                             &file_offset, /*wait_for_uploads=*/false, &file_rate);
+  const int st = build_batch(plan, n_bufs, mask, afx::kPcmScaledF32, lengths, status, /*zero_arena=*/false, fill, out_batch, ws, &file_samples,
+                             &file_offset, /*wait_for_uploads=*/false, &file_rate, &scales);
   if (g_create_timing.on) {
     const long long t_end = now_ns();
     g_create_timing.ns[0] += t_scanned - t_begin; g_create_timing.ns[1] += t_placed - t_scanned;
@@ -1446,15 +1462,40 @@ int afx_batch_create_from_raw(afx_plan* plan, const afx_raw* raws, int32_t n_buf
 
 int afx_batch_fetch_samples(afx_batch* b, int32_t buf, double* dst, int64_t n) {
   if (!b || !dst || buf < 0 || buf >= b->n_bufs || n < 0) return fail(AFX_ERR_INVALID_ARG, "bad argument");
-  if (b->pcm_dtype != AFX_PCM_F64) return fail(AFX_ERR_INVALID_ARG, "batch does not hold double PCM");
+  if (b->pcm_dtype == afx::kPcmF32) return fail(AFX_ERR_INVALID_ARG, "batch does not hold double PCM");
   const int64_t m = std::min<int64_t>(n, b->used[buf]);
   HIP_TRY(hipSetDevice(b->plan->desc.device));
   HIP_TRY(hipStreamSynchronize(b->stream));   // the LoadSample write kernel is not waited for at creation
-  if (m > 0) HIP_TRY(hipMemcpy(dst, (const double*)b->d_pcm + b->arena_off[buf], (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+  if (m <= 0) return AFX_OK;
+  if (b->pcm_dtype == afx::kPcmF64) {
+    HIP_TRY(hipMemcpy(dst, (const double*)b->d_pcm + b->arena_off[buf], (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+    return AFX_OK;
+  }
+  // LoadSample batches keep the float signal and the buffer's FinalScaling: the doubles of TSampleData::mData are their
+  // products (SampleAnalyser.cpp:710-718), formed here on demand exactly as the kernels form them
+  std::vector<float> tmp((size_t)m);
+  HIP_TRY(hipMemcpy(tmp.data(), (const float*)b->d_pcm + b->arena_off[buf], (size_t)m * sizeof(float), hipMemcpyDeviceToHost));
+  const double scaling = b->buf_scale[(size_t)buf];
+  for (int64_t k = 0; k < m; ++k) dst[k] = (double)tmp[(size_t)k] * scaling;
   return AFX_OK;
 }
 
 int64_t afx_batch_total_frames(const afx_batch* batch) { return batch ? batch->total_frames : 0; }
+
+int afx_batch_get_info(const afx_batch* b, afx_batch_info* info) {
+  if (!b || !info) return fail(AFX_ERR_INVALID_ARG, "null argument");
+  const uint32_t fmask = frames_mask(b->mask);
+  info->frame_kernel = b->halfwave ? AFX_FRAME_KERNEL_HALFWAVE : AFX_FRAME_KERNEL_WAVE64;
+  info->feature_class = afx::frames_feature_class(fmask);
+  info->pcm_kind = b->pcm_dtype;
+  info->chunk_frames = b->chunk_frames;
+  info->n_chunks = b->n_chunks;
+  info->grid_blocks = b->grid_blocks;
+  int64_t samples = 0;
+  for (size_t i = 0; i < b->used.size(); ++i) samples += (b->used[i] + 3) & ~(int64_t)3;
+  info->arena_bytes = samples * (b->pcm_dtype == afx::kPcmF64 ? 8 : 4);
+  return AFX_OK;
+}
 
 int afx_batch_run(afx_batch* b) {
   if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
@@ -1505,7 +1546,7 @@ int afx_batch_run(afx_batch* b) {
       a.queue_base = b->ws->queue_count;
       b->ws->queue_count += (unsigned)((b->n_chunks + 1) / 2);
       a.stat_tmp = b->d_stat_tmp;
-      HIP_TRY(afx::launch_frames32(a, b->grid_blocks, b->stream, b->total_frames));
+      HIP_TRY(afx::launch_frames32(a, b->grid_blocks, b->stream, b->total_frames, b->pcm_dtype == afx::kPcmScaledF32));
     } else HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
   }
   if (b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) {
@@ -1783,6 +1824,19 @@ void afx_batch_destroy(afx_batch* b) {
 #endif
   ws_release(b->plan, b->ws);
   delete b;
+}
+
+int afx_plan_probe_device(afx_plan* plan) {
+  if (!plan) return fail(AFX_ERR_INVALID_ARG, "null plan");
+  HIP_TRY(hipSetDevice(plan->desc.device));
+  (void)hipGetLastError();
+  // a trivial allocation and a query of the plan's own upload stream: both fail with the fault's error once the context is gone
+  void* p = nullptr;
+  HIP_TRY(hipMalloc(&p, 256));
+  HIP_TRY(hipFree(p));
+  const hipError_t e = hipStreamQuery(plan->up_stream);
+  if (e != hipSuccess && e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery");
+  return AFX_OK;
 }
 
 int afx_plan_set_blocking_wait(afx_plan* plan, int32_t blocking) {

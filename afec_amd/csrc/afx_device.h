@@ -138,6 +138,23 @@ __device__ __forceinline__ double wave_scan_incl(double v, int lane) {
 
 __device__ __forceinline__ double nan_to_zero(double v) { return (v != v) ? 0.0 : v; }
 
+// a double that is the same in every lane, moved to an SGPR pair (the compiler cannot prove it for values loaded through
+// a per-wave index)
+__device__ __forceinline__ double wave_uniform(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+// A PCM sample as the double the reference's loop sees.  SCALED (kPcmScaledF32, afx_internal.h): the arena holds the
+// float mono signal LoadSample worked on and `scale` is the buffer's FinalScaling -- the product, rounded once, is the
+// reference's TSampleData::mData[n] bit for bit (SampleAnalyser.cpp:710-718).
+// No contraction: fused into a later addition (fma(x, scale, b)) the product would be rounded once less than the
+// reference's stored double.
+template <bool SCALED, typename X>
+__device__ __forceinline__ double pcm_double(X x, double scale) {
+#pragma clang fp contract(off)
+  return SCALED ? (double)x * scale : (double)x;
+}
+
 // sqrt for magnitudes: x >= 0 and far from overflow, so the range scaling of the generic
 // expansion is dropped: one v_rsq_f64 seed, one Goldschmidt step, one residual correction
 // (<= 1 ulp).  Sums of squares below the smallest normal double are flushed to 0: the reference's

@@ -71,7 +71,7 @@ __device__ __forceinline__ double table_load1(__amdgpu_buffer_rsrc_t rs, int lan
 template <int IMM>
 __device__ __forceinline__ void dma_piece(const void* gaddr, unsigned lds_base) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2 nt"
-               :: "v"(gaddr), "s"(lds_base), "n"(IMM) : "memory");
+               :: "v"(gaddr), "s"(lds_base), "n"(IMM) : "memory", "m0");
 }
 // the eight pieces of a wave's hop image: global piece j at +512 j bytes, LDS piece j at +1024 j
 __device__ __forceinline__ void dma_hop(const float* g, unsigned lds_plane) {
@@ -100,11 +100,12 @@ __device__ __forceinline__ double mag_sqrt_mel(double xr, double xi, double tiny
 }
 
 // Lanes 0 and 32 (bins 32 r) are their own partners, at another register than everybody else's: two 64-bit moves
-// under EXEC = {0, 32} put their values in place, instead of four v_cndmask_b32 per row.  Only called where EXEC is
-// all ones (wave-uniform control flow).
+// under EXEC = {0, 32} put their values in place, instead of four v_cndmask_b32 per row.  EXEC is saved and restored
+// (the kernel's control flow is wave-uniform where this is called, but nothing here depends on that).
 __device__ __forceinline__ void keep_lane0(double& re, double& im, double own_re, double own_im, unsigned long long lane0_mask) {
-  asm("s_mov_b64 exec, %4\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3\n\ts_mov_b64 exec, -1"
-      : "+v"(re), "+v"(im) : "v"(own_re), "v"(own_im), "s"(lane0_mask));
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %5\n\tv_mov_b64 %0, %3\n\tv_mov_b64 %1, %4\n\ts_mov_b64 exec, %2"
+               : "+v"(re), "+v"(im), "=&s"(saved) : "v"(own_re), "v"(own_im), "s"(lane0_mask));
 }
 
 // ---- reduction of 16 per-lane values over the 32 lanes of each half, in registers: lane L ends with the total of
@@ -218,7 +219,7 @@ __device__ __forceinline__ void finish_mfcc32(double acc, double*& recp, int& le
 // bin) -- for ten more operations instead of a second fetch + untangle.  Rows 0..15, bin 512 (lane 0 of row 16, its own
 // partner) and M_15..M_8 cover the analysis range 1..738: 16 untangle steps instead of 24.
 
-template <int FEAT>
+template <int FEAT, bool SCALED>
 __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs a) {
   constexpr bool PAIRS = (FEAT == 1);
   // rows of 32 bins that are untangled directly: bins 0..383 for the mel filters, 0..511 (+ their mirrored blocks) for
@@ -290,6 +291,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
     const bool have = ci < a.n_chunks;
     const Chunk ch = a.chunks[have ? ci : 2 * slot];
     const int nfr = have ? ch.nframes : 0;
+    const double sc = ch.scale;   // SCALED: FinalScaling of this half's buffer (the arena holds LoadSample's float signal)
     const int total = max(__builtin_amdgcn_readlane(nfr, 0), __builtin_amdgcn_readlane(nfr, 32));
     const float2* src = reinterpret_cast<const float2*>(pcm + ch.sample_off) + q;
     // this lane's part in the LDS-DMA: the chunk of half dh
@@ -334,8 +336,10 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         // j + 16, j + 24 from the new hop): a w_a +- c w_c as one product and two fused multiply-adds
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const double ar = (double)lo[j].x, ai = (double)lo[j].y, br = (double)lo[j + 8].x, bi = (double)lo[j + 8].y;
-          const double cr = (double)nx[j].x, ci = (double)nx[j].y, dr = (double)nx[j + 8].x, di = (double)nx[j + 8].y;
+          const double ar = pcm_double<SCALED>(lo[j].x, sc), ai = pcm_double<SCALED>(lo[j].y, sc);
+          const double br = pcm_double<SCALED>(lo[j + 8].x, sc), bi = pcm_double<SCALED>(lo[j + 8].y, sc);
+          const double cr = pcm_double<SCALED>(nx[j].x, sc), ci = pcm_double<SCALED>(nx[j].y, sc);
+          const double dr = pcm_double<SCALED>(nx[j + 8].x, sc), di = pcm_double<SCALED>(nx[j + 8].y, sc);
           const double par = ar * w[j].x, pai = ai * w[j].y, pbr = br * w[j + 8].x, pbi = bi * w[j + 8].y;
           const double t0r = fma(cr, w[j + 16].x, par), t0i = fma(ci, w[j + 16].y, pai);
           const double t1r = fma(-cr, w[j + 16].x, par), t1i = fma(-ci, w[j + 16].y, pai);
@@ -782,13 +786,13 @@ int frames32_waves_per_block() { return kWaves32; }
 // which (descriptor mask, arithmetic, PCM type) combinations the half-wave kernels serve: MFCC alone, or MFCC with any
 // of the spectral statistics rms / centroid / spread / skewness / kurtosis / rolloff / flatness (bits 1..7)
 bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype) {
-  return (mask & 1u) && !(mask & ~0xFFu) && precision == 0 && pcm_dtype == 0;
+  return (mask & 1u) && !(mask & ~0xFFu) && precision == 0 && (pcm_dtype == kPcmF32 || pcm_dtype == kPcmScaledF32);
 }
 
-template <int FEAT>
+template <int FEAT, bool SCALED>
 static hipError_t launch_frames32_class(const FrameArgs& a, int grid_blocks, hipStream_t stream) {
   constexpr int lds = Lds32<kMel32Rows>::total;
-  auto k = frames32_kernel<FEAT>;
+  auto k = frames32_kernel<FEAT, SCALED>;
   static bool attribute_set[16] = {};   // per device: raising the dynamic LDS limit once is enough
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -801,12 +805,13 @@ static hipError_t launch_frames32_class(const FrameArgs& a, int grid_blocks, hip
   return hipGetLastError();
 }
 
-// f64 arithmetic, f32 PCM: the MFCC-only class, or the statistics class (a.mask has bits 1..7, a.stat_tmp holds
-// total_frames x 8 doubles) followed by its closed-form kernel
-hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames) {
+// f64 arithmetic, f32 PCM (scaled: the LoadSample front end's float signal times the buffer's FinalScaling): the
+// MFCC-only class, or the statistics class (a.mask has bits 1..7, a.stat_tmp holds total_frames x 8 doubles) followed
+// by its closed-form kernel
+hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames, bool scaled) {
   if (a.n_chunks <= 0) return hipSuccess;
-  if (a.mask == 1u) return launch_frames32_class<0>(a, grid_blocks, stream);
-  hipError_t e = launch_frames32_class<1>(a, grid_blocks, stream);
+  if (a.mask == 1u) return scaled ? launch_frames32_class<0, true>(a, grid_blocks, stream) : launch_frames32_class<0, false>(a, grid_blocks, stream);
+  hipError_t e = scaled ? launch_frames32_class<1, true>(a, grid_blocks, stream) : launch_frames32_class<1, false>(a, grid_blocks, stream);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(stats32_finish_kernel, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, stream, a, total_frames);
   return hipGetLastError();

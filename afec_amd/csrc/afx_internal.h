@@ -79,12 +79,21 @@ constexpr bool band_touches(int b, int r) {
 // 50..15500 Hz at 21 Hz/bin (SampleAnalyser.cpp:2077-2100), laid out contiguously from bin 1
 constexpr int kSubN[kNumSub] = {2, 4, 6, 10, 12, 15, 17, 23, 29, 41, 61, 96, 148, 287};
 
+// PCM element types of the analysis arena.  kPcmF32 / kPcmF64 are the ABI's AFX_PCM_F32 / AFX_PCM_F64 (buffers the
+// caller normalised itself).  kPcmScaledF32 is what the LoadSample front end leaves: the float mono signal of the file
+// (TSampleAnalyser::LoadSample's AnalyzationSampleBuffer, a TArray<float>, SampleAnalyser.cpp:487-491, 534-561, 625-631)
+// plus one double per buffer, FinalScaling -- the reference's TSampleData::mData[n] is exactly
+// (double)AnalyzationSampleBuffer[n + lead] * FinalScaling (SampleAnalyser.cpp:710-718), which every consumer forms
+// when it loads a sample: the same doubles at half the bytes.
+enum { kPcmF32 = 0, kPcmF64 = 1, kPcmScaledF32 = 2 };
+
 // chunk = a run of consecutive frames of one buffer processed by one wave
 struct Chunk {
   int64_t sample_off;  // offset of the first processed frame's first sample in the PCM arena
   int32_t frame0;      // global output row of the first *emitted* frame
   int16_t nframes;     // emitted frames
   int16_t flags;
+  double scale;        // kPcmScaledF32: the buffer's FinalScaling (1.0 otherwise)
 };
 // companion of Chunk for the time-domain kernels: samples of the buffer from the chunk's first frame on
 // (TSampleData::mData.Size() - n, SampleAnalyser.cpp:943), saturated at 2^30
@@ -125,13 +134,13 @@ struct FrameArgs {
   double* stat_tmp;             // half-wave statistics class: [F][8] raw sums per frame (afx_frames32.hip)   // diagnostic builds (AFX_STAMPS): 16 per-stage cycle counters, else nullptr
 };
 
-// launchers (afx_kernels.hip).  precision: 0 = f64, 1 = f32; pcm_dtype: AFX_PCM_*
+// launchers (afx_kernels.hip).  precision: 0 = f64, 1 = f32; pcm_dtype: kPcm*
 hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int grid_blocks,
                          hipStream_t stream);
 int frames_waves_per_block(uint32_t mask);    // waves (of 64 lanes) per workgroup
 // half-wave kernels (afx_frames32.hip): a wave walks two chunks at a time, one per 32-lane half
 bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype);
-hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames);
+hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames, bool scaled);
 int frames32_waves_per_block();
 int frames_feature_class(uint32_t mask);     // 0 = MFCC only, 1 = + statistics, 2 = everything
 
@@ -154,7 +163,7 @@ struct TimeArgs {
   const Chunk* chunks;
   const ChunkRemaining* remaining;
   int32_t n_chunks;
-  int32_t pcm_dtype;      // AFX_PCM_*
+  int32_t pcm_dtype;      // kPcm*
   double* rec;
   RecordLayout lay;
   const void* t1;         // the double FFT tables of FrameArgs
@@ -188,6 +197,7 @@ hipError_t launch_whiten(const WhitenArgs& a, hipStream_t stream);
 struct BufSpan {
   int64_t off;   // first sample of the buffer in the PCM arena
   int64_t n;     // samples (the whole buffer)
+  double scale;  // kPcmScaledF32: the buffer's FinalScaling (1.0 otherwise)
 };
 hipError_t launch_effective_length(const void* pcm, int pcm_dtype, const BufSpan* spans, int n_bufs, double floor48,
                                    double floor24, double floor12, int32_t* out, hipStream_t stream);
@@ -210,6 +220,7 @@ struct RhythmFile {
   int64_t frame0;       // first row of the buffer's 512/128 frames in the batch-wide arrays
   int32_t frames;       // 512/128 frames of the analysed prefix (SampleAnalyser.cpp:991)
   int32_t long_slot;    // > 0: the file's onset functions come from the long-file kernels (slot long_slot - 1)
+  double scale;         // kPcmScaledF32: the buffer's FinalScaling (1.0 otherwise)
   double duration_s;    // SampleDurationInSeconds (SampleAnalyser.cpp:1001-1002)
   double offset_s;      // OnsetOffsetInSeconds    (SampleAnalyser.cpp:1003-1004)
 };
@@ -217,7 +228,7 @@ constexpr int kRhythmLdsFrames = 8192;   // longest onset series the post kernel
 constexpr int kRayleighTable = 8192;   // beyond it the Rayleigh weight of the beat tracker has underflowed to 0
 struct RhythmArgs {
   const void* pcm;
-  int32_t pcm_dtype;            // AFX_PCM_*
+  int32_t pcm_dtype;            // kPcm*
   int32_t n_files;
   const RhythmFile* files;
   int64_t total_frames;
@@ -280,7 +291,7 @@ int load_scan_blocks_per_file(int n_files);      // partial_scratch holds n_file
 hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int n_files, double silence_floor,
                             void* partial_scratch, LoadScan* scan, hipStream_t stream);
 hipError_t launch_load_write(const unsigned char* raw, const LoadFile* files, const LoadPlace* place, int n_files,
-                             double* arena, hipStream_t stream);
+                             float* arena, hipStream_t stream);
 
 // ---- sample-rate conversion in front of the LoadSample kernels (SampleAnalyser.cpp:563-607 -> libresample; afx_resample.hip) ----
 // zero samples on either side of a file's mono mix: the filter's reach at the smallest supported factor (1/16: 18 x 16

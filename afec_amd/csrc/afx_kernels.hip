@@ -105,7 +105,7 @@ __device__ __forceinline__ void finish_mfcc(double acc, int nslots, int64_t row0
   if (n < kNumCep && s < nslots) a.rec[(row0 + s) * a.lay.stride + a.lay.mfcc + n] = c;
 }
 
-template <typename T, typename TIn, int FEAT, int WAVES>
+template <typename T, typename TIn, int FEAT, int WAVES, bool SCALED>
 __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
   using Pair = typename InPair<TIn>::type;
   constexpr int MR = (FEAT == kFeatC2) ? kMelRows : (FEAT == kFeatStats ? 12 : 16);
@@ -151,6 +151,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
     const Chunk ch = a.chunks[ci];
     const Pair* src = reinterpret_cast<const Pair*>(pcm + ch.sample_off) + lane;
     const int total = ch.nframes;
+    const double sc = SCALED ? wave_uniform(ch.scale) : 1.0;   // SCALED: the buffer's FinalScaling (the arena holds LoadSample's float signal)
 
     Pair lo[8], nxt[8];
 #pragma unroll
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
       if (FEAT != kFeatC2 && (a.mask & ((1u << 11) | (1u << 12)))) {
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-          const double x0 = (double)lo[r].x, x1 = (double)lo[r].y;
+          const double x0 = pcm_double<SCALED>(lo[r].x, sc), x1 = pcm_double<SCALED>(lo[r].y, sc);
           amp_peak = fmax(amp_peak, fmax(fabs(x0), fabs(x1)));
           amp_sq += x0 * x0 + x1 * x1;
         }
@@ -186,8 +187,8 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
       for (int r = 0; r < 8; ++r) {
         const cx<T> w0 = win[64 * r];
         const cx<T> w1 = win[64 * (r + 8)];
-        v[r] = {(T)lo[r].x * w0.re, (T)lo[r].y * w0.im};
-        v[r + 8] = {(T)nxt[r].x * w1.re, (T)nxt[r].y * w1.im};
+        v[r] = {(T)pcm_double<SCALED>(lo[r].x, sc) * w0.re, (T)pcm_double<SCALED>(lo[r].y, sc) * w0.im};
+        v[r + 8] = {(T)pcm_double<SCALED>(nxt[r].x, sc) * w1.re, (T)pcm_double<SCALED>(nxt[r].y, sc) * w1.im};
         lo[r] = nxt[r];
 #if AFX_TABLE_BATCH
         if ((2 * r + 2) % AFX_TABLE_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
@@ -410,11 +411,11 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
 constexpr int kWavesC2 = AFX_WAVES_C2;
 constexpr int kWavesOther = 8;
 
-template <typename T, typename TIn, int FEAT, int WAVES>
+template <typename T, typename TIn, int FEAT, int WAVES, bool SCALED>
 hipError_t launch_one(const FrameArgs& a, int grid_blocks, hipStream_t stream) {
   constexpr int MR = (FEAT == kFeatC2) ? kMelRows : (FEAT == kFeatStats ? 12 : 16);
   const size_t lds = (size_t)LdsMap<T, MR>::total(WAVES);
-  auto k = frames_kernel<T, TIn, FEAT, WAVES>;
+  auto k = frames_kernel<T, TIn, FEAT, WAVES, SCALED>;
   static bool attribute_set[16] = {};   // per device: raising the dynamic LDS limit once is enough
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -427,12 +428,12 @@ hipError_t launch_one(const FrameArgs& a, int grid_blocks, hipStream_t stream) {
   return hipGetLastError();
 }
 
-template <typename T, typename TIn>
+template <typename T, typename TIn, bool SCALED>
 hipError_t launch_typed(const FrameArgs& a, int feat, int grid_blocks, hipStream_t stream) {
   switch (feat) {
-    case kFeatC2: return launch_one<T, TIn, kFeatC2, kWavesC2>(a, grid_blocks, stream);
-    case kFeatStats: return launch_one<T, TIn, kFeatStats, kWavesOther>(a, grid_blocks, stream);
-    default: return launch_one<T, TIn, kFeatFull, kWavesOther>(a, grid_blocks, stream);
+    case kFeatC2: return launch_one<T, TIn, kFeatC2, kWavesC2, SCALED>(a, grid_blocks, stream);
+    case kFeatStats: return launch_one<T, TIn, kFeatStats, kWavesOther, SCALED>(a, grid_blocks, stream);
+    default: return launch_one<T, TIn, kFeatFull, kWavesOther, SCALED>(a, grid_blocks, stream);
   }
 }
 
@@ -451,8 +452,9 @@ hipError_t launch_frames(const FrameArgs& a, int precision, int pcm_dtype, int g
   if (a.n_chunks <= 0) return hipSuccess;
   const int feat = frames_feature_class(a.mask);
   if (precision != 0) return hipErrorInvalidValue;   // the float STFT mode is gone (include/afx.h, AFX_PRECISION_F32)
-  return pcm_dtype == 0 ? launch_typed<double, float>(a, feat, grid_blocks, stream)
-                        : launch_typed<double, double>(a, feat, grid_blocks, stream);
+  if (pcm_dtype == kPcmScaledF32) return launch_typed<double, float, true>(a, feat, grid_blocks, stream);
+  return pcm_dtype == kPcmF32 ? launch_typed<double, float, false>(a, feat, grid_blocks, stream)
+                              : launch_typed<double, double, false>(a, feat, grid_blocks, stream);
 }
 
 }  // namespace afx

@@ -3,15 +3,18 @@
 // TSampleAnalyser::LoadSample (SampleAnalyser.cpp:484-718) after the container decode: conversion to
 // the "16-bit float" range, mono mix-down, rms / peak, peak normalisation factor, -48 dB silence trim
 // and zero padding.  Byte / integer work and two reductions per file: HBM-bound by construction
-// (2..4 bytes in, 8 bytes out per sample).
+// (2..4 bytes in, 4 bytes out per sample).
 //
 //   load_scan   max |x| and sum (x/32768)^2 of the mono mix (several workgroups per file), then first and last sample
 //               whose normalised magnitude exceeds the silence floor (one workgroup per file, from both ends)
-//   load_write  writes scaling * x[lead + n] as doubles behind start_pad zeros, and the zeros of the pads
+//   load_write  writes the float mono signal x[lead + n] behind start_pad zeros, and the zeros of the pads; the
+//               buffer's FinalScaling stays a per-buffer double (kPcmScaledF32, afx_internal.h): the reference's
+//               mData[n] = (double)x * FinalScaling (SA:710-718) is formed by every consumer as it loads a sample
 
 #include <hip/hip_runtime.h>
 
 #include "afx_internal.h"
+#include "afx_device.h"
 
 namespace afx {
 namespace {
@@ -181,12 +184,12 @@ __global__ __launch_bounds__(kLoadThreads) void load_scan3_kernel(const unsigned
 }
 
 __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned char* raw, const LoadFile* files,
-                                                                  const LoadPlace* place, double* arena) {
+                                                                  const LoadPlace* place, float* arena) {
   const LoadFile f = files[blockIdx.x];
   const LoadPlace p = place[blockIdx.x];
   if (f.n_frames <= 0 || p.out_n <= 0) return;
   const unsigned char* src = raw + f.raw_off;
-  double* dst = arena + p.out_off;
+  float* dst = arena + p.out_off;
   // only the analysed prefix is kept
   int64_t n_copy = (p.audible < p.out_n - p.start_pad) ? p.audible : (p.out_n - p.start_pad);
   if (n_copy < 0) n_copy = 0;
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned
   if (blockIdx.y == 0) {
     const int64_t slot = (p.out_n + 3) & ~(int64_t)3, tail = p.start_pad + n_copy;
     const int64_t pad = p.start_pad < slot ? p.start_pad : slot;   // a capped analysis may end inside the start pad
-    for (int64_t n = threadIdx.x; n < pad; n += kLoadThreads) dst[n] = 0.0;
-    for (int64_t n = tail + threadIdx.x; n < slot; n += kLoadThreads) dst[n] = 0.0;
+    for (int64_t n = threadIdx.x; n < pad; n += kLoadThreads) dst[n] = 0.0f;
+    for (int64_t n = tail + threadIdx.x; n < slot; n += kLoadThreads) dst[n] = 0.0f;
   }
   // groups of four source frames on the source's alignment (vector loads); frames before `lead` and behind the copied
   // range are skipped
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned
     mono4(src, f.format, f.channels, s4, f.n_frames, x);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
-      if (s4 + k >= p.lead && s4 + k < s_end) dst[p.start_pad + (s4 + k - p.lead)] = (double)x[k] * p.scaling;  // SA:712-718
+      if (s4 + k >= p.lead && s4 + k < s_end) dst[p.start_pad + (s4 + k - p.lead)] = x[k];  // x p.scaling on load: SA:712-718
   }
 }
 
@@ -219,7 +222,7 @@ __global__ void effective_length_init_kernel(int32_t* out, int n) {
   if (i < n) out[i] = (i & 1) ? -1 : 0x7FFFFFFF;
 }
 
-template <typename TIn>
+template <typename TIn, bool SCALED>
 __global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TIn* pcm, const BufSpan* spans, double f0,
                                                                         double f1, double f2, int32_t* out) {
   __shared__ long long sl[kLoadThreads / 64];
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TI
   const double floors[3] = {f0, f1, f2};
   long long first[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, last[3] = {-1, -1, -1};
   for (int64_t n = (int64_t)blockIdx.y * kLoadThreads + threadIdx.x; n < sp.n; n += (int64_t)gridDim.y * kLoadThreads) {
-    const double v = fabs((double)x[n]);
+    const double v = fabs(pcm_double<SCALED>(x[n], sp.scale));
 #pragma unroll
     for (int j = 0; j < 3; ++j)
       if (v > floors[j]) {
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(kLoadThreads) void effective_length_kernel(const TI
 
 // The same for batches of many buffers: one workgroup per buffer walks blocks of 1024 samples from the front until
 // the highest floor has been crossed, then from the back -- typical audio is read only at its ends.
-template <typename TIn>
+template <typename TIn, bool SCALED>
 __global__ __launch_bounds__(kLoadThreads) void effective_length_ends_kernel(const TIn* pcm, const BufSpan* spans, double f0,
                                                                              double f1, double f2, int32_t* out) {
   __shared__ long long sl[kLoadThreads / 64];
@@ -265,7 +268,7 @@ __global__ __launch_bounds__(kLoadThreads) void effective_length_ends_kernel(con
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int64_t n = b * kBlock + (int64_t)k * kLoadThreads + threadIdx.x;
-      const double v = n < sp.n ? fabs((double)x[n]) : 0.0;
+      const double v = n < sp.n ? fabs(pcm_double<SCALED>(x[n], sp.scale)) : 0.0;
 #pragma unroll
       for (int j = 0; j < 3; ++j)
         if (v > floors[j] && n < lo[j]) lo[j] = n;
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(kLoadThreads) void effective_length_ends_kernel(con
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int64_t n = b * kBlock + (int64_t)k * kLoadThreads + threadIdx.x;
-        const double v = n < sp.n ? fabs((double)x[n]) : 0.0;
+        const double v = n < sp.n ? fabs(pcm_double<SCALED>(x[n], sp.scale)) : 0.0;
 #pragma unroll
         for (int j = 0; j < 3; ++j)
           if (v > floors[j] && n > hi[j]) hi[j] = n;
@@ -312,22 +315,28 @@ hipError_t launch_effective_length(const void* pcm, int pcm_dtype, const BufSpan
                                    double floor24, double floor12, int32_t* out, hipStream_t stream) {
   if (n_bufs <= 0) return hipSuccess;
   if (n_bufs >= 64) {   // many buffers: one workgroup each, from both ends (writes every output itself)
-    if (pcm_dtype == 0)
-      hipLaunchKernelGGL(effective_length_ends_kernel<float>, dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+    if (pcm_dtype == kPcmF32)
+      hipLaunchKernelGGL((effective_length_ends_kernel<float, false>), dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+                         reinterpret_cast<const float*>(pcm), spans, floor48, floor24, floor12, out);
+    else if (pcm_dtype == kPcmScaledF32)
+      hipLaunchKernelGGL((effective_length_ends_kernel<float, true>), dim3(n_bufs), dim3(kLoadThreads), 0, stream,
                          reinterpret_cast<const float*>(pcm), spans, floor48, floor24, floor12, out);
     else
-      hipLaunchKernelGGL(effective_length_ends_kernel<double>, dim3(n_bufs), dim3(kLoadThreads), 0, stream,
+      hipLaunchKernelGGL((effective_length_ends_kernel<double, false>), dim3(n_bufs), dim3(kLoadThreads), 0, stream,
                          reinterpret_cast<const double*>(pcm), spans, floor48, floor24, floor12, out);
     return hipGetLastError();
   }
   hipLaunchKernelGGL(effective_length_init_kernel, dim3((6 * n_bufs + 255) / 256), dim3(256), 0, stream, out, 6 * n_bufs);
   // few buffers: many workgroups per buffer; many buffers: one each
   const int per_buffer = 128;
-  if (pcm_dtype == 0)
-    hipLaunchKernelGGL(effective_length_kernel<float>, dim3(n_bufs, per_buffer), dim3(kLoadThreads), 0, stream,
+  if (pcm_dtype == kPcmF32)
+    hipLaunchKernelGGL((effective_length_kernel<float, false>), dim3(n_bufs, per_buffer), dim3(kLoadThreads), 0, stream,
+                       reinterpret_cast<const float*>(pcm), spans, floor48, floor24, floor12, out);
+  else if (pcm_dtype == kPcmScaledF32)
+    hipLaunchKernelGGL((effective_length_kernel<float, true>), dim3(n_bufs, per_buffer), dim3(kLoadThreads), 0, stream,
                        reinterpret_cast<const float*>(pcm), spans, floor48, floor24, floor12, out);
   else
-    hipLaunchKernelGGL(effective_length_kernel<double>, dim3(n_bufs, per_buffer), dim3(kLoadThreads), 0, stream,
+    hipLaunchKernelGGL((effective_length_kernel<double, false>), dim3(n_bufs, per_buffer), dim3(kLoadThreads), 0, stream,
                        reinterpret_cast<const double*>(pcm), spans, floor48, floor24, floor12, out);
   return hipGetLastError();
 }
@@ -346,7 +355,7 @@ hipError_t launch_load_scan(const unsigned char* raw, const LoadFile* files, int
 }
 
 hipError_t launch_load_write(const unsigned char* raw, const LoadFile* files, const LoadPlace* place, int n_files,
-                             double* arena, hipStream_t stream) {
+                             float* arena, hipStream_t stream) {
   if (n_files <= 0) return hipSuccess;
   hipLaunchKernelGGL(load_write_kernel, dim3(n_files, 8), dim3(kLoadThreads), 0, stream, raw, files, place, arena);
   return hipGetLastError();

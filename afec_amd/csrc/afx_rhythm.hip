@@ -151,9 +151,11 @@ __device__ __forceinline__ void dft16(C (&v)[16]) {
 // phase of bins q + 16 r as float.  z[j] = (w x)[2j] + i (w x)[2j+1], j = 16 n1 + n2: lane n2 = q holds n1 = 0..15.  The
 // window table carries the 1/2 of the real-input untangle (an exact scaling).  xg: the group's exchange plane (kPlane
 // doubles of LDS).
-template <typename PCM>
-__device__ __forceinline__ void onset_polar_frame(const PCM* xf, double* xg, const RhythmArgs& a, int q, float (&magf)[16],
-                                                  float (&phf)[16]) {
+// SCALED (kPcmScaledF32): the arena holds LoadSample's float signal, `scale` is the buffer's FinalScaling and the
+// reference's sample is their product (pcm_double, afx_device.h).
+template <typename PCM, bool SCALED>
+__device__ __forceinline__ void onset_polar_frame(const PCM* xf, double scale, double* xg, const RhythmArgs& a, int q,
+                                                  float (&magf)[16], float (&phf)[16]) {
   const C* tw = reinterpret_cast<const C*>(a.tw256);   // [n2][k1]: w256^(n2 k1)
   const C* ut = reinterpret_cast<const C*>(a.ut512);   // [r][q]:   w512^(q + 16 r)
   C v[16];
@@ -162,6 +164,10 @@ __device__ __forceinline__ void onset_polar_frame(const PCM* xf, double* xg, con
     const int j = 16 * n1 + q;
     double x0, x1, w0, w1;
     load2(xf + 2 * j, x0, x1);
+    if (SCALED) {
+      x0 = pcm_double<true>(x0, scale);
+      x1 = pcm_double<true>(x1, scale);
+    }
     load2(a.window + 2 * j, w0, w1);
     v[n1] = {w0 * x0, w1 * x1};
   }
@@ -286,7 +292,7 @@ __device__ __forceinline__ float onset_sum(const float* plane_p, const float* pl
   return v;
 }
 
-template <typename PCM>
+template <typename PCM, bool SCALED>
 __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel(RhythmArgs a) {
   __shared__ double s_x[kRound * kPlane];   // 34,816 B: exchange planes of the FFT stage, then the float polar / term rows
   const RhythmFile f = a.files[blockIdx.x];
@@ -304,7 +310,7 @@ __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel
   for (int t0 = 0; t0 < T; t0 += kRound) {
     const int nf = min(kRound, T - t0);
     float magf[16], phf[16];
-    if (g < nf) onset_polar_frame(x + (int64_t)(t0 + g) * kRtHop, xg, a, q, magf, phf);
+    if (g < nf) onset_polar_frame<PCM, SCALED>(x + (int64_t)(t0 + g) * kRtHop, f.scale, xg, a, q, magf, phf);
     __syncthreads();   // every group is done with its exchange plane: the polar rows take the space
     if (g < nf) {
 #pragma unroll
@@ -361,7 +367,7 @@ __device__ __forceinline__ int long_file_of_round(const RhythmArgs& a, int round
   return i;
 }
 
-template <typename PCM>
+template <typename PCM, bool SCALED>
 __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_polar_kernel(RhythmArgs a) {
   __shared__ double s_x[kRound * kPlane];
   int round;
@@ -371,7 +377,7 @@ __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_polar_kernel(Rh
   if (t0 + g >= T) return;
   const PCM* x = reinterpret_cast<const PCM*>(a.pcm) + f.sample_off;
   float magf[16], phf[16];
-  onset_polar_frame(x + (int64_t)(t0 + g) * kRtHop, s_x + g * kPlane, a, q, magf, phf);
+  onset_polar_frame<PCM, SCALED>(x + (int64_t)(t0 + g) * kRtHop, f.scale, s_x + g * kPlane, a, q, magf, phf);
   float2* row = a.long_polar + (a.long_frame_off[slot] + t0 + g) * 256;
 #pragma unroll
   for (int r = 0; r < 16; ++r) row[q + 16 * r] = float2{magf[r], phf[r]};
@@ -975,12 +981,14 @@ hipError_t launch_rhythm(const RhythmArgs& a, hipStream_t stream) {
   if (a.n_files <= 0) return hipSuccess;
   if (a.total_frames > 0) {
     if (a.n_long < a.n_files) {     // (every file long: nothing for the one-workgroup-per-file kernel)
-      if (a.pcm_dtype == 1) hipLaunchKernelGGL(onset_function_kernel<double>, dim3(a.n_files), dim3(256), 0, stream, a);
-      else hipLaunchKernelGGL(onset_function_kernel<float>, dim3(a.n_files), dim3(256), 0, stream, a);
+      if (a.pcm_dtype == kPcmF64) hipLaunchKernelGGL((onset_function_kernel<double, false>), dim3(a.n_files), dim3(256), 0, stream, a);
+      else if (a.pcm_dtype == kPcmScaledF32) hipLaunchKernelGGL((onset_function_kernel<float, true>), dim3(a.n_files), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((onset_function_kernel<float, false>), dim3(a.n_files), dim3(256), 0, stream, a);
     }
     if (a.n_long > 0) {
-      if (a.pcm_dtype == 1) hipLaunchKernelGGL(onset_polar_kernel<double>, dim3(a.long_rounds), dim3(256), 0, stream, a);
-      else hipLaunchKernelGGL(onset_polar_kernel<float>, dim3(a.long_rounds), dim3(256), 0, stream, a);
+      if (a.pcm_dtype == kPcmF64) hipLaunchKernelGGL((onset_polar_kernel<double, false>), dim3(a.long_rounds), dim3(256), 0, stream, a);
+      else if (a.pcm_dtype == kPcmScaledF32) hipLaunchKernelGGL((onset_polar_kernel<float, true>), dim3(a.long_rounds), dim3(256), 0, stream, a);
+      else hipLaunchKernelGGL((onset_polar_kernel<float, false>), dim3(a.long_rounds), dim3(256), 0, stream, a);
       hipLaunchKernelGGL(onset_follow_kernel, dim3(a.n_long), dim3(256), 0, stream, a);
       hipLaunchKernelGGL(onset_terms_kernel, dim3(a.long_rounds), dim3(256), 0, stream, a);
     }

@@ -51,6 +51,16 @@ __device__ __forceinline__ void load16(const double* p, double (&x)[16]) {
   }
 }
 
+// kPcmScaledF32: the sixteen loaded samples times the buffer's FinalScaling (each product rounded once, like the
+// reference's stored doubles: pcm_double, afx_device.h)
+template <bool SCALED>
+__device__ __forceinline__ void scale16(double (&x)[16], double scale) {
+  if (SCALED) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) x[i] = pcm_double<true>(x[i], scale);
+  }
+}
+
 using mask64 = unsigned long long;
 __device__ __forceinline__ int wave_min_i(int v) {
 #pragma unroll
@@ -73,7 +83,7 @@ __device__ __forceinline__ bool au_silent(double sum_sq, int n) {
 // ---------------------------------------------------------------------------------------------
 // hop kernel: silence flag + envelope maximum of the hop (first 1024 samples of the frame)
 // ---------------------------------------------------------------------------------------------
-template <typename TIn>
+template <typename TIn, bool SCALED>
 __global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
   const int lane = threadIdx.x & 63;
   const int wave_global = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -91,9 +101,11 @@ __global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];
+    const double sc = SCALED ? wave_uniform(ch.scale) : 1.0;
     for (int fi = 0; fi < ch.nframes; ++fi) {
       double x[16];
       load16(pcm + ch.sample_off + (int64_t)fi * kHop + 16 * lane, x);
+      scale16<SCALED>(x, sc);
       double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
 
       double e = 0.0;
@@ -182,7 +194,7 @@ __device__ __forceinline__ void even_odd(cx<double> z, cx<double> p, cx<double>&
 // ---------------------------------------------------------------------------------------------
 // auto_correlation (SA:2312-2398)
 // ---------------------------------------------------------------------------------------------
-template <typename TIn>
+template <typename TIn, bool SCALED>
 __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const TimeCtx c = time_setup(a, lds_raw);
@@ -195,6 +207,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];
+    const double sc = SCALED ? wave_uniform(ch.scale) : 1.0;
     const int remaining0 = a.remaining[ci];
     for (int fi = 0; fi < ch.nframes; ++fi) {
       const TIn* const x = pcm + ch.sample_off + (int64_t)fi * kHop;
@@ -255,7 +268,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
         wave_lds_fence();
 #pragma unroll
         for (int q = 0; q < 25; ++q)
-          if (q >= q0 && q < q0 + 10) c.plane_d[64 * (q - q0) + lane] = (double)ra[q];
+          if (q >= q0 && q < q0 + 10) c.plane_d[64 * (q - q0) + lane] = pcm_double<SCALED>(ra[q], sc);
         wave_lds_fence();
         // r[i] = sum_j s[j] s[j+i] through the 2048-point transform of the zero-padded segment
         cx<double> v[16];
@@ -313,7 +326,7 @@ struct PairOf<float> { using type = float2; };
 template <>
 struct PairOf<double> { using type = double2; };
 
-template <typename TIn>
+template <typename TIn, bool SCALED>
 __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a) {
   using Pair = typename PairOf<TIn>::type;
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -328,6 +341,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];
+    const double sc = SCALED ? wave_uniform(ch.scale) : 1.0;
     // transform of the zero-padded first half of the chunk's first frame (packed z[m] = x[2m] + i x[2m+1])
     cx<double> zu[16];
     {
@@ -337,7 +351,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
         zu[r] = {0.0, 0.0};
         if (r < 8) {
           const Pair p = src[64 * r];
-          zu[r] = {(double)p.x, (double)p.y};
+          zu[r] = {pcm_double<SCALED>(p.x, sc), pcm_double<SCALED>(p.y, sc)};
         }
       }
     }
@@ -357,7 +371,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
           zn[r] = {0.0, 0.0};
           if (r < 8) {
             const Pair p = src[64 * r];
-            zn[r] = {(double)p.x, (double)p.y};
+            zn[r] = {pcm_double<SCALED>(p.x, sc), pcm_double<SCALED>(p.y, sc)};
           }
         }
       }
@@ -410,6 +424,8 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       double xa[16], xb[16];
       load16(x + 16 * lane, xa);
       load16(x + W + 16 * lane, xb);
+      scale16<SCALED>(xa, sc);
+      scale16<SCALED>(xb, sc);
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -533,37 +549,44 @@ int time_grid(int n_chunks, int waves) {
 hipError_t launch_hop(const TimeArgs& a, hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
   const int grid = (a.n_chunks + 3) / 4 < 2048 ? (a.n_chunks + 3) / 4 : 2048;
-  if (a.pcm_dtype == 0) hipLaunchKernelGGL(hop_kernel<float>, dim3(grid), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(hop_kernel<double>, dim3(grid), dim3(256), 0, stream, a);
+  if (a.pcm_dtype == kPcmF32) hipLaunchKernelGGL((hop_kernel<float, false>), dim3(grid), dim3(256), 0, stream, a);
+  else if (a.pcm_dtype == kPcmScaledF32) hipLaunchKernelGGL((hop_kernel<float, true>), dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL((hop_kernel<double, false>), dim3(grid), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 
 hipError_t launch_acorr(const TimeArgs& a, hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
-  static bool done_f[16] = {}, done_d[16] = {};
+  static bool done_f[16] = {}, done_d[16] = {}, done_s[16] = {};
   const int grid = time_grid(a.n_chunks, kTimeWaves);
   hipError_t e;
-  if (a.pcm_dtype == 0) {
-    if ((e = raise_lds_limit(acorr_kernel<float>, done_f)) != hipSuccess) return e;
-    hipLaunchKernelGGL(acorr_kernel<float>, dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+  if (a.pcm_dtype == kPcmF32) {
+    if ((e = raise_lds_limit(acorr_kernel<float, false>, done_f)) != hipSuccess) return e;
+    hipLaunchKernelGGL((acorr_kernel<float, false>), dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+  } else if (a.pcm_dtype == kPcmScaledF32) {
+    if ((e = raise_lds_limit(acorr_kernel<float, true>, done_s)) != hipSuccess) return e;
+    hipLaunchKernelGGL((acorr_kernel<float, true>), dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
   } else {
-    if ((e = raise_lds_limit(acorr_kernel<double>, done_d)) != hipSuccess) return e;
-    hipLaunchKernelGGL(acorr_kernel<double>, dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+    if ((e = raise_lds_limit(acorr_kernel<double, false>, done_d)) != hipSuccess) return e;
+    hipLaunchKernelGGL((acorr_kernel<double, false>), dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_pitch(const TimeArgs& a, hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
-  static bool done_f[16] = {}, done_d[16] = {};
+  static bool done_f[16] = {}, done_d[16] = {}, done_s[16] = {};
   const int grid = time_grid(a.n_chunks, kTimeWaves);
   hipError_t e;
-  if (a.pcm_dtype == 0) {
-    if ((e = raise_lds_limit(pitch_kernel<float>, done_f)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pitch_kernel<float>, dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+  if (a.pcm_dtype == kPcmF32) {
+    if ((e = raise_lds_limit(pitch_kernel<float, false>, done_f)) != hipSuccess) return e;
+    hipLaunchKernelGGL((pitch_kernel<float, false>), dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+  } else if (a.pcm_dtype == kPcmScaledF32) {
+    if ((e = raise_lds_limit(pitch_kernel<float, true>, done_s)) != hipSuccess) return e;
+    hipLaunchKernelGGL((pitch_kernel<float, true>), dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
   } else {
-    if ((e = raise_lds_limit(pitch_kernel<double>, done_d)) != hipSuccess) return e;
-    hipLaunchKernelGGL(pitch_kernel<double>, dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
+    if ((e = raise_lds_limit(pitch_kernel<double, false>, done_d)) != hipSuccess) return e;
+    hipLaunchKernelGGL((pitch_kernel<double, false>), dim3(grid), dim3(kTimeWaves * 64), kTimeLdsBytes, stream, a);
   }
   return hipGetLastError();
 }

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -183,6 +184,7 @@ struct TCrawler::TImpl {
   std::vector<std::unique_ptr<TSampleAnalyser>> mAnalysers;
   TPinnedPool mRecordPool, mStatisticsPool, mRhythmPool, mStagingPool;   // one pool per kind of buffer: nothing regrows
   TRowSetPool mRowPool;
+  int mHardwareQueuesInEnvironment = 0;
 };
 
 TCrawler::TCrawler(const TCrawlOptions& Options) : mpImpl(new TImpl) {
@@ -193,8 +195,16 @@ TCrawler::TCrawler(const TCrawlOptions& Options) : mpImpl(new TImpl) {
     // one analyser (plan) per device, shared by that device's workers like the reference's const analyser; the
     // workers' waits for the device sleep instead of spinning (eight spinning threads per GPU would need eight CPUs
     // per GPU for the same throughput); the hardware-queue wish has to reach the runtime before its first call
+    // (setenv is not safe against a concurrent getenv in another thread and has no effect once the HIP runtime is up:
+    // an embedding application sets the variable itself at process start -- bench.py does -- and passes
+    // mHardwareQueues = 0; what the environment says when the crawler is built is reported in
+    // TCrawlStatistics::mHardwareQueuesInEnvironment)
     if (Options.mHardwareQueues > 0)
       ::setenv("GPU_MAX_HW_QUEUES", std::to_string(Options.mHardwareQueues).c_str(), /*overwrite=*/0);
+    {
+      const char* const q = std::getenv("GPU_MAX_HW_QUEUES");
+      mpImpl->mHardwareQueuesInEnvironment = q ? std::atoi(q) : 0;
+    }
     for (int Device : Options.mDevices) {
       mpImpl->mAnalysers.emplace_back(new TSampleAnalyser(Options.mSampleRate, Options.mFftFrameSize, Options.mHopFrameSize, Device));
       mpImpl->mAnalysers.back()->SetSleepingWaits(Options.mSleepingWaits);
@@ -242,6 +252,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
 
   TCrawlStatistics Total;
   Total.mFilesPerDevice.assign((size_t)G, 0);
+  Total.mHardwareQueuesInEnvironment = mpImpl->mHardwareQueuesInEnvironment;
   double PhaseSeconds[2] = {0, 0};   // summed over workers: parse + staging copy, GPU round trip
   double GpuSeconds[3] = {0, 0, 0};  // of the round trip: upload + LoadSample, kernels enqueue, download + wait
   double PhaseCpuSeconds[3] = {0, 0, 0};   // CPU time of the threads: workers parse + staging, workers GPU round trip, writer
@@ -250,9 +261,157 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   std::atomic<bool> Abort(false);
   std::string FirstError;
 
+  // ---- one batch on the GPU, with the reference's failure semantics (SampleAnalyser.cpp:368-408: a file that cannot
+  // be analysed gets a failed row and the crawl goes on) for errors of the device path: a batch whose GPU round trip
+  // fails -- out of device memory, results that do not fit, a failed runtime call -- is cut in halves and each half is
+  // tried on its own; a single file is tried twice and then recorded as "Sample failed to analyse: ...".  Only a device
+  // that no longer answers ends the crawl.
+  std::atomic<int> NextOrdinal(0);
+  std::atomic<int> FaultBudget(Options.mTestFailAttempts < 0 ? (1 << 30) : Options.mTestFailAttempts);
+  const int64_t DeviceBytesPerBatch = Options.mDeviceBytesPerBatch < 1 ? 1 : Options.mDeviceBytesPerBatch;
+  // device memory a file needs once it is analysed: its converted samples as floats, the raw upload, 8 KiB of
+  // magnitudes + ~1 KiB of records per 1024-sample hop, the rhythm tracker's rows (a converted file may be far larger
+  // than its bytes on disk: a header that claims a low sampling rate)
+  auto DeviceBytesOf = [&](const TDecodedSample& s) -> int64_t {
+    const int64_t Converted = TSampleAnalyser::ConvertedSampleFrames(s, Options.mSampleRate);
+    return Converted * 16 + s.mNumberOfSampleFrames * s.mNumberOfChannels * 4;
+  };
+
+  struct TWork {
+    std::unique_ptr<TFinishedBatch> mpDone;
+    std::vector<TDecodedSample> mDecoded;
+    int mOrdinal = 0;
+  };
+  // the two halves of a batch: decoded files [0, m) and [m, K); files that never reached the GPU stay with the first
+  auto Split = [](TWork& Whole, TWork& A, TWork& B) {
+    const size_t K = Whole.mDecoded.size(), m = K / 2;
+    A.mpDone.reset(new TFinishedBatch); B.mpDone.reset(new TFinishedBatch);
+    A.mOrdinal = B.mOrdinal = Whole.mOrdinal;
+    A.mDecoded.assign(Whole.mDecoded.begin(), Whole.mDecoded.begin() + (long)m);
+    B.mDecoded.assign(Whole.mDecoded.begin() + (long)m, Whole.mDecoded.end());
+    TFinishedBatch& W = *Whole.mpDone;
+    for (size_t i = 0; i < W.mFiles.size(); ++i) {
+      const int k = W.mBatchIndex[i];
+      TFinishedBatch& T = (k >= (int)m) ? *B.mpDone : *A.mpDone;
+      T.mFiles.push_back(W.mFiles[i]);
+      T.mProperties.push_back(W.mProperties[i]);
+      T.mFailed.push_back(W.mFailed[i]);
+      T.mSkipped.push_back(W.mSkipped[i]);
+      T.mBatchIndex.push_back(k < 0 ? -1 : (k >= (int)m ? k - (int)m : k));
+    }
+  };
+
+  std::function<void(int, TWork&, int)> Process = [&](int d, TWork& Work, int Attempt) {
+    const TSampleAnalyser& Analyser = *Analysers[(size_t)d];
+    TFinishedBatch& Done = *Work.mpDone;
+    const std::vector<TDecodedSample>& Decoded = Work.mDecoded;
+    const size_t n = Done.mFiles.size();
+    // a batch whose converted samples would not fit the device budget is cut before it is tried
+    if (Decoded.size() > 1) {
+      int64_t Need = 0;
+      for (const TDecodedSample& s : Decoded) Need += DeviceBytesOf(s);
+      if (Need > DeviceBytesPerBatch) {
+        TWork A, B;
+        Split(Work, A, B);
+        Process(d, A, 0);
+        Process(d, B, 0);
+        return;
+      }
+    }
+    const double tGpu0 = Now(), cGpu0 = ThreadCpuSeconds();
+    int64_t Frames = 0, ResultBytes = 0, PcmBytes = 0;
+    for (const TDecodedSample& s : Decoded) PcmBytes += s.mNumberOfSampleFrames * s.mNumberOfChannels * (s.mFormat == AFX_RAW_I16 ? 2 : (s.mFormat == AFX_RAW_I24 ? 3 : (s.mFormat == AFX_RAW_F64 ? 8 : 4)));
+    if (!Decoded.empty()) {
+      try {
+        if (Work.mOrdinal == Options.mTestFailBatch && FaultBudget.fetch_sub(1) > 0)
+          throw TReadableException("GPU feature extraction failed: injected fault (TCrawlOptions::mTestFailBatch)");
+        Done.mpStatistics = StatisticsPool.Acquire(Decoded.size() * (size_t)TSampleAnalyser::kMaxStride * 13 * sizeof(double));
+        Done.mpRhythm = RhythmPool.Acquire(Analyser.RhythmDoubles(Decoded) * sizeof(double));
+        // frames are at most samples / hop + 2 per file (LoadSample pads by up to a frame)
+        size_t MaxFrames = 0;
+        for (const TDecodedSample& s : Decoded) MaxFrames += (size_t)(TSampleAnalyser::ConvertedSampleFrames(s, Options.mSampleRate) / Options.mHopFrameSize) + 3;
+        size_t Capacity = MaxFrames * (size_t)TSampleAnalyser::kMaxStride;
+        int Attempts = 0;
+        for (;;) {
+          if (Done.mpRecords) Done.mpRecords->Reserve(Capacity * sizeof(double));
+          else Done.mpRecords = Pool.Acquire(Capacity * sizeof(double));
+          if (Analyser.AnalyzeToRecords(Decoded, (double*)Done.mpRecords->mp, Done.mpRecords->mBytes / sizeof(double),
+                                        (double*)Done.mpStatistics->mp, (double*)Done.mpRhythm->mp,
+                                        Done.mpRhythm->mBytes / sizeof(double), Done.mResults))
+            break;
+          if (++Attempts > 6) throw TReadableException("AnalyzeToRecords: the results do not fit the largest buffers tried");
+          Capacity *= 2;
+          Done.mpRhythm->Reserve(2 * Done.mpRhythm->mBytes);
+        }
+      } catch (const TReadableException& e) {
+        Pool.Release(std::move(Done.mpRecords));
+        StatisticsPool.Release(std::move(Done.mpStatistics));
+        RhythmPool.Release(std::move(Done.mpRhythm));
+        Done.mResults = TRecordBatch();
+        if (Options.mTestDeviceLost || !Analyser.DeviceUsable()) throw;   // nothing more can be analysed: the crawl ends
+        {
+          std::lock_guard<std::mutex> Lock(StatMutex);
+          Total.mRetriedBatches += 1;
+        }
+        if (Decoded.size() > 1) {
+          TWork A, B;
+          Split(Work, A, B);
+          Process(d, A, 0);
+          Process(d, B, 0);
+          return;
+        }
+        if (Attempt == 0) { Process(d, Work, 1); return; }
+        // one file, twice, on a device that still answers: the file's row says so (SampleAnalyser.cpp:397-408)
+        for (size_t i = 0; i < n; ++i)
+          if (Done.mBatchIndex[i] >= 0) {
+            Done.mFailed[i] = std::string("Sample failed to analyse: ") + e.what();
+            Done.mBatchIndex[i] = -1;
+          }
+        Work.mDecoded.clear();
+        std::lock_guard<std::mutex> Lock(StatMutex);
+        Total.mDeviceFailedFiles += 1;
+      }
+    }
+    if (!Work.mDecoded.empty()) {
+      Frames = Done.mResults.mFrameOffset.back();
+      ResultBytes = (Frames * Done.mResults.mStride + (int64_t)Decoded.size() * Done.mResults.mStride * 13 +
+                     Done.mResults.mRhythmOffset.back() * 2 + (int64_t)Decoded.size() * 40) * 8;
+      for (size_t i = 0; i < n; ++i) {
+        const int k = Done.mBatchIndex[i];
+        // the per-file status of the LoadSample front end (a buffer it cannot take): a load failure (SampleAnalyser.cpp:372-387)
+        if (k >= 0 && Done.mResults.mStatus[(size_t)k] != AFX_OK)
+          Done.mFailed[i] = std::string("Sample failed to load: ") + afx_status_str(Done.mResults.mStatus[(size_t)k]);
+      }
+      // with a database: the rows' column values are built here, by the eight workers, not by the one writer
+      if (pPool && Options.mPrepareRowsInWorkers) {
+        Done.mpRows = RowPool.Acquire();
+        if (Done.mpRows->mRows.size() < Decoded.size()) Done.mpRows->mRows.resize(Decoded.size());
+        for (size_t i = 0; i < n; ++i) {
+          const int k = Done.mBatchIndex[i];
+          if (k < 0 || !Done.mFailed[i].empty()) continue;
+          const TSampleDescriptors Results = Done.mResults.Descriptors(k);
+          RefillLowLevelColumns(Done.mpRows->mRows[(size_t)k], Results, &Done.mResults.mInfo[(size_t)k]);
+        }
+      }
+    }
+    const double tGpu1 = Now(), cGpu1 = ThreadCpuSeconds();
+    {
+      std::lock_guard<std::mutex> Lock(StatMutex);
+      PhaseSeconds[1] += tGpu1 - tGpu0;
+      PhaseCpuSeconds[1] += cGpu1 - cGpu0;
+      for (int k = 0; k < 3; ++k) GpuSeconds[k] += Done.mResults.mSeconds[k];
+      Total.mFiles += (int64_t)n;
+      Total.mBatches += 1;
+      Total.mFrames += Frames;
+      Total.mPcmBytes += Work.mDecoded.empty() ? 0 : PcmBytes;
+      Total.mResultBytes += ResultBytes;
+      Total.mFilesPerDevice[(size_t)d] += (int64_t)n;
+    }
+    Queue.Push(std::move(Work.mpDone));
+  };
+
   auto Worker = [&](int d) {
     try {
-      const TSampleAnalyser& Analyser = *Analysers[(size_t)d];
       struct TStagingLease {   // the worker's page-locked staging buffer goes back to the crawler when the worker ends
         TPinnedPool& mPool;
         std::unique_ptr<TPinned> mp;
@@ -265,6 +424,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
         // the staging buffer, the device workspace and the result buffers all scale with the PCM of a batch)
         size_t Begin, End;
         int64_t BatchBytes = 0;
+        TWork Work;
         {
           std::lock_guard<std::mutex> Lock(CursorMutex[(size_t)d]);
           const std::vector<const TCrawlFile*>& Mine = Shard[(size_t)d];
@@ -277,9 +437,10 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
             ++End;
           }
           Cursor[(size_t)d] = End;
+          Work.mOrdinal = NextOrdinal.fetch_add(1);   // batches in the order they were cut (per device: the order of its files)
         }
-        std::unique_ptr<TFinishedBatch> pDone(new TFinishedBatch);
-        TFinishedBatch& Done = *pDone;
+        Work.mpDone.reset(new TFinishedBatch);
+        TFinishedBatch& Done = *Work.mpDone;
         const size_t n = End - Begin;
         Done.mFiles.assign(Shard[(size_t)d].begin() + (long)Begin, Shard[(size_t)d].begin() + (long)End);
         Done.mProperties.resize(n);
@@ -292,10 +453,9 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
         // payloads back to back, 16-byte aligned, so that the C-ABI uploads the batch in one transfer): a memcpy out of
         // a file image, a pread out of the page cache for a file on disk.  The buffer is sized from the files' sizes
         // up front; only 8-bit files (widened to int16) can make it grow on the way.
-        std::vector<TDecodedSample> Decoded;
+        std::vector<TDecodedSample>& Decoded = Work.mDecoded;
         std::vector<size_t> Offset;
         size_t Bytes = 0;
-        int64_t PcmBytes = 0;
         Staging.Reserve((size_t)BatchBytes + 16 * n + 64);
         TWaveFile Wave;
         for (size_t i = 0; i < n; ++i) {
@@ -320,71 +480,19 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
             Decoded.push_back(s);
             Offset.push_back(Bytes);
             Bytes += (Size + 15) & ~(size_t)15;
-            PcmBytes += (int64_t)Size;
           } catch (const TReadableException& e) {
             Wave.Close();
-            Done.mFailed[i] = e.what();
+            Done.mFailed[i] = std::string("Sample failed to load: ") + e.what();   // SampleAnalyser.cpp:372-387
           }
         }
         for (size_t k = 0; k < Decoded.size(); ++k) Decoded[k].mpInterleavedSamples = (char*)Staging.mp + Offset[k];
-        const double tGpu0 = Now(), cGpu0 = ThreadCpuSeconds();
-        // GPU: LoadSample + descriptors + statistics; results straight into page-locked buffers
-        int64_t Frames = 0, ResultBytes = 0;
-        if (!Decoded.empty()) {
-          Done.mpStatistics = StatisticsPool.Acquire(Decoded.size() * (size_t)TSampleAnalyser::kMaxStride * 13 * sizeof(double));
-          Done.mpRhythm = RhythmPool.Acquire(TSampleAnalyser::RhythmDoubles(Decoded) * sizeof(double));
-          // frames are at most samples / hop + 2 per file (LoadSample pads by up to a frame)
-          size_t MaxFrames = 0;
-          for (const TDecodedSample& s : Decoded) MaxFrames += (size_t)(TSampleAnalyser::ConvertedSampleFrames(s, Options.mSampleRate) / Options.mHopFrameSize) + 3;
-          size_t Capacity = MaxFrames * (size_t)TSampleAnalyser::kMaxStride;
-          int Attempts = 0;
-          for (;;) {
-            if (Done.mpRecords) Done.mpRecords->Reserve(Capacity * sizeof(double));
-            else Done.mpRecords = Pool.Acquire(Capacity * sizeof(double));
-            if (Analyser.AnalyzeToRecords(Decoded, (double*)Done.mpRecords->mp, Done.mpRecords->mBytes / sizeof(double),
-                                          (double*)Done.mpStatistics->mp, (double*)Done.mpRhythm->mp,
-                                          Done.mpRhythm->mBytes / sizeof(double), Done.mResults))
-              break;
-            if (++Attempts > 6) throw TReadableException("AnalyzeToRecords: the results do not fit the largest buffers tried");
-            Capacity *= 2;
-            Done.mpRhythm->Reserve(2 * Done.mpRhythm->mBytes);
-          }
-          Frames = Done.mResults.mFrameOffset.back();
-          ResultBytes = (Frames * Done.mResults.mStride + (int64_t)Decoded.size() * Done.mResults.mStride * 13 +
-                         Done.mResults.mRhythmOffset.back() * 2 + (int64_t)Decoded.size() * 40) * 8;
-          for (size_t i = 0; i < n; ++i) {
-            const int k = Done.mBatchIndex[i];
-            if (k >= 0 && Done.mResults.mStatus[(size_t)k] != AFX_OK)
-              Done.mFailed[i] = std::string(afx_status_str(Done.mResults.mStatus[(size_t)k]));
-          }
-          // with a database: the rows' column values are built here, by the eight workers, not by the one writer
-          if (pPool && Options.mPrepareRowsInWorkers) {
-            Done.mpRows = RowPool.Acquire();
-            if (Done.mpRows->mRows.size() < Decoded.size()) Done.mpRows->mRows.resize(Decoded.size());
-            for (size_t i = 0; i < n; ++i) {
-              const int k = Done.mBatchIndex[i];
-              if (k < 0 || !Done.mFailed[i].empty()) continue;
-              const TSampleDescriptors Results = Done.mResults.Descriptors(k);
-              RefillLowLevelColumns(Done.mpRows->mRows[(size_t)k], Results, &Done.mResults.mInfo[(size_t)k]);
-            }
-          }
-        }
-        const double tGpu1 = Now(), cGpu1 = ThreadCpuSeconds();
         {
           std::lock_guard<std::mutex> Lock(StatMutex);
-          PhaseSeconds[0] += tGpu0 - tParse0;
-          PhaseSeconds[1] += tGpu1 - tGpu0;
-          PhaseCpuSeconds[0] += cGpu0 - cParse0;
-          PhaseCpuSeconds[1] += cGpu1 - cGpu0;
-          for (int k = 0; k < 3; ++k) GpuSeconds[k] += Done.mResults.mSeconds[k];
-          Total.mFiles += (int64_t)n;
-          Total.mBatches += 1;
-          Total.mFrames += Frames;
-          Total.mPcmBytes += PcmBytes;
-          Total.mResultBytes += ResultBytes;
-          Total.mFilesPerDevice[(size_t)d] += (int64_t)n;
+          PhaseSeconds[0] += Now() - tParse0;
+          PhaseCpuSeconds[0] += ThreadCpuSeconds() - cParse0;
         }
-        Queue.Push(std::move(pDone));
+        // GPU: LoadSample + descriptors + statistics; results straight into page-locked buffers
+        Process(d, Work, 0);
       }
     } catch (const std::exception& e) {
       std::lock_guard<std::mutex> Lock(StatMutex);
@@ -406,6 +514,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
         Abort = true;
       }
       for (size_t i = 0; i < p->mFiles.size(); ++i) {
+        if (Abort) break;     // a failed insert rolled the batch's transaction back: no partial batch is committed behind it
         const TCrawlFile& f = *p->mFiles[i];
         try {
           if (p->mSkipped[i]) {
@@ -487,7 +596,17 @@ extern "C" void afec_crawl_release(void) {
 
 extern "C" void afec_crawl_set_bytes_per_batch(int64_t bytes) { gBytesPerBatch = bytes; }
 
-namespace { std::mutex gPragmaMutex; std::string gDatabasePragmas; std::atomic<bool> gResample(true); }
+namespace {
+std::mutex gPragmaMutex;
+std::string gDatabasePragmas;
+std::atomic<bool> gResample(true);
+std::atomic<int> gTestFailBatch(-1), gTestFailAttempts(0), gTestDeviceLost(0);
+std::atomic<int64_t> gDeviceBytesPerBatch(0);
+}  // namespace
+extern "C" void afec_crawl_set_test_fault(int32_t batch, int32_t attempts, int32_t device_lost) {
+  gTestFailBatch = batch; gTestFailAttempts = attempts; gTestDeviceLost = device_lost;
+}
+extern "C" void afec_crawl_set_device_bytes_per_batch(int64_t bytes) { gDeviceBytesPerBatch = bytes; }
 extern "C" void afec_crawl_set_resample(int32_t resample) { gResample = resample != 0; }
 extern "C" void afec_crawl_set_database_pragmas(const char* pragmas) {
   std::lock_guard<std::mutex> Lock(gPragmaMutex);
@@ -513,6 +632,8 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     if (database_path) Options.mDatabasePath = database_path;
     if (gBytesPerBatch > 0) Options.mBytesPerBatch = gBytesPerBatch;
     Options.mResample = gResample;
+    Options.mTestFailBatch = gTestFailBatch; Options.mTestFailAttempts = gTestFailAttempts; Options.mTestDeviceLost = gTestDeviceLost != 0;
+    if (gDeviceBytesPerBatch > 0) Options.mDeviceBytesPerBatch = gDeviceBytesPerBatch;
     {
       std::lock_guard<std::mutex> Lock(gPragmaMutex);
       Options.mDatabasePragmas = gDatabasePragmas;
@@ -540,6 +661,8 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
       for (int32_t d = 0; d < n_devices; ++d) stats[8 + d] = (double)s.mFilesPerDevice[(size_t)d];
       stats[8 + n_devices] = s.mCpuSeconds;
       stats[9 + n_devices] = (double)s.mSkippedSampleRateFiles;
+      stats[10 + n_devices] = (double)s.mRetriedBatches;
+      stats[11 + n_devices] = (double)s.mDeviceFailedFiles;
     }
     return 0;
   } catch (const std::exception& e) {

@@ -57,6 +57,15 @@ struct TCrawlOptions {
   // with a database: the workers build the rows' column values (msgpack BLOBs: ~12 % of the single writer's time per
   // row), the writer only binds and steps; false: the writer does both
   bool mPrepareRowsInWorkers = true;
+  // a batch is also cut (before it is tried) when the device memory its files need -- their samples *after* the
+  // sample-rate conversion, spectra, records -- exceeds this: a header that claims 1 kHz makes a small file a large one
+  int64_t mDeviceBytesPerBatch = (int64_t)2 << 30;
+  // Fault injection for the tests of the failure path (a batch whose GPU round trip fails is retried in halves, a single
+  // file twice, then recorded as failed; the crawl goes on): the first mTestFailAttempts GPU attempts on files of the
+  // mTestFailBatch-th batch of the crawl throw (-1: every attempt); mTestDeviceLost: and the device counts as lost
+  // (the crawl must end with the error).
+  int mTestFailBatch = -1, mTestFailAttempts = 0;
+  bool mTestDeviceLost = false;
 };
 
 struct TCrawlStatistics {
@@ -70,13 +79,19 @@ struct TCrawlStatistics {
   double mWriterSeconds = 0;        // time the writer spent inserting (0 without a database)
   std::vector<int64_t> mFilesPerDevice;
   double mCpuSeconds = 0;           // CPU time the process spent during the crawl (all threads): mCpuSeconds / mSeconds = busy CPUs
+  // GPU_MAX_HW_QUEUES as the environment had it when the crawler was built (0: unset).  The HIP runtime reads it at its
+  // first call: when the process had used HIP before, a value set here came too late (175-205 k instead of 268 k files/s)
+  int mHardwareQueuesInEnvironment = 0;
+  int64_t mRetriedBatches = 0;      // GPU round trips that failed on a live device and were retried (in halves / once more)
+  int64_t mDeviceFailedFiles = 0;   // files recorded as "Sample failed to analyse: ..." after their own two attempts failed
 };
 
 // file i -> device index i mod G
 inline int ShardOfFile(int64_t FileIndex, int NumberOfDevices) { return (int)(FileIndex % NumberOfDevices); }
 
-// analyse every file; throws TReadableException when a device or the database cannot be set up (single files
-// that cannot be read or analysed are counted / inserted as failed samples, SampleAnalyser.cpp:397-408)
+// analyse every file; throws TReadableException when a device or the database cannot be set up or a device stops
+// answering (single files that cannot be read or analysed -- also after a failed GPU round trip, retried in halves --
+// are counted / inserted as failed samples, SampleAnalyser.cpp:368-408)
 TCrawlStatistics CrawlWaveFiles(const std::vector<TCrawlFile>& Files, const TCrawlOptions& Options);
 
 // The same with the set-up kept between crawls: the analysers (one plan per device and its pooled device workspaces)
@@ -102,7 +117,7 @@ extern "C" {
 // NULL -- files on disk, names[i] being their paths.  The process keeps
 // one TCrawler per (devices, geometry) between calls (afec_crawl_release drops them), so a second crawl starts warm.
 // stats: [files, failed, frames, pcm_bytes, result_bytes, seconds, writer_seconds, batches, files on device 0, 1, ...,
-// cpu_seconds, files skipped for their sampling rate] (8 + n_devices + 2 doubles);
+// cpu_seconds, files skipped for their sampling rate, retried batches, files failed on the device] (8 + n_devices + 4 doubles);
 // returns 0, or -1 with the message in error.
 int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
                            const int32_t* devices, int32_t n_devices, int32_t workers_per_device, int32_t files_per_batch,
@@ -123,4 +138,8 @@ void afec_crawl_set_bytes_per_batch(int64_t bytes);
 void afec_crawl_set_database_pragmas(const char* pragmas);
 // TCrawlOptions::mResample of the crawls that follow (0: files at another rate than the analyser's are skipped and counted)
 void afec_crawl_set_resample(int32_t resample);
+// TCrawlOptions::mTestFailBatch / mTestFailAttempts / mTestDeviceLost of the crawls that follow (-1, 0, 0: no fault)
+void afec_crawl_set_test_fault(int32_t batch, int32_t attempts, int32_t device_lost);
+// TCrawlOptions::mDeviceBytesPerBatch of the crawls that follow (0: the default)
+void afec_crawl_set_device_bytes_per_batch(int64_t bytes);
 }

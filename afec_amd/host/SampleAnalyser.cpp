@@ -225,7 +225,7 @@ std::vector<TSampleDescriptors> Collect(TBatchGuard& Batch, int32_t n, std::vect
   for (int32_t i = 0; i < n; ++i) {
     const int32_t Bad = (BufStatus[i] != AFX_OK) ? BufStatus[i] : StatsStatus[i];
     if (Bad != AFX_OK) {
-      if (pFailed) (*pFailed)[i] = std::string("error: ") + afx_status_str(Bad);
+      if (pFailed) (*pFailed)[i] = std::string("Sample failed to load: ") + afx_status_str(Bad);
       continue;
     }
     const int64_t f0 = Offset[i], nf = Offset[i + 1] - Offset[i];
@@ -310,9 +310,11 @@ int64_t TSampleAnalyser::ConvertedSampleFrames(const TDecodedSample& File, int R
   return (int64_t)((double)File.mNumberOfSampleFrames / ((double)File.mSampleRate / (double)Rate) + 0.5) + 1;
 }
 
-size_t TSampleAnalyser::RhythmDoubles(const std::vector<TDecodedSample>& Files) {
+bool TSampleAnalyser::DeviceUsable() const { return afx_plan_probe_device(mpPlan) == AFX_OK; }
+
+size_t TSampleAnalyser::RhythmDoubles(const std::vector<TDecodedSample>& Files) const {
   size_t Rows = 0;
-  for (const TDecodedSample& f : Files) Rows += (size_t)(ConvertedSampleFrames(f, 44100) / 128) + 17;
+  for (const TDecodedSample& f : Files) Rows += (size_t)(ConvertedSampleFrames(f, mSampleRate) / 128) + 17;
   return Rows * 2 + Files.size() * (AFX_NUM_RHYTHM_SCALARS + 2 * AFX_NUM_STATISTICS);
 }
 

@@ -143,7 +143,10 @@ public:
   // RhythmCapacity doubles (RhythmDoubles() of the files is always enough).  Returns false (and leaves Batch empty)
   // when the records do not fit RecordCapacity or the rhythm results RhythmCapacity: call again with larger buffers.
   enum { kMaxStride = 134 };
-  static size_t RhythmDoubles(const std::vector<TDecodedSample>& Files);
+  size_t RhythmDoubles(const std::vector<TDecodedSample>& Files) const;
+  // does the analyser's device still answer (afx_plan_probe_device)?  false after a fault that took the context down:
+  // nothing more can be analysed, as opposed to a batch that failed for its own reasons (memory, a bad file)
+  bool DeviceUsable() const;
   static int64_t ConvertedSampleFrames(const TDecodedSample& File, int Rate);   // sample frames once the file is at Rate
   bool AnalyzeToRecords(const std::vector<TDecodedSample>& Files, double* pRecords, size_t RecordCapacity,
                         double* pStatistics, double* pRhythm, size_t RhythmCapacity, TRecordBatch& Batch) const;

@@ -183,7 +183,18 @@ void TSqliteSampleDescriptorPool::InsertColumns(const std::string& FileName, int
     Sql += ")";
     I.Check(I.mApi.prepare_v2(I.mpDatabase, Sql.c_str(), -1, &I.mpInsert, nullptr), "prepare");
   }
-  if (I.mBoundColumnCount != Values.size()) {
+  // the binding table (schema column -> index into Values) is resolved once and reused while Values keeps its shape:
+  // the same number of columns and, checked cheaply on every row, the same names where the table points
+  bool Resolved = I.mBoundColumnCount == Values.size();
+  if (Resolved) {
+    // (every 37th binding and the last one: a reordered or renamed set of the same size does not get past that)
+    const size_t n = I.mBindings.size();
+    for (size_t k = 0; k < n; k = (k + 37 < n || k + 1 == n) ? k + 37 : n - 1) {
+      const TImpl::TBinding& b = I.mBindings[k];
+      if (b.mSource == TImpl::kValue && Values[(size_t)b.mValueIndex].mName != I.mSchema[k].mName) { Resolved = false; break; }
+    }
+  }
+  if (!Resolved) {
     std::unordered_map<std::string, int> ByName;
     for (size_t i = 0; i < Values.size(); ++i) ByName[Values[i].mName] = (int)i;
     I.mBindings.clear();

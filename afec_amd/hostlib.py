@@ -71,7 +71,7 @@ def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, data
     else:
         c_images = c_sizes = None
     c_dev = (ctypes.c_int32 * len(devices))(*devices)
-    stats = (ctypes.c_double * (10 + len(devices)))()
+    stats = (ctypes.c_double * (12 + len(devices)))()
     err = ctypes.create_string_buffer(512)
     rc = L.afec_crawl_wave_images(c_names, c_images, c_sizes, n, c_dev, len(devices), workers, files_per_batch,
                                   database.encode() if database else None, stats, err, 512)
@@ -82,6 +82,8 @@ def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, data
     out["files_per_device"] = [int(v) for v in list(stats)[8:8 + len(devices)]]
     out["cpu_seconds"] = stats[8 + len(devices)]   # process CPU time during the crawl: / seconds = busy CPUs
     out["skipped_sample_rate"] = int(stats[9 + len(devices)])   # files at another rate than the analyser's (not resampled here)
+    out["retried_batches"] = int(stats[10 + len(devices)])      # GPU round trips that failed on a live device and were retried
+    out["device_failed_files"] = int(stats[11 + len(devices)])  # files recorded as failed after their own attempts failed
     return out
 
 
@@ -114,3 +116,20 @@ def set_resample(on):
     L.afec_crawl_set_resample.restype = None
     L.afec_crawl_set_resample.argtypes = [ctypes.c_int32]
     L.afec_crawl_set_resample(1 if on else 0)
+
+
+def set_test_fault(batch=-1, attempts=0, device_lost=False):
+    """Fault injection (TCrawlOptions::mTestFailBatch / mTestFailAttempts / mTestDeviceLost) of the crawls that follow: the
+    first `attempts` GPU attempts on files of the batch-th batch throw (-1: every attempt); defaults: no fault."""
+    L = lib()
+    L.afec_crawl_set_test_fault.restype = None
+    L.afec_crawl_set_test_fault.argtypes = [ctypes.c_int32, ctypes.c_int32, ctypes.c_int32]
+    L.afec_crawl_set_test_fault(int(batch), int(attempts), 1 if device_lost else 0)
+
+
+def set_device_bytes_per_batch(n_bytes):
+    """TCrawlOptions::mDeviceBytesPerBatch of the crawls that follow (0: the default, 2 GiB)."""
+    L = lib()
+    L.afec_crawl_set_device_bytes_per_batch.restype = None
+    L.afec_crawl_set_device_bytes_per_batch.argtypes = [ctypes.c_int64]
+    L.afec_crawl_set_device_bytes_per_batch(int(n_bytes))

@@ -62,6 +62,12 @@ def parse_args():
     ap.add_argument("--workers", type=int, default=8, help="host threads (batches in flight) per GPU of --end-to-end")
     ap.add_argument("--files-per-batch", type=int, default=512, help="files per GPU batch of --end-to-end")
     ap.add_argument("--cpu-frames", type=int, default=30000, help="frames per CPU worker for the baseline")
+    ap.add_argument("--frame-kernel", choices=["auto", "wave64", "halfwave"], default="auto",
+                    help="afx_plan_desc.frame_kernel: layout of the STFT kernel (A/B timing; auto = by batch size)")
+    ap.add_argument("--no-side-stream", action="store_true",
+                    help="AFX_PLAN_NO_SIDE_STREAM: the rhythm tracker's kernels on the batch's own stream (profiles: a "
+                         "kernel's duration is then its own)")
+    ap.add_argument("--no-spot-check", action="store_true", help="skip the parity spot check of the timed batch")
     return ap.parse_args()
 
 
@@ -281,6 +287,25 @@ def kernel_profile(precision, mask_name, workload):
     return prof
 
 
+def parity_spot_check(batch, spot_bufs, frames_per_buffer, n_frames=64):
+    """MFCC of the first n_frames frames of the given buffers, as the timed launches left them, against the oracle."""
+    from tests import _tol
+    from tests._oracle import Oracle
+    oracle = Oracle()
+    got = batch.fetch()["mfcc"]
+    worst = 0.0
+    rtol, atol = _tol.GPU_TOL["mfcc"]
+    ok = True
+    for i, x in spot_bufs.items():
+        ref = oracle.run_mfcc(x[:2048 + 1024 * (n_frames - 1)].astype(np.float64))
+        mine = got[i * frames_per_buffer:i * frames_per_buffer + n_frames]
+        err = np.abs(mine - ref) / np.maximum(np.abs(ref), 1e-9)
+        worst = max(worst, float(err.max()))
+        ok = ok and bool(np.all(np.abs(mine - ref) <= atol + rtol * np.abs(ref)))
+    return {"frames": n_frames * len(spot_bufs), "buffers": sorted(spot_bufs), "descriptor": "mfcc", "max_rel_err": worst,
+            "rtol": rtol, "atol": atol, "passed": ok, "against": "oracle/afx_oracle.c (pinned on the reference's objects)"}
+
+
 def secondary_rate(plan, mask, buffers, steps=5):
     """frames/s of another descriptor set on the same synthetic PCM (reported beside the headline)."""
     b = plan.batch(make_buffers(buffers, 777), mask)
@@ -339,7 +364,11 @@ def main():
     precision = afx.PRECISION_F64
     # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)
     device = int(os.environ.get("AFX_BENCH_DEVICE", local))
-    plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0)
+    plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0,
+                    frame_kernel={"auto": afx.FRAME_KERNEL_AUTO, "wave64": afx.FRAME_KERNEL_WAVE64,
+                                  "halfwave": afx.FRAME_KERNEL_HALFWAVE}[args.frame_kernel],
+                    flags=afx.PLAN_NO_SIDE_STREAM if args.no_side_stream else 0)
+    spot_bufs = None
     if args.workload in ("c3", "c4"):
         mask = (afx.D_ALL_PER_FRAME if args.mask in ("frame", "neighbours", "everything") else afx.D_ALL_LOW_LEVEL) | afx.D_STATISTICS
         if args.mask == "everything":
@@ -348,13 +377,16 @@ def main():
         bufs = make_c3_files(1000, 1234 + rank) if args.workload == "c3" else make_c4_files(args.files, 1234 + rank)
         n_bufs = len(bufs)
         batch, _ = plan.batch_from_raw([(b, channels) for b in bufs], mask)
-        pcm_kind = afx.PCM_F64
+        pcm_kind = afx.PCM_F32   # the LoadSample front end keeps the float mono signal + one scale per file
     else:
         bufs = make_buffers(args.buffers, 1234 + rank)
         n_bufs = len(bufs)
         batch = plan.batch(bufs, mask)
         pcm_kind = afx.PCM_F32
+        # the buffers the parity spot check looks at after the timed region: first, middle, last of the batch
+        spot_bufs = {i: bufs[i] for i in sorted({0, n_bufs // 2, n_bufs - 1})}
     del bufs
+    batch_info = batch.info()
     frames = batch.total_frames
     bytes_per_frame = plan.bytes_per_frame(mask & ~afx.D_STATISTICS, pcm_kind)
 
@@ -369,6 +401,15 @@ def main():
     if dist is not None:
         dist.barrier()
     seconds, frames_all = reduce_max_sum(dist, t1 - t0, frames)
+
+    # What the timed launches left in HBM is checked, not only timed: the MFCC of 64 frames of three buffers of this
+    # very batch against the oracle (the checker, after the timed region; tests/_tol.py's bar for the descriptor)
+    spot = None
+    if rank == 0 and spot_bufs and (mask & afx.D_MFCC) and not args.no_spot_check:
+        try:
+            spot = parity_spot_check(batch, spot_bufs, FRAMES_PER_BUFFER)
+        except Exception as e:  # noqa: BLE001
+            spot = {"error": str(e)}
 
     # the literal BASELINE configs[1] shape as a secondary number: ONE resident buffer of 10 000 frames
     single = None
@@ -475,11 +516,16 @@ def main():
                              if args.mask == "c2" else f"{args.mask} descriptor set, {args.buffers} x {FRAMES_PER_BUFFER} frames"),
                 "frames_per_gpu_per_step": frames,
                 "files_per_gpu_per_step": n_bufs,
+                "parity_spot_check": spot,
+                "frame_kernel": {1: "wave64", 2: "halfwave"}.get(batch_info["frame_kernel"]),
+                "frame_kernel_class": batch_info["feature_class"],
+                "chunk_frames": batch_info["chunk_frames"],
                 "single_10k_frame_buffer_frames_per_s": single,
                 "star_descriptor_set_frames_per_s": star_rate,
                 "all_spectral_descriptors_frames_per_s": all_rate,
                 "end_to_end_host_driver": e2e,
-                "pcm": "f32 resident in HBM" if pcm_kind == afx.PCM_F32 else "f64 (LoadSample output) resident in HBM",
+                "pcm": "f32 resident in HBM" if args.workload == "c2" else
+                       "f32 mono signal + one double scale per file (LoadSample output, SampleAnalyser.cpp:710-718) resident in HBM",
                 "parallelism": f"replicas x{world} (buffers sharded, no collective)",
             },
             # achieved / peak / frac / traffic: the HBM roofline the path is priced against (a streaming scan of PCM,

@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define AFX_VERSION 3
+#define AFX_VERSION 5
 
 /* ---- status codes (replace TReadableException on this path, SampleAnalyser.cpp:397-408) ---- */
 enum {
@@ -113,14 +113,23 @@ typedef struct {
   int32_t precision;       /* AFX_PRECISION_*                                                 */
   int32_t max_analysis_ms; /* MAnalyzationDurationMaxInMs = 20000 (SampleAnalyser.cpp:37);
                               0 disables the cap (synthetic benchmarks)                       */
+  int32_t frame_kernel;    /* AFX_FRAME_KERNEL_*: layout of the STFT kernel for the batches the half-wave layout serves
+                              (float PCM; AFX_D_MFCC alone or with any of bits 1..7); results agree to rounding   */
+  int32_t flags;           /* AFX_PLAN_* bits                                                  */
 } afx_plan_desc;
+enum {
+  AFX_FRAME_KERNEL_AUTO = 0,     /* by batch size (what a zeroed field means)                                   */
+  AFX_FRAME_KERNEL_WAVE64 = 1,   /* one frame per 64-lane wave for every batch (A/B timing, tests)             */
+  AFX_FRAME_KERNEL_HALFWAVE = 2  /* one frame per 32-lane half for every batch the layout serves (tests)       */
+};
+enum {
+  AFX_PLAN_NO_SIDE_STREAM = 1u << 0 /* the rhythm tracker's kernels run on the batch's own stream instead of beside the
+                                       per-frame kernels (profiles: a kernel's duration is then its own; results are
+                                       identical)                                                               */
+};
 
-/* Environment read by afx_plan_create:
- * AFX_HALFWAVE = 0 | 1 | 2 selects the frame kernel of the masks the half-wave layout serves (float PCM; AFX_D_MFCC alone
- * or with any of AFX_D_SPECTRAL_RMS .. AFX_D_SPECTRAL_FLATNESS, bits 1..7): 0 = 64-lane kernel, 1 = by batch size
- * (default), 2 = half-wave kernel for every batch; results agree to rounding.
- * AFX_SIDE_STREAM = 0: the rhythm tracker's kernels run on the batch's own stream instead of beside the per-frame kernels
- * (for profiles: per-kernel durations are then not inflated by overlap; results are identical).
+/* Nothing in the environment changes what afx_plan_create builds or what a batch computes (ABI 4 read AFX_HALFWAVE and
+ * AFX_SIDE_STREAM; they are afx_plan_desc.frame_kernel / flags now).
  * AFX_TIMING (any value, read when the library is loaded): wall time of the phases of afx_batch_create_from_raw, summed
  * over calls, printed to stderr when the process ends -- a diagnostic for pipelines, no effect on results.
  * The library does not touch the process' environment.  A pipeline that keeps several batches in flight per device
@@ -251,6 +260,20 @@ int afx_batch_fetch(afx_batch* batch, afx_out* out);    /* D2H + unpack, synchro
 int afx_batch_fetch_statistics(afx_batch* batch, afx_stats_out* out); /* needs AFX_D_STATISTICS in the mask */
 void afx_batch_destroy(afx_batch* batch);
 
+/* What a batch will launch (decided when it is created): for tests and profiles that must know which kernel a result or
+ * a duration belongs to. */
+typedef struct {
+  int32_t frame_kernel;  /* AFX_FRAME_KERNEL_WAVE64 or AFX_FRAME_KERNEL_HALFWAVE */
+  int32_t feature_class; /* of the STFT kernel: 0 = MFCC only, 1 = + spectral statistics, 2 = + spectrum bands /
+                            amplitude / stored magnitudes ("full")                                            */
+  int32_t pcm_kind;      /* 0 = float, 1 = double, 2 = float + one double scale per buffer (LoadSample front end) */
+  int32_t chunk_frames;  /* frames per chunk (the unit of work of a wave / half-wave)                          */
+  int32_t n_chunks;
+  int32_t grid_blocks;   /* workgroups of the STFT kernel                                                     */
+  int64_t arena_bytes;   /* PCM kept in HBM for this batch                                                    */
+} afx_batch_info;
+int afx_batch_get_info(const afx_batch* batch, afx_batch_info* info);
+
 /* Raw results for pipelines that keep many batches in flight: the per-frame records exactly as the kernels leave
  * them, double[total_frames][stride], and the statistics double[n_bufs][stride][AFX_NUM_STATISTICS], each moved by
  * ONE device-to-host transfer into caller memory (page-locked memory from afx_host_alloc makes it a direct DMA; no
@@ -271,12 +294,16 @@ int afx_batch_fetch_records(afx_batch* batch, double* records, double* statistic
  * Decoded, interleaved PCM of a file in; on the GPU: conversion to the reference's "16-bit float"
  * range, mono mix-down, peak / rms, peak normalisation, -48 dB leading / trailing silence trim, and the
  * half-frame / one-frame zero padding.  The result is the double buffer TSampleData::mData holds and
- * stays in HBM as the batch's PCM arena.  Files that are not at the plan's rate (afx_raw.sample_rate) are converted
+ * is kept in HBM as the float mono signal LoadSample itself works on plus the file's FinalScaling: mData[n] is their
+ * product (SampleAnalyser.cpp:710-718) and every kernel forms it as it loads a sample (bit-identical, half the bytes);
+ * afx_batch_fetch_samples returns the doubles.  Files that are not at the plan's rate (afx_raw.sample_rate) are converted
  * first, on the GPU, exactly as the reference does it on the CPU (SampleAnalyser.cpp:563-607: libresample 0.1.3,
  * resample_open(1, f, f) + one resample_process call, f = plan rate / file rate, on the mono mix; afx_resample.hip);
  * afx_load_info and the rhythm tracker's duration heuristics then see the file's own rate and length
  * (TSampleData::mOriginalSampleRate / mOriginalNumberOfSamples).  A file above 16 x the plan's rate gets
- * AFX_ERR_UNSUPPORTED in its buf_status.  Decoding the container stays with the caller. */
+ * AFX_ERR_UNSUPPORTED in its buf_status, and so does a file whose conversion would blow it up beyond reason (a rate
+ * below the plan's / 64, or more than 2^28 converted samples: a header claiming 1 Hz must fail that file, not exhaust the
+ * device for the batch).  Decoding the container stays with the caller. */
 enum {
   AFX_RAW_I16 = 0, /* int16                      (S16BitSignedTo16BitFloat, SampleConverter.h:446-449) */
   AFX_RAW_I24 = 1, /* packed little-endian int24 (S24BitTo16BitFloat, SampleConverter.h:474-486)       */
@@ -357,6 +384,12 @@ void afx_host_free(void* p);
  * 270 k files/s with about 3 instead of 7 busy CPUs (TCrawlOptions::mSleepingWaits).  Per plan; applies to the batches
  * created after the call.  (ABI 3 had a process-wide afx_set_blocking_wait instead.) */
 int afx_plan_set_blocking_wait(afx_plan* plan, int32_t blocking);
+
+/* Does the plan's device still answer?  AFX_OK, or AFX_ERR_HIP when the runtime reports an error for a trivial request
+ * on this device (after a fault that took the context down every call fails).  A caller whose batch failed uses this to
+ * tell "this batch cannot be analysed" (retry smaller, record the file as failed, go on: SampleAnalyser.cpp:368-408)
+ * from "nothing more can be analysed".  Cheap, no device-wide synchronisation. */
+int afx_plan_probe_device(afx_plan* plan);
 
 /* static facts for roofline accounting (bytes the algorithm must move per frame for `mask`) */
 int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int32_t pcm_dtype);

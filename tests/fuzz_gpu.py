@@ -58,7 +58,9 @@ def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     rng = np.random.default_rng(seed)
-    plan, oracle = afx.Plan(max_analysis_ms=0), Oracle()
+    # AFX_FUZZ_KERNEL = wave64 | halfwave forces the STFT kernel's layout (afx_plan_desc.frame_kernel); default: by batch size
+    kernel = {"wave64": afx.FRAME_KERNEL_WAVE64, "halfwave": afx.FRAME_KERNEL_HALFWAVE}.get(os.environ.get("AFX_FUZZ_KERNEL", ""), afx.FRAME_KERNEL_AUTO)
+    plan, oracle = afx.Plan(max_analysis_ms=0, frame_kernel=kernel), Oracle()
     t0 = time.time()
     rounds = frames = bad = skipped = rhythm_frames = rhythm_gate_flips = 0
     while time.time() - t0 < seconds:
@@ -73,7 +75,7 @@ def main():
         if mask == 0:
             mask = afx.D_ALL_PER_FRAME
         if os.environ.get("AFX_FUZZ_STATS"):
-            # the statistics class of the half-wave kernel (run with AFX_HALFWAVE=2): MFCC + a random subset of
+            # the statistics class of the half-wave kernel (run with AFX_FUZZ_KERNEL=halfwave): MFCC + a random subset of
             # spectral rms / centroid / spread / skewness / kurtosis / rolloff / flatness, float32 PCM
             mask = afx.D_MFCC | (int(rng.integers(0, 128)) << 1)
             bufs = [b.astype(np.float32) for b in bufs]

@@ -74,7 +74,7 @@ def test_crawl_into_the_descriptor_database(tmp_path):
     assert con.execute("PRAGMA user_version").fetchone()[0] == 2
     rows = {r["filename"]: r for r in con.execute("SELECT * FROM assets")}
     assert len(rows) == len(images)
-    assert rows["Broken/_Not A Wavefile.wav"]["status"] == "error: Not a valid WAV file."
+    assert rows["Broken/_Not A Wavefile.wav"]["status"] == "error: Sample failed to load: Not a valid WAV file."   # SampleAnalyser.cpp:372-387
     assert sum(1 for r in rows.values() if r["status"] != "succeeded") == 1          # cf. UnitTests.cpp:338-350
     z = np.load(GOLD)
     ora = Oracle()
@@ -201,7 +201,7 @@ def rows_by_hash(db):
     return out
 
 
-@pytest.mark.parametrize("shards", [2, 4])
+@pytest.mark.parametrize("shards", [2, 4, 8])
 def test_several_shards_on_one_device(tmp_path, shards):
     """The G > 1 branch of the crawler (file i -> shard i mod G, one analyser, worker set and cursor per shard,
     Crawler.cpp:706-728) with every shard on device 0: the database rows are those of the one-shard crawl, the files
@@ -336,3 +336,80 @@ def test_conversion_can_be_switched_off():
         hostlib.set_resample(True)
     assert on["skipped_sample_rate"] == 0 and off["skipped_sample_rate"] == 3
     assert off["files"] == on["files"] and off["failed"] == on["failed"] == 1 and off["frames"] < on["frames"]
+
+
+def statuses(db):
+    con = sqlite3.connect(db)
+    out = {r[0]: r[1] for r in con.execute("SELECT filename, status FROM assets")}
+    con.close()
+    return out
+
+
+def test_a_failed_gpu_round_trip_is_retried_in_halves_and_the_crawl_goes_on(tmp_path):
+    """SampleAnalyser.cpp:368-408: a file that cannot be analysed gets a failed row and the crawl continues.  For errors
+    of the device path (out of memory, a failed runtime call) the unit that fails is a batch: it is retried in halves
+    (TCrawlOptions::mTestFailBatch injects the fault).  One failure: every file still gets its row, identical to the
+    clean crawl's.  A batch that fails whatever its size: its files become "Sample failed to analyse" rows, every other
+    row is the clean crawl's, the crawl ends normally."""
+    from afec_amd import hostlib
+    images, names, _ = make_crawl(90)        # 90 + 5 + 1 + 3 files, batches of 16: batch 3 = files 48..63
+    dbs = [str(tmp_path / f"{k}.db") for k in ("clean", "once", "always")]
+    clean = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=16, database=dbs[0])
+    assert clean["retried_batches"] == 0 and clean["device_failed_files"] == 0
+    try:
+        hostlib.set_test_fault(batch=3, attempts=1)
+        once = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=16, database=dbs[1])
+        hostlib.set_test_fault(batch=3, attempts=-1)
+        always = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=16, database=dbs[2])
+    finally:
+        hostlib.set_test_fault()
+    a, b, c = (rows_by_hash(d) for d in dbs)
+    assert len(a) == len(images) and a == b
+    assert once["retried_batches"] == 1 and once["device_failed_files"] == 0 and once["failed"] == clean["failed"]
+    assert once["frames"] == clean["frames"] and once["batches"] == clean["batches"] + 1        # two halves instead of one batch
+    hit = set(names[48:64])
+    assert len(c) == len(images) and {n: h for n, h in c.items() if n not in hit} == {n: h for n, h in a.items() if n not in hit}
+    st = statuses(dbs[2])
+    assert all(st[n].startswith("error: Sample failed to analyse: ") and "injected fault" in st[n] for n in hit)
+    assert always["device_failed_files"] == 16 and always["failed"] == clean["failed"] + 16
+    # 1 whole + 2 + 4 + 8 halves + 16 single files tried twice = 47 failed round trips
+    assert always["retried_batches"] == 47
+
+
+def test_a_lost_device_ends_the_crawl():
+    """...whereas a device that no longer answers (TCrawlOptions::mTestDeviceLost stands in for the probe's verdict) is
+    not something a smaller batch cures: the crawl ends with the error."""
+    from afec_amd import hostlib
+    images, names, _ = make_crawl(40)
+    try:
+        hostlib.set_test_fault(batch=1, attempts=1, device_lost=True)
+        with pytest.raises(RuntimeError, match="injected fault"):
+            _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=8)
+    finally:
+        hostlib.set_test_fault()
+    again = _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=8)     # the crawler itself is fine
+    assert again["files"] == len(images) and again["failed"] == 1
+
+
+def test_a_file_whose_header_would_blow_it_up_fails_alone(tmp_path):
+    """A small file whose header claims 1 Hz would be 2^31 samples once converted to 44.1 kHz: it is refused by itself
+    (AFX_ERR_UNSUPPORTED -> a failed row), its batch is analysed; a file at 1 kHz (x 44.1) is converted, and the batch
+    it is in is cut by the device budget (TCrawlOptions::mDeviceBytesPerBatch) instead of growing the workspace."""
+    from afec_amd import hostlib
+    images, names, _ = make_crawl(20)
+    rng = np.random.default_rng(4)
+    tiny = np.round(rng.uniform(-0.5, 0.5, 48000) * 32767).astype(np.int16)
+    images += [wav_bytes(tiny, 1, 16, rate=1), wav_bytes(tiny[:4000], 1, 16, rate=1000), wav_bytes(tiny[:4000], 1, 16, rate=500)]
+    names += ["Odd/one_hertz.wav", "Odd/one_kilohertz.wav", "Odd/five_hundred_hertz.wav"]
+    db = str(tmp_path / "odd.db")
+    st = _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=64, database=db)
+    s = statuses(db)
+    assert s["Odd/one_hertz.wav"].startswith("error: Sample failed to load: ") and s["Odd/five_hundred_hertz.wav"].startswith("error: Sample failed to load: ")
+    assert s["Odd/one_kilohertz.wav"] == "succeeded"
+    assert st["files"] == len(images) and st["failed"] == 3 and st["retried_batches"] == 0
+    try:
+        hostlib.set_device_bytes_per_batch(4 << 20)          # the 1 kHz file alone is 176 400 converted samples = 2.8 MB
+        cut = _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=64)
+    finally:
+        hostlib.set_device_bytes_per_batch(0)
+    assert cut["batches"] > st["batches"] and cut["frames"] == st["frames"] and cut["failed"] == 3

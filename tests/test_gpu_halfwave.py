@@ -1,6 +1,6 @@
 """GPU parity of the half-wave STFT + MFCC kernel (afec_amd/csrc/afx_frames32.hip): the MFCC-only class with
-f32 PCM, forced on for every batch size with AFX_HALFWAVE=2, against the reference goldens, the oracle and the
-64-lane kernel (AFX_HALFWAVE=0).  Covers what the work queue and the two-chunks-per-wave walk can get wrong:
+f32 PCM, forced on for every batch size with afx_plan_desc.frame_kernel = AFX_FRAME_KERNEL_HALFWAVE, against the
+reference goldens, the oracle and the 64-lane kernel (AFX_FRAME_KERNEL_WAVE64).  Covers what the work queue and the two-chunks-per-wave walk can get wrong:
 odd chunk counts, chunks of different lengths in the two halves of a wave, one-frame buffers, repeated launches
 on one batch (the queue counter is never reset) and workspace reuse between batches."""
 import os
@@ -18,15 +18,9 @@ GOLD = os.path.join(os.path.dirname(__file__), "golden")
 
 
 def make_plan(mode):
-    old = os.environ.get("AFX_HALFWAVE")
-    os.environ["AFX_HALFWAVE"] = str(mode)
-    try:
-        return afx.Plan(max_analysis_ms=0)
-    finally:
-        if old is None:
-            del os.environ["AFX_HALFWAVE"]
-        else:
-            os.environ["AFX_HALFWAVE"] = old
+    """mode 0: the 64-lane kernel for every batch, 1: by batch size (the default), 2: the half-wave kernel for every batch"""
+    return afx.Plan(max_analysis_ms=0, frame_kernel={0: afx.FRAME_KERNEL_WAVE64, 1: afx.FRAME_KERNEL_AUTO,
+                                                      2: afx.FRAME_KERNEL_HALFWAVE}[mode])
 
 
 @pytest.fixture(scope="module")

@@ -183,3 +183,37 @@ def test_upload_reads_only_the_callers_bytes():
         plan.close()
         del view, tail
         libc.mprotect(base + 3 * page, page, 3)
+
+
+def test_the_arena_behind_loadsample_holds_floats_and_one_scale_per_file():
+    """LoadSample's output is (double)float_sample * FinalScaling (SampleAnalyser.cpp:710-718): the batch keeps the
+    float signal and the scale (afx_batch_info.pcm_kind = 2, four bytes a sample), afx_batch_fetch_samples forms the
+    doubles on demand, and a batch made of exactly those doubles (the reference's mData, AFX_PCM_F64) gives the same
+    descriptors -- every kernel forms the same products when it loads a sample."""
+    files = make_files()
+    plan = afx.Plan()
+    mask = afx.D_ALL_PER_FRAME
+    batch, infos = plan.batch_from_raw(files, mask)
+    info = batch.info()
+    assert info["pcm_kind"] == 2
+    wants = [_oracle.load_sample(data, ch)[0] for data, ch in files]
+    kept = []
+    for w in wants:
+        nf = plan.num_frames(w.size)
+        kept.append(min(w.size, (nf - 1) * 1024 + 2048 + 64) if nf > 0 else 0)     # (+ 64: the autocorrelation's second search)
+    assert info["arena_bytes"] == 4 * sum((k + 3) // 4 * 4 for k in kept)
+    batch.run()
+    res = batch.fetch()
+    for i, w in enumerate(wants):
+        np.testing.assert_array_equal(batch.fetch_samples(i, kept[i]), w[:kept[i]], err_msg=f"file {i}")
+    batch.close()
+    again = plan.batch(wants, mask)
+    assert again.info()["pcm_kind"] == afx.PCM_F64 and again.info()["arena_bytes"] == 2 * info["arena_bytes"]
+    again.run()
+    res64 = again.fetch()
+    for field in res:
+        if field in ("frame_offset", "buf_status"):
+            continue
+        np.testing.assert_array_equal(res[field], res64[field], err_msg=field)
+    again.close()
+    plan.close()

@@ -136,7 +136,7 @@ def test_crawl_the_reference_fixtures_into_the_database(tmp_path):
     con.row_factory = sqlite3.Row
     rows = {r["filename"]: r for r in con.execute("SELECT * FROM assets")}
     assert len(rows) == len(images)
-    assert rows["Kicks/_Not A Wavefile.wav"]["status"] == "error: Not a valid WAV file."
+    assert rows["Kicks/_Not A Wavefile.wav"]["status"] == "error: Sample failed to load: Not a valid WAV file."
     assert sum(1 for r in rows.values() if r["status"] != "succeeded") == 1            # UnitTests.cpp:338-350
     ora = Oracle()
     checked = set()

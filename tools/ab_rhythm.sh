@@ -7,7 +7,7 @@ for d in $GRAFT_REPO_ROOT/afec_amd/lib/var/*/; do
   export AFX_LIBRARY=$d/libafx_hip.so
   ok=$(cd $GRAFT_REPO_ROOT && timeout 600 python -m pytest tests/test_gpu_rhythm.py tests/test_real_audio.py -m gpu -q -x --timeout 300 2>&1 | tail -1)
   rm -rf /tmp/prt_$v
-  AFX_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prt_$v -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-single --workload c4 --mask everything > /dev/null 2>&1
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prt_$v -o p -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-single --no-side-stream --workload c4 --mask everything > /dev/null 2>&1
   f=$(find /tmp/prt_$v -name "*kernel_stats.csv" | head -1)
   echo "== $v: $ok"
   python3 - "$f" <<'PY'

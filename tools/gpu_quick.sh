@@ -4,7 +4,7 @@ set -u
 O=gpurun_out/r03; mkdir -p $O
 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_robustness.py tests/test_gpu_halfwave.py -x -q 2>&1 | tail -3
 for hw in 1 0 1; do
-  AFX_HALFWAVE=$hw timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 3 > $O/bench_hw${hw}.json 2>$O/bench_hw${hw}.err
+  timeout 300 python bench.py --frame-kernel $(case $hw in 0) echo wave64;; 2) echo halfwave;; *) echo auto;; esac) --no-cpu-baseline --steps 20 --warmup 3 > $O/bench_hw${hw}.json 2>$O/bench_hw${hw}.err
   python - <<PY
 import json
 try:

@@ -6,7 +6,7 @@ O=gpurun_out/r02
 timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.log
 tail -5 $O/pytest_gpu.log
 for hw in 1 0 1 0; do
-  AFX_HALFWAVE=$hw timeout 300 python bench.py --no-cpu-baseline --steps 20 --warmup 3 > $O/bench_hw${hw}.json 2>$O/bench_hw${hw}.err
+  timeout 300 python bench.py --frame-kernel $(case $hw in 0) echo wave64;; 2) echo halfwave;; *) echo auto;; esac) --no-cpu-baseline --steps 20 --warmup 3 > $O/bench_hw${hw}.json 2>$O/bench_hw${hw}.err
   python - <<PY
 import json
 try:

@@ -23,7 +23,7 @@ out = {"_comment": "Per bench configuration, from rocprofv3 passes on MI355X (to
                    f"profiles/{ROUND}/profile_<tag>.json): HBM bytes per frame = (2*FETCH_SIZE + WRITE_SIZE)*1024/frames (gfx950 "
                    "FETCH_SIZE half-count correction, calibrated for 16-B streaming reads only), VALU pipe cycles per frame = "
                    "4*SQ_ACTIVE_INST_VALU/frames summed over the kernels of one step (rhythm kernels on the batch's own stream: "
-                   "AFX_SIDE_STREAM=0), clock = in-kernel s_memtime/s_memrealtime of the stamps build under this load."}
+                   "bench.py --no-side-stream), clock = in-kernel s_memtime/s_memrealtime of the stamps build under this load."}
 builds = set()
 for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
     builds.add(json.load(open(f)).get("build_info"))

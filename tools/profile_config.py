@@ -20,7 +20,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("AFX_ROUND", "r03")
+ROUND = os.environ.get("AFX_ROUND", "r04")
 # steps of a few ms (C3: 3.7 ms) need more warm-up launches to get past the ~30 ms the clocks take to settle from an
 # idle GPU (profiles/r03/clock_ramp.txt): AFX_PROF_WARMUP / AFX_PROF_STEPS
 STEPS, WARMUP = int(os.environ.get("AFX_PROF_STEPS", "10")), int(os.environ.get("AFX_PROF_WARMUP", "2"))
@@ -31,9 +31,9 @@ def run_pass(tag, name, prof_args, bench_args):
     shutil.rmtree(d, ignore_errors=True)
     cmd = ["rocprofv3"] + prof_args + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3",
                                        os.path.join(ROOT, "bench.py"), "--steps", str(STEPS), "--warmup", str(WARMUP),
-                                       "--no-cpu-baseline", "--no-single"] + bench_args
-    # AFX_SIDE_STREAM=0: the rhythm kernels on the batch's own stream, so that a kernel's duration is its own
-    env = dict(os.environ, TMPDIR="/tmp", AFX_SIDE_STREAM="0")
+                                       "--no-cpu-baseline", "--no-single", "--no-spot-check", "--no-side-stream"] + bench_args
+    # --no-side-stream: the rhythm kernels on the batch's own stream, so that a kernel's duration is its own
+    env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
     return d, (json.loads(line[-1]) if line else None), r

@@ -28,7 +28,9 @@ namespace {
 constexpr int kTimeWaves = 8;
 constexpr int kPadSlots = 1088;                 // 1024 + 64 pads, >= kPlaneSlots
 constexpr int kTimePlaneBytes = kPadSlots * 8;
-constexpr int kLdsT2 = 0, kLdsPost = 16384, kLdsPlanes = 32768;
+// shared tables (t2, post: 16 KiB each; t1: 1 KiB -- from global memory its reads were three exposed cache round trips
+// per transform, the vector-memory path being what the frame's own loads wait on), then one plane per wave
+constexpr int kLdsT2 = 0, kLdsPost = 16384, kLdsT1 = 32768, kLdsPlanes = 32768 + 1024;
 constexpr int kTimeLdsBytes = kLdsPlanes + kTimeWaves * kTimePlaneBytes;
 
 __device__ __forceinline__ int pad_slot(int e) { return e + (e >> 4); }
@@ -60,6 +62,54 @@ __device__ __forceinline__ void scale16(double (&x)[16], double scale) {
     for (int i = 0; i < 16; ++i) x[i] = pcm_double<true>(x[i], scale);
   }
 }
+
+// sixteen consecutive samples held as they were loaded (the conversion to double happens where they are used: loads
+// issued early keep 16 / 32 registers, not 32 / 64)
+template <typename TIn>
+struct Block16;
+template <>
+struct Block16<float> {
+  float4 q[4];
+  __device__ __forceinline__ void load(const float* p) {
+    const float4* s = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = s[j];
+  }
+  __device__ __forceinline__ void get(double (&x)[16]) const {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      x[4 * j] = (double)q[j].x; x[4 * j + 1] = (double)q[j].y; x[4 * j + 2] = (double)q[j].z; x[4 * j + 3] = (double)q[j].w;
+    }
+  }
+};
+template <>
+struct Block16<double> {
+  double2 q[8];
+  __device__ __forceinline__ void load(const double* p) {
+    const double2* s = reinterpret_cast<const double2*>(p);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) q[j] = s[j];
+  }
+  __device__ __forceinline__ void get(double (&x)[16]) const {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x[2 * j] = q[j].x; x[2 * j + 1] = q[j].y;
+    }
+  }
+};
+
+// v of lane + 1 (wave_shl:1: lane i reads lane i + 1); lane 63 gets `last`
+__device__ __forceinline__ float next_lane(float v, float last) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last), __float_as_int(v), 0x130, 0xF, 0xF, false));
+}
+__device__ __forceinline__ double next_lane(double v, double last) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(last), __double2loint(v), 0x130, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(last), __double2hiint(v), 0x130, 0xF, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// lane 0's value, in every lane
+__device__ __forceinline__ float first_lane(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); }
+__device__ __forceinline__ double first_lane(double v) { return read_lane<0>(v); }
 
 using mask64 = unsigned long long;
 __device__ __forceinline__ int wave_min_i(int v) {
@@ -146,7 +196,7 @@ __global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
 // FFT plumbing shared by the correlation kernels
 // ---------------------------------------------------------------------------------------------
 struct TimeCtx {
-  const cx<double>* t1;     // global, + 16 (lane >> 4)
+  const cx<double>* t1;     // LDS, + 16 (lane >> 4)
   const cx<double>* t2;     // LDS, + lane
   const cx<double>* post;   // LDS, + lane: w2048^(lane + 64 r) at [64 r]
   unsigned char* plane;
@@ -159,9 +209,10 @@ __device__ __forceinline__ TimeCtx time_setup(const TimeArgs& a, unsigned char* 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   copy_lds_table(lds_raw + kLdsT2, a.t2, 16384, threadIdx.x, kTimeWaves * 64);
   copy_lds_table(lds_raw + kLdsPost, a.post, 16384, threadIdx.x, kTimeWaves * 64);
+  copy_lds_table(lds_raw + kLdsT1, a.t1, 1024, threadIdx.x, kTimeWaves * 64);
   __syncthreads();
   TimeCtx c;
-  c.t1 = reinterpret_cast<const cx<double>*>(a.t1) + 16 * (lane >> 4);
+  c.t1 = reinterpret_cast<const cx<double>*>(lds_raw + kLdsT1) + 16 * (lane >> 4);
   c.t2 = reinterpret_cast<const cx<double>*>(lds_raw + kLdsT2) + lane;
   c.post = reinterpret_cast<const cx<double>*>(lds_raw + kLdsPost) + lane;
   c.plane = lds_raw + kLdsPlanes + wave * kTimePlaneBytes;
@@ -209,24 +260,36 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
     const Chunk ch = a.chunks[ci];
     const double sc = SCALED ? wave_uniform(ch.scale) : 1.0;
     const int remaining0 = a.remaining[ci];
-    for (int fi = 0; fi < ch.nframes; ++fi) {
+    // Everything the two searches and the correlation may touch -- samples 0 .. 2111 of the frame, as far as
+    // the buffer has them (the arena keeps up to 64 samples past the last frame; zeros behind it) -- is loaded in one
+    // go: a[q] = x[64 q + lane].  "x[p+1] > x[p]" is then one ballot per row -- the row against itself shifted by one
+    // lane (wave_shl:1), lane 63 against lane 0 of the next row -- and the first-index searches are scalar bit scans; no
+    // load depends on a search result.  The rows of frame fi + 1 are asked for as soon as frame fi has staged its
+    // segment: they travel while the two transforms run.
+    constexpr int kRowsHeld = 33;
+    TIn ra[kRowsHeld];
+    auto load_rows = [&](int fi) {
       const TIn* const x = pcm + ch.sample_off + (int64_t)fi * kHop;
-      int remaining = remaining0 - fi * kHop;          // mData.Size() - n, >= 2048 for an emitted frame
-      double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
-
-      // Everything the two searches and the correlation may touch -- samples 0 .. 2111 of the frame, as far as
-      // the buffer has them (the arena keeps up to 64 samples past the last frame) -- is loaded in one go:
-      // a[q] = x[64 q + lane], b[q] = x[64 q + lane + 1].  "x[p+1] > x[p]" is then one ballot per row and the
-      // first-index searches are scalar bit scans; no load depends on a search result.
-      constexpr int kRowsHeld = 33;
-      const int lim = min(remaining, 64 * kRowsHeld);
-      TIn ra[kRowsHeld], rb[kRowsHeld];
+      const int lim = min(remaining0 - fi * kHop, 64 * kRowsHeld);
 #pragma unroll
       for (int q = 0; q < kRowsHeld; ++q) {
         const int p = 64 * q + lane;
         ra[q] = (q < 32 || p < lim) ? x[p] : (TIn)0;
-        rb[q] = (q < 31 || p + 1 < lim) ? x[p + 1] : (TIn)0;
       }
+    };
+    // bit l of the result: x[64 q + l + 1] > x[64 q + l]
+    auto rising = [&](int q) -> mask64 {
+      const TIn next0 = (q + 1 < kRowsHeld) ? first_lane(ra[q + 1 < kRowsHeld ? q + 1 : q]) : (TIn)0;
+      return __ballot(next_lane(ra[q], next0) > ra[q]);
+    };
+    // (double PCM -- buffers a caller normalised itself -- would hold 66 registers of rows in flight: loaded per frame)
+    constexpr bool kPrefetch = sizeof(TIn) == 4;
+    if (kPrefetch) load_rows(0);
+    for (int fi = 0; fi < ch.nframes; ++fi) {
+      if (!kPrefetch) load_rows(fi);
+      int remaining = remaining0 - fi * kHop;          // mData.Size() - n, >= 2048 for an emitted frame
+      double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
+
       // first rising step in [0, min(remaining, 1024) - 1)  (SA:2328-2341)
       int start = 0;
       {
@@ -235,7 +298,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
 #pragma unroll
         for (int q = 0; q < kMaxSeek / 64; ++q) {
           if (!found && 64 * q < bound) {
-            mask64 m = __ballot(rb[q] > ra[q]);
+            mask64 m = rising(q);
             const int valid = bound - 64 * q;
             if (valid < 64) m &= ((mask64)1 << valid) - 1;
             if (m) { start = 64 * q + __ffsll((long long)m) - 1; found = true; }
@@ -253,7 +316,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
 #pragma unroll
         for (int q = 0; q < kRowsHeld; ++q) {
           if (!found && 64 * q + 63 >= lo && 64 * q < hi) {
-            mask64 m = __ballot(rb[q] > ra[q]);
+            mask64 m = rising(q);
             if (64 * q < lo) m &= ~(((mask64)1 << (lo - 64 * q)) - 1);
             if (hi - 64 * q < 64) m &= ((mask64)1 << (hi - 64 * q)) - 1;
             if (m) { period = seek_off + (64 * q + __ffsll((long long)m) - 1 - lo); found = true; }
@@ -261,15 +324,24 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
         }
       }
       double best = 0.0;
-      if (remaining != 0 && period < remaining) {
-        const int width = min(remaining, kSeekWidth);
+      const bool active = remaining != 0 && period < remaining;
+      const int width = min(remaining, kSeekWidth);
+      const int q0 = start >> 6, off = start & 63;
+      if (active) {
         // the segment x[start .. start + width) sits in rows start/64 .. start/64 + 9: through the plane
-        const int q0 = start >> 6, off = start & 63;
         wave_lds_fence();
 #pragma unroll
         for (int q = 0; q < 25; ++q)
           if (q >= q0 && q < q0 + 10) c.plane_d[64 * (q - q0) + lane] = pcm_double<SCALED>(ra[q], sc);
         wave_lds_fence();
+      }
+      // the rows are dead: the next frame's take their registers (the last frame of a chunk re-reads its own)
+      if (kPrefetch) {
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(fi + 1 < ch.nframes ? fi + 1 : fi);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (active) {
         // r[i] = sum_j s[j] s[j+i] through the 2048-point transform of the zero-padded segment
         cx<double> v[16];
 #pragma unroll
@@ -355,6 +427,18 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
         }
       }
     }
+    // The loads of a frame are issued long before they are used (two waves per SIMD hide little: every exposed load
+    // was ~a microsecond of an idle vector ALU): the second half of frame fi + 1 -- the only new samples of a frame --
+    // travels during the whole of frame fi (nx), the blocked copies for the squared-difference terms during the
+    // inverse transform.
+    // (double PCM -- buffers a caller normalised itself -- holds twice the registers in flight: loaded where they are used)
+    constexpr bool kPrefetch = sizeof(TIn) == 4;
+    Pair nx[8];
+    if (kPrefetch) {
+      const Pair* src = reinterpret_cast<const Pair*>(pcm + ch.sample_off + W) + lane;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) nx[r] = src[64 * r];
+    }
     fft(zu, c);
     for (int fi = 0; fi < ch.nframes; ++fi) {
       const TIn* const x = pcm + ch.sample_off + (int64_t)fi * kHop;
@@ -364,16 +448,25 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       //      half, X = spectrum of the frame = U + (-1)^k Un with Un the spectrum of the zero-padded second half.
       //      The second half is the next frame's first half, so each frame costs one forward transform. ----
       cx<double> zn[16];
-      {
+      if (!kPrefetch) {
         const Pair* src = reinterpret_cast<const Pair*>(x + W) + lane;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          zn[r] = {0.0, 0.0};
-          if (r < 8) {
-            const Pair p = src[64 * r];
-            zn[r] = {pcm_double<SCALED>(p.x, sc), pcm_double<SCALED>(p.y, sc)};
-          }
-        }
+        for (int r = 0; r < 8; ++r) nx[r] = src[64 * r];
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        zn[r] = {0.0, 0.0};
+        if (r < 8) zn[r] = {pcm_double<SCALED>(nx[r].x, sc), pcm_double<SCALED>(nx[r].y, sc)};
+      }
+      if (kPrefetch) {
+        __builtin_amdgcn_sched_barrier(0);
+        // the next frame's second half (the last frame of a chunk re-reads its own: no branch, nothing is read
+        // beyond what the chunk's frames cover)
+        const int fn = (fi + 1 < ch.nframes) ? fi + 1 : fi;
+        const Pair* src = reinterpret_cast<const Pair*>(pcm + ch.sample_off + (int64_t)fn * kHop + W) + lane;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) nx[r] = src[64 * r];
+        __builtin_amdgcn_sched_barrier(0);
       }
       fft(zn, c);
       const double sign = (lane & 1) ? -1.0 : 1.0;      // (-1)^k, k = lane + 64 r (1024 - k has the same parity)
@@ -403,6 +496,15 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       // the second half's transform is the next frame's first-half transform
 #pragma unroll
       for (int r = 0; r < 16; ++r) zu[r] = zn[r];
+      // the frame's samples in the blocked layout (16 consecutive per lane) for the squared-difference terms: asked for
+      // now, used behind the inverse transform
+      Block16<TIn> qa, qb;
+      if (kPrefetch) {
+        __builtin_amdgcn_sched_barrier(0);
+        qa.load(x + 16 * lane);
+        qb.load(x + W + 16 * lane);
+        __builtin_amdgcn_sched_barrier(0);
+      }
       fft(g, c);
       // c[2m] = Re F[m] / 1024, c[2m+1] = -Im F[m] / 1024 (and the carried factor 8), m = lane + 64 r;
       // tau < 1024 <=> r < 8.
@@ -422,8 +524,12 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
 
       // ---- squared-difference terms (pitchyinfast.c:96-117) ----
       double xa[16], xb[16];
-      load16(x + 16 * lane, xa);
-      load16(x + W + 16 * lane, xb);
+      if (!kPrefetch) {
+        qa.load(x + 16 * lane);
+        qb.load(x + W + 16 * lane);
+      }
+      qa.get(xa);
+      qb.get(xb);
       scale16<SCALED>(xa, sc);
       scale16<SCALED>(xb, sc);
       double s0 = 0.0, s1 = 0.0;

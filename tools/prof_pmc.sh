@@ -4,7 +4,7 @@
 set -u
 TAG=$1; KSUB=$2; shift 2
 ROOT=$(pwd)
-O=$ROOT/gpurun_out/r03; mkdir -p $O
+O=$ROOT/gpurun_out/${AFX_ROUND:-r04}; mkdir -p $O
 export TMPDIR=/tmp
 cd /tmp
 PASSES=(
@@ -19,12 +19,12 @@ if [ -n "${PMC_PASSES:-}" ]; then IFS=';' read -ra PASSES <<< "$PMC_PASSES"; fi
 i=0
 for P in "${PASSES[@]}"; do
   rm -rf /tmp/pmc_${TAG}_$i
-  timeout 600 rocprofv3 --pmc $P --output-format csv -d /tmp/pmc_${TAG}_$i -o p -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-single "$@" > /tmp/pmc_${TAG}_$i.log 2>&1
+  timeout 600 rocprofv3 --pmc $P --output-format csv -d /tmp/pmc_${TAG}_$i -o p -- python3 $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-single --no-spot-check --no-side-stream "$@" > /tmp/pmc_${TAG}_$i.log 2>&1
   i=$((i+1))
 done
 python3 $ROOT/tools/summarize_pmc.py "$KSUB" $(find /tmp/pmc_${TAG}_* -name "*counter_collection.csv") > $O/${TAG}_pmc_summary.csv
 rm -rf /tmp/kt_$TAG
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o k -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-single "$@" > /tmp/kt_$TAG.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt_$TAG -o k -- python3 $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-single --no-spot-check --no-side-stream "$@" > /tmp/kt_$TAG.log 2>&1
 cp $(find /tmp/kt_$TAG -name "*kernel_stats.csv" | head -1) $O/${TAG}_kernel_stats.csv
 cat $O/${TAG}_pmc_summary.csv
 head -5 $O/${TAG}_kernel_stats.csv

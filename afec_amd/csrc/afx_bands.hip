@@ -104,6 +104,35 @@ __device__ __forceinline__ double band_max(F value_of_row, const mask64 (&bm)[kS
   return wave_max16(acc, lane);
 }
 
+// The spectrum bands ("frequency_bands", SA:2007-2048) that lie inside the stored rows: bands 0..25 = bins 1..737 (the
+// half-wave frame kernel sums bands 26, 27 = bins 738..1023 itself, from the mirrored halves it does not store).
+// x[r] = |X[64 r + lane]|; lanes with (lane & 3) == h, h = 0 / 1, receive band 16 h + (lane >> 2).
+constexpr int kBandsHere = 26;
+__device__ __forceinline__ double spectrum_band_sums(const double (&x)[12], int lane) {
+  double mine = 0.0;
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    double acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int b = 16 * half + i;
+      acc[i] = 0.0;
+      if (b < kBandsHere) {
+#pragma unroll
+        for (int r = 0; r < 12; ++r)
+          if (band_touches(b, r)) {
+            const int k = 64 * r + lane;
+            const bool whole = kBandEdge[b] <= 64 * r && kBandEdge[b + 1] - 1 >= 64 * r + 63;
+            acc[i] += (whole || (k >= kBandEdge[b] && k < kBandEdge[b + 1])) ? x[r] * x[r] : 0.0;
+          }
+      }
+    }
+    const double tot = wave_sum16(acc, lane);  // lane L: band 16 half + ((L >> 2) & 15)
+    if ((lane & 3) == half) mine = tot;
+  }
+  return mine;
+}
+
 // ---- 1024-slot bitonic sort of 32-bit keys, p = 16 lane + reg, every comparator ascending ----
 // ("flip" form: the first stage of a merge of size K pairs p with p ^ (K-1), the rest with p ^ J).
 // In-lane comparators are v_min_u32 / v_max_u32; cross-lane partners come through DPP where the
@@ -265,7 +294,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   for (int ci = wave0; ci < a.n_chunks; ci += stride) {
     const Chunk ch = a.chunks[ci];
     double x[kRows], y[kRows];
-    {
+    if (a.flags & (kBandsFeatures | kBandsFlux)) {
       // the frame before the chunk; the first frame of a buffer is compared with itself (SA:937-940)
       const int64_t prow = (ch.flags & kChunkFirstOfBuffer) ? (int64_t)ch.frame0 : (int64_t)ch.frame0 - 1;
       const double* const prv = a.mag + prow * kHalf;
@@ -297,6 +326,14 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     const double* const cur = a.mag + f * kHalf;
 #pragma unroll
     for (int r = 0; r < kRows; ++r) x[r] = cur[64 * r + lane_v];
+
+    // ---- spectrum bands 0..25 for the half-wave frame kernel, which only stores the magnitudes ----
+    if (a.flags & kBandsSpectrum) {
+      const double mine = spectrum_band_sums(x, lane_v);
+      const int b = 16 * (lane_v & 3) + (lane_v >> 2);
+      if ((lane_v & 3) < 2 && b < kBandsHere) a.rec[f * a.lay.stride + a.lay.bands + b] = mine;
+    }
+    if (!(a.flags & (kBandsFeatures | kBandsFlux))) continue;
 
     // ---- spectral_flux: Pearson r with the previous frame over bins 1..738 (SA:1919-1933,
     //      Statistics.cpp:604-638) ----

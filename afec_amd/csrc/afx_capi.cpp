@@ -168,12 +168,12 @@ struct Workspace {
   hipEvent_t ev_copy = nullptr;   // the host's waits for the plan's upload / download streams (and, when blocking, for this batch's stream)
   bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_plan_set_blocking_wait)
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
-  Buf pcm, chunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
+  Buf pcm, chunks, wchunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff, rt_long, rt_polar;   // rhythm tracker
   Buf stat_tmp;                                                                 // half-wave statistics class
   Buf rs_files, rs_groups, rs_ngroups;                                          // sample-rate conversion (afx_resample.hip)
   size_t bytes() const {
-    return pcm.cap + chunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
+    return pcm.cap + chunks.cap + wchunks.cap + rem.cap + rec.cap + mag.cap + foff.cap + stats.cap + cfirst.cap + follower.cap + spans.cap +
            efflen.cap + raw.cap + files.cap + scan.cap + partial.cap + place.cap + queue.cap + rt_files.cap + rt_long.cap + rt_polar.cap + rt_odf.cap +
            rt_onsets.cap + rt_scratch.cap + rt_scalars.cap + rt_stats.cap + rt_foff.cap + stat_tmp.cap + rs_files.cap + rs_groups.cap + rs_ngroups.cap;
   }
@@ -222,7 +222,10 @@ struct afx_batch {
   void* d_pcm = nullptr;
   afx::Chunk* d_chunks = nullptr;
   afx::ChunkRemaining* d_rem = nullptr;
-  int32_t* d_chunk_first = nullptr;
+  int32_t* d_chunk_first = nullptr;      // whitening kernels: [n_bufs + 1] into d_wchunks
+  afx::Chunk* d_wchunks = nullptr;       // whitening kernels' chunk table
+  int n_wchunks = 0;
+  bool need_follow = false;
   afx::BufSpan* d_spans = nullptr;
   int32_t* d_efflen = nullptr;
   double* d_follower = nullptr;
@@ -260,6 +263,7 @@ struct afx_batch {
   std::vector<afx::Chunk> h_chunks;
   std::vector<afx::ChunkRemaining> h_remaining;
   std::vector<int32_t> h_chunk_first;
+  std::vector<afx::Chunk> h_wchunks;
   std::vector<afx::BufSpan> h_spans;
   std::vector<afx::LoadPlace> h_place;
   bool mag_wanted = false;
@@ -411,7 +415,7 @@ void free_tables(afx_plan* p) {
 
 void ws_free(Workspace* w) {
   if (!w) return;
-  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
+  for (Workspace::Buf* b : {&w->pcm, &w->chunks, &w->wchunks, &w->rem, &w->rec, &w->mag, &w->foff, &w->stats, &w->cfirst, &w->follower, &w->spans,
                             &w->efflen, &w->raw, &w->files, &w->scan, &w->partial, &w->place, &w->queue, &w->rt_files, &w->rt_long, &w->rt_polar, &w->rt_odf,
                             &w->rt_onsets, &w->rt_scratch, &w->rt_scalars, &w->rt_stats, &w->rt_foff, &w->stat_tmp, &w->rs_files, &w->rs_groups,
                             &w->rs_ngroups}) hipFree(b->p);
@@ -543,6 +547,8 @@ constexpr uint32_t kTimeBits = AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOP
 uint32_t frames_mask(uint32_t mask) {
   uint32_t m = mask & kSpectralBits;
   if (mask & kNeedsMagnitudes) m |= AFX_D_MAGNITUDE;
+  // who reads bins above 768 of the stored magnitudes: the caller (AFX_D_MAGNITUDE) and the whitening kernels
+  if (mask & (AFX_D_MAGNITUDE | AFX_D_SPECTRAL_COMPLEXITY | AFX_D_F0)) m |= afx::kFramesWholeSpectrum;
   return m;
 }
 
@@ -812,6 +818,9 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   // several frames; smaller ones (one short file per call) stay with the 64-lane kernel
   b->halfwave = plan->halfwave && afx::frames_use_halfwave(fmask, plan->desc.precision, dtype) &&
                 (plan->halfwave == 2 || frames >= 8 * (int64_t)plan->cu_count * afx::frames32_waves_per_block() * 2);
+  // the half-wave full class always leaves the magnitudes (bands_kernel takes flux, the 28 bands and the sub-band
+  // descriptors from them)
+  if (b->halfwave && afx::frames32_class(fmask) >= 2) b->mag_wanted = true;
   const int waves_per_block = b->halfwave ? afx::frames32_waves_per_block() : afx::frames_waves_per_block(fmask);
   const int64_t slots = (int64_t)plan->cu_count * waves_per_block * (b->halfwave ? 2 : 1);
   int K = 32;
@@ -826,8 +835,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   }
   std::vector<afx::Chunk>& chunks = b->h_chunks;
   std::vector<afx::ChunkRemaining>& remaining = b->h_remaining;
-  std::vector<int32_t>& chunk_first = b->h_chunk_first;
-  chunk_first.assign((size_t)n_bufs, 0);
+  std::vector<int32_t>& chunk_first = b->h_chunk_first;   // (of the whitening kernels' table, below)
   b->chunk_frames = K;
   // When the half-wave frame kernel is the only consumer of the chunk table (it draws chunks from a work queue),
   // the last part of every buffer is cut into short chunks and the table is ordered long chunks first: the waves
@@ -836,7 +844,6 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   const int Ks = guided ? K / 4 : K;
   for (int i = 0; i < n_bufs; ++i) {
     const int64_t f = b->frame_offset[i + 1] - b->frame_offset[i];
-    chunk_first[(size_t)i] = (int32_t)chunks.size();
     const int64_t f_long = guided ? (f * 7 / 8) / K * K : f;   // frames covered by chunks of K
     for (int64_t f0 = 0; f0 < f;) {
       const int k = (f0 < f_long) ? K : Ks;
@@ -889,7 +896,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     }
     b->d_queue = (unsigned*)w.queue.p;
     if (fmask != 1u) {   // statistics class: raw sums per frame for its closed-form kernel
-      if ((e = ws_reserve(w.stat_tmp, (size_t)frames * 8 * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stat_tmp)"));
+      if ((e = ws_reserve(w.stat_tmp, (size_t)frames * afx::frames32_stat_tmp_doubles() * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stat_tmp)"));
       b->d_stat_tmp = (double*)w.stat_tmp.p;
     }
   }
@@ -898,12 +905,43 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     b->d_rem = (afx::ChunkRemaining*)w.rem.p;
     if ((e = hipMemcpyAsync(b->d_rem, remaining.data(), remaining.size() * sizeof(afx::ChunkRemaining), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(remaining)"));
   }
-  if (b->n_chunks > 0 && (mask & AFX_D_SPECTRAL_COMPLEXITY)) {
+  if (b->n_chunks > 0 && (mask & kWhitenBits)) {
+    // The whitening kernels walk their own chunk table.  Their only state across frames is the follower, which starts
+    // from the reset value at a buffer's first frame: in a batch of thousands of short files (a crawl's typical batch)
+    // a chunk is the whole file -- every chunk then starts from the reset state and follow_kernel (one more pass over
+    // the 8 KiB of magnitudes per frame) is not needed; long files, and batches too small to fill the chip with one
+    // wave per file, keep chunks of K frames whose start states follow_kernel provides.
+    constexpr int64_t kWholeFileFrames = 128;
+    const bool whole_files = n_bufs >= 1024;
+    std::vector<afx::Chunk>& wchunks = b->h_wchunks;
+    chunk_first.assign((size_t)n_bufs + 1, 0);
+    for (int i = 0; i < n_bufs; ++i) {
+      const int64_t f = b->frame_offset[i + 1] - b->frame_offset[i];
+      chunk_first[(size_t)i] = (int32_t)wchunks.size();
+      const int64_t step = (whole_files && f <= kWholeFileFrames) ? std::max<int64_t>(f, 1) : K;
+      if (f > step) b->need_follow = true;
+      for (int64_t f0 = 0; f0 < f; f0 += step) {
+        afx::Chunk c;
+        c.sample_off = b->arena_off[i] + f0 * plan->desc.hop_size;
+        c.frame0 = (int32_t)(b->frame_offset[i] + f0);
+        c.nframes = (int16_t)std::min<int64_t>(step, f - f0);
+        c.flags = (int16_t)(f0 == 0 ? afx::kChunkFirstOfBuffer : 0);
+        c.scale = scale_of(i);
+        wchunks.push_back(c);
+      }
+    }
+    chunk_first[(size_t)n_bufs] = (int32_t)wchunks.size();
+    b->n_wchunks = (int)wchunks.size();
+    if ((e = ws_reserve(w.wchunks, wchunks.size() * sizeof(afx::Chunk))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(whitening chunks)"));
+    b->d_wchunks = (afx::Chunk*)w.wchunks.p;
+    if ((e = hipMemcpyAsync(b->d_wchunks, wchunks.data(), wchunks.size() * sizeof(afx::Chunk), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(whitening chunks)"));
     if ((e = ws_reserve(w.cfirst, chunk_first.size() * sizeof(int32_t))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(chunk_first)"));
     b->d_chunk_first = (int32_t*)w.cfirst.p;
     if ((e = hipMemcpyAsync(b->d_chunk_first, chunk_first.data(), chunk_first.size() * sizeof(int32_t), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(chunk_first)"));
-    if ((e = ws_reserve(w.follower, (size_t)b->n_chunks * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(follower)"));
-    b->d_follower = (double*)w.follower.p;
+    if ((mask & AFX_D_SPECTRAL_COMPLEXITY) && b->need_follow) {
+      if ((e = ws_reserve(w.follower, (size_t)b->n_wchunks * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(follower)"));
+      b->d_follower = (double*)w.follower.p;
+    }
   }
   if (n_bufs > 0 && (mask & AFX_D_EFFECTIVE_LENGTH)) {
     std::vector<afx::BufSpan>& spans = b->h_spans;
@@ -920,7 +958,8 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     b->d_rec = (double*)w.rec.p;
   }
   if (frames > 0 && b->mag_wanted) {
-    if ((e = ws_reserve(w.mag, (size_t)frames * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(mag)"));
+    // (+ 1 row: the half-wave full class sends the stores of frames past a chunk's end there)
+    if ((e = ws_reserve(w.mag, (size_t)(frames + 1) * afx::kHalf * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(mag)"));
     b->d_mag = (double*)w.mag.p;
   }
   if ((want_stats || (mask & kWhitenBits)) && n_bufs > 0 && b->lay.stride > 0) {
@@ -1546,29 +1585,36 @@ int afx_batch_run(afx_batch* b) {
       a.queue_base = b->ws->queue_count;
       b->ws->queue_count += (unsigned)((b->n_chunks + 1) / 2);
       a.stat_tmp = b->d_stat_tmp;
+      a.mag_spare_row = b->total_frames;
       HIP_TRY(afx::launch_frames32(a, b->grid_blocks, b->stream, b->total_frames, b->pcm_dtype == afx::kPcmScaledF32));
     } else HIP_TRY(afx::launch_frames(a, b->plan->desc.precision, b->pcm_dtype, b->grid_blocks, b->stream));
   }
-  if (b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) {
+  // the half-wave full class leaves the 28 spectrum bands to bands_kernel (it stores the magnitudes for it)
+  const bool bands28_later = b->halfwave && (b->mask & AFX_D_SPECTRUM_BANDS);
+  if ((b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) || bands28_later) {
     afx::BandArgs ba{};
     ba.mag = b->d_mag; ba.chunks = b->d_chunks; ba.n_chunks = b->n_chunks; ba.rec = b->d_rec; ba.lay = b->lay;
-    ba.flags = ((b->mask & AFX_D_BAND_FEATURES) ? afx::kBandsFeatures : 0) | ((b->mask & AFX_D_SPECTRAL_FLUX) ? afx::kBandsFlux : 0);
+    ba.flags = ((b->mask & AFX_D_BAND_FEATURES) ? afx::kBandsFeatures : 0) | ((b->mask & AFX_D_SPECTRAL_FLUX) ? afx::kBandsFlux : 0) |
+               (bands28_later ? afx::kBandsSpectrum : 0);
     HIP_TRY(afx::launch_bands(ba, b->stream));
   }
-  if (b->mask & kTimeBits) {
+  // the half-wave full classes leave the amplitude of the hop to hop_kernel
+  const uint32_t post_amplitude = (b->halfwave && afx::frames32_class(frames_mask(b->mask)) >= 2) ? (b->mask & (AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS)) : 0u;
+  if ((b->mask & kTimeBits) || post_amplitude) {
     afx::TimeArgs ta{};
     ta.pcm = b->d_pcm; ta.chunks = b->d_chunks; ta.remaining = b->d_rem; ta.n_chunks = b->n_chunks;
     ta.pcm_dtype = b->pcm_dtype; ta.rec = b->d_rec; ta.lay = b->lay;
     ta.t1 = t.t1_f64; ta.t2 = t.t2_f64; ta.post = t.post_f64;
-    if (b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) HIP_TRY(afx::launch_hop(ta, b->stream));
+    ta.amplitude = post_amplitude;
+    if ((b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) || post_amplitude) HIP_TRY(afx::launch_hop(ta, b->stream));
     if (b->mask & AFX_D_AUTO_CORRELATION) HIP_TRY(afx::launch_acorr(ta, b->stream));
     if (b->mask & AFX_D_F0) HIP_TRY(afx::launch_pitch(ta, b->stream));
   }
   if (b->mask & kWhitenBits) {
     afx::WhitenArgs wa{};
     wa.mag = b->d_mag; wa.frame_offset = b->d_frame_offset; wa.n_bufs = b->n_bufs; wa.mask = b->mask;
-    wa.chunk_first = b->d_chunk_first; wa.chunks = b->d_chunks; wa.n_chunks = b->n_chunks;
-    wa.chunk_frames = b->chunk_frames; wa.follower = b->d_follower;
+    wa.chunk_first = b->d_chunk_first; wa.chunks = b->d_wchunks; wa.n_chunks = b->n_wchunks;
+    wa.chunk_frames = b->chunk_frames; wa.follower = b->d_follower; wa.need_follow = b->need_follow ? 1 : 0;
     wa.rec = b->d_rec; wa.lay = b->lay;
     // new_aubio_spectral_whitening + set_relax_time(MSpectralWhiteningDecay = 22): awhitening.c:53-87,
     // SampleAnalyser.cpp:44, 805-809

@@ -37,6 +37,9 @@ using f32x32::cx;
 constexpr int kHalfSlots = 1056;                      // 8-byte slots per half: 33 * 31 + 31 + 1, rounded to 32
 constexpr int kPlane32Bytes = 2 * kHalfSlots * 8;     // 16 896 per wave
 constexpr int kWaves32 = 8;
+// raw sums per frame the statistics / full classes leave for stats32_finish_kernel: sum m, m^2, j m, j^2 m, m^3, m^4,
+// sum log(m + 1e-20), rolloff count, sum x^2 of the hop, max |x| of the hop
+constexpr int kStatTmp = 10;
 
 template <int POST_ROWS>
 struct Lds32 {
@@ -221,10 +224,18 @@ __device__ __forceinline__ void finish_mfcc32(double acc, double*& recp, int& le
 
 template <int FEAT, bool SCALED>
 __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs a) {
-  constexpr bool PAIRS = (FEAT == 1);
+  constexpr bool PAIRS = (FEAT >= 1);
+  // FEAT 2, 3 ("full" classes, for masks with flux / spectrum bands / sub-band descriptors / amplitude): the statistics
+  // class that also leaves the magnitudes in a.mag_out for bands_kernel and the whitening kernels, the amplitude peak /
+  // rms of the hop (SA:1760-1783) and the two spectrum bands above the analysis range (bins 738..904, 905..1023: sums
+  // of |X|^2 straight from the mirrored halves of rows 0..8, no square root).  FEAT 2 stores what the statistics class
+  // computes anyway: bins 0..768, all bands_kernel reads.  FEAT 3 also produces and stores the mirrored blocks of rows
+  // 0..7 (bins 769..1023): the whole spectrum, for the whitening follower / fail-safe f0 and the magnitude output.
+  constexpr bool STORE = (FEAT >= 2);
+  constexpr bool UPPER = (FEAT == 3);
   // rows of 32 bins that are untangled directly: bins 0..383 for the mel filters, 0..511 (+ their mirrored blocks) for
   // the spectral statistics
-  constexpr int MR = (FEAT == 1) ? 16 : kMel32Rows;
+  constexpr int MR = (FEAT >= 1) ? 16 : kMel32Rows;
   using Map = Lds32<kMel32Rows>;   // untangle factors of rows 0..11; rows 12..15 are rows 0..3 times w2048^384
   extern __shared__ __align__(16) unsigned char lds_raw[];
   const int lane = threadIdx.x & 63;
@@ -355,7 +366,6 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       }
       __builtin_amdgcn_sched_barrier(0);
       AFX_STAMP(1);   // hop reads + conversion + window + first radix-4 stage
-
       // ---- P1 (rest) ----
       f32x32::dft32_rest(v);
       __builtin_amdgcn_sched_barrier(0);
@@ -435,7 +445,19 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       // statistics class: magnitudes of rows 0..11 wait here for the rolloff walk (upper part of the wave's exchange
       // plane: 384 doubles per half behind the 8 KiB the hop DMA writes)
       double* const park = reinterpret_cast<double*>(plane_bytes + 8192 + 4352 * h);
-      if (FEAT == 1) {
+      // full classes: this half's row of a.mag_out; a frame past the end of the half's chunk writes the spare row behind
+      // the last frame instead (no branch around the stores).  Stored magnitudes are flushed like the reference's
+      // (TAudioMath::Magnitude runs with DAZ + FZ): exactly 0 at or below kFlushLevel -- the value the sums take anyway.
+      // The address is rebuilt at every group of stores: two pointers kept for the whole frame are four registers
+      // this kernel does not have.
+      auto mag_row = [&]() -> double* {
+        int fl = fi, ql = lane;
+        asm volatile("" : "+v"(ql), "+s"(fl));
+        const int64_t mrow = (fl < nfr) ? (int64_t)ch.frame0 + fl : a.mag_spare_row;
+        return a.mag_out + mrow * 1024 + (ql & 31);          // + 32 r: bin 32 r + q;  + 1024 - 2 q - 32 r: bin 1024 - 32 r - q
+      };
+      double band26 = 0.0, band27 = 0.0;   // full classes: sums of |X|^2 over bins 738..904 and 905..1023 (spectrum bands 26, 27)
+      if (FEAT >= 1) {
         int ql = lane;
         asm volatile("" : "+v"(ql));
         jq = (double)((ql & 31) - 1);
@@ -447,9 +469,12 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       // Magnitudes below sqrt(DBL_MIN) are 0 in the reference (TAudioMath::Magnitude runs with DAZ + FZ): a silent
       // frame has centroid 0, not (n - 1) / 2.
       // accumulate_at: a value that is not one of the direct rows (mirrored block, bin 512)
-      auto accumulate_at = [&](double value, double j, bool in_range) {
-        const bool ok = in_range && value > logc[kCSqrtMin];
+      // store_at: full classes, where the flushed value goes (nullptr: nowhere); every in-range caller stores what it sums
+      auto accumulate_at = [&](double value, double j, bool in_range, double* store_at, bool all_in_range) {
+        const bool audible = value > logc[kCSqrtMin];
+        const bool ok = in_range && audible;
         const double m = ok ? value : 0.0;
+        if (STORE && store_at) *store_at = all_in_range ? m : (audible ? value : 0.0);
         const double m2 = m * m;
         const double jm = j * m;
         s1 += m;
@@ -460,9 +485,11 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         s4 = fma(m2, m2, s4);
         prod_b *= ok ? (value + logc[kCEps]) : 1.0;
       };
-      auto accumulate = [&](int r) {
-        const bool ok = ((r == 0) ? (q != 0) : true) && mag[r] > logc[kCSqrtMin];
+      auto accumulate = [&](int r, double* store_at) {
+        const bool audible = mag[r] > logc[kCSqrtMin];
+        const bool ok = ((r == 0) ? (q != 0) : true) && audible;
         const double m = ok ? mag[r] : 0.0;
+        if (STORE && store_at) *store_at = (r == 0) ? (audible ? mag[r] : 0.0) : m;   // bin 0 is outside the sums, not outside the spectrum
         const double m2 = m * m;
         const double jm = jq * m;
         s1 += m;
@@ -490,28 +517,42 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         }
         const double er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
         const double orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
-        if (PAIRS && r >= 8) {
+        if (PAIRS && (STORE || r >= 8)) {
           const double tr = fma(wq.x, orr, -wq.y * oi), ti = fma(wq.x, oi, wq.y * orr);   // w O
           const double xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
           mag[r] = mag_sqrt_mel(xr, xi, k_tiny, k_three);
-          const double mv = mag_sqrt_mel(yr, yi, k_tiny, k_three);                        // |X[1024 - k]|
-          if (r < kMel32Rows) park[32 * (r + 4) + q] = mv;    // M_8..M_11 wait in LDS (slots 12..15) for the registers of the FFT
-          else {
-            mir[r - kMel32Rows] = mv;
-            accumulate_at(mv, jmir, true);
-            jmir -= logc[kC32];
+          if (r < 8) {
+            // the mirrored block lies above the analysis range (bins 769..1023): |X|^2 into the two spectrum bands there
+            // (M_3 = bins 897..928 holds the edge at 905); row 0, lane 0 would be bin 1024, which does not exist
+            const double sq = fma(yi, yi, yr * yr);
+            if (r < 3) band27 += (r == 0 && q == 0) ? 0.0 : sq;
+            else if (r == 3) { band27 += (q <= 23) ? sq : 0.0; band26 += (q <= 23) ? 0.0 : sq; }
+            else band26 += sq;
+            if (UPPER) {
+              const double mv = mag_sqrt_mel(yr, yi, k_tiny, k_three);
+              double* const dst = mag_row() + (1024 - 32 * r) - 2 * q;
+              if (!(r == 0 && q == 0)) *dst = mv > logc[kCSqrtMin] ? mv : 0.0;
+            }
+          } else {
+            const double mv = mag_sqrt_mel(yr, yi, k_tiny, k_three);                      // |X[1024 - k]|
+            if (r < kMel32Rows) park[32 * (r + 4) + q] = mv;    // M_8..M_11 wait in LDS (slots 12..15) for the registers of the FFT
+            else {
+              mir[r - kMel32Rows] = mv;
+              accumulate_at(mv, jmir, true, STORE ? mag_row() + (1024 - 32 * r) - 2 * q : nullptr, true);
+              jmir -= logc[kC32];
+            }
           }
         } else {
           const double xr = fma(wq.x, orr, fma(-wq.y, oi, er));
           const double xi = fma(wq.x, oi, fma(wq.y, orr, ei));
           mag[r] = mag_sqrt_mel(xr, xi, k_tiny, k_three);
         }
-        if (FEAT == 1 && r >= kMel32Rows) accumulate(r);
+        if (FEAT >= 1 && r >= kMel32Rows) accumulate(r, STORE ? mag_row() + 32 * r : nullptr);
       };
-      if constexpr (FEAT == 1) {
-        // statistics class: rows in groups of two, one group of fetches ahead.  It keeps eighteen doubles of sums next to the
-        // FFT registers; with four rows in flight (as below) the allocator spilled 88 bytes per lane, with two 36, and the
-        // shorter groups cost less than the spills did (285 -> 291 M frames/s on the star set).
+      if constexpr (FEAT >= 1) {
+        // statistics and full classes: rows in groups of two, one group of fetches ahead.  They keep eighteen doubles of sums
+        // next to the FFT registers; with four rows in flight (as below) the allocator spilled 88 bytes per lane, with two 36,
+        // and the shorter groups cost less than the spills did (285 -> 291 M frames/s on the star set).
         fetch(0); fetch(1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -545,7 +586,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       for (int r = 8; r < 12; ++r) untangle(r);
       __builtin_amdgcn_sched_barrier(0);
       }
-      if (FEAT == 1) {   // statistics class: behind the last rows (62 registers in flight that it cannot spare earlier)
+      if (FEAT >= 1) {   // statistics class: behind the last rows (62 registers in flight that it cannot spare earlier)
 #pragma unroll
         for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
       }
@@ -563,12 +604,15 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
             if (mel32_touches(f, r)) e[f] += mag[r] * mwt[mel32_pair_index(r, f)];
         __builtin_amdgcn_sched_barrier(0);
         AFX_STAMP(7);   // mel rows (waits for the table loads)
-        if (FEAT == 1) {
+        if (FEAT >= 1) {
           // statistics class: the mel sums are reduced first (their registers are needed), then rows 12..15 and their mirrors
           const double tot1 = half_sum16(e, lane);
           if ((lane & 1) == (fi & 1)) mel_acc = tot1;
+          {
+            double* const row0 = STORE ? mag_row() : nullptr;
 #pragma unroll
-          for (int r = 0; r < kMel32Rows; ++r) accumulate(r);
+            for (int r = 0; r < kMel32Rows; ++r) accumulate(r, STORE ? row0 + 32 * r : nullptr);
+          }
           // rows 0..11 are needed once more (rolloff): their row sums now, the values parked in the part of the
           // exchange plane that the hop DMA does not use
           {
@@ -578,14 +622,19 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
             pa = half_sum16(ra, lane);               // lane L: row (L & 31) >> 1
 #pragma unroll
             for (int r = 0; r < 12; ++r) park[32 * r + q] = mag[r];
+
           }
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int r = 12; r < 16; ++r) fetch(r);
           if constexpr (PAIRS) {   // the mirrored blocks of rows 8..11, parked by the untangle stage: bins 737..768 (two of them in range) .. 641..672
+            double* const mrow0 = STORE ? mag_row() + 1024 - 2 * q : nullptr;   // bin 1024 - 32 r - q at - 32 r
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              accumulate_at(park[32 * (12 + i) + q], jmir, (i == 0) ? (q >= 30) : true);
+              const double mv = park[32 * (12 + i) + q];
+              // M_8 = bins 737..768: two of them inside the analysis range, the others (q <= 30) in spectrum band 26
+              if (STORE && i == 0) band26 += (q <= 30) ? 0.25 * (mv * mv) : 0.0;   // (the row sums are of the halved spectrum, x 4 below)
+              accumulate_at(mv, jmir, (i == 0) ? (q >= 30) : true, STORE ? mrow0 - 32 * (8 + i) : nullptr, i != 0);
               jmir -= logc[kC32];
             }
           }
@@ -597,7 +646,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
             // bin 512 = lane 0 of row 16 is its own partner: E = 2 Re Z, w O = -2i Im Z (the window carries the 1/2)
             const double er = v[16].re + v[16].re, orr = v[16].im + v[16].im;
             cmid = (q == 0) ? mag_sqrt_mel(er, orr, k_tiny, k_three) : 0.0;
-            accumulate_at(cmid, logc[kC511], q == 0);
+            accumulate_at(cmid, logc[kC511], q == 0, (STORE && q == 0) ? mag_row() + 512 : nullptr, true);
           }
         }
         // the next frame's window pairs, under the reduction and the log / DCT (statistics class: behind its sums,
@@ -611,7 +660,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           if ((lane & 1) == (fi & 1)) mel_acc = tot;
         }
         AFX_STAMP(8);   // window issue + reduction
-        if (FEAT == 1) {
+        if (FEAT >= 1) {
           // ---- spectral statistics (SA:1808-1933): the sums of this half's frame, reduced over its 32 lanes; the
           //      closed forms (sqrt, divisions, exp / log of the flatness) are left to stats32_finish_kernel ----
           int ln = lane;
@@ -620,13 +669,19 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           double st[16];
           st[0] = s1; st[1] = s2; st[2] = sj; st[3] = sjj; st[4] = s3; st[5] = s4;
           st[6] = log_lds(prod_a, logc) + log_lds(prod_b, logc);
+          st[7] = STORE ? 4.0 * band26 : 0.0;   // the window carries an extra 1/2 (mag_sqrt_mel): |X|^2 = 4 |X / 2|^2
+          st[8] = STORE ? 4.0 * band27 : 0.0;
 #pragma unroll
-          for (int i = 7; i < 16; ++i) st[i] = 0.0;
+          for (int i = 9; i < 16; ++i) st[i] = 0.0;
           const double red = half_sum16(st, ln);    // lane L: st[(L & 31) >> 1]
           const int64_t row = (int64_t)ch.frame0 + fi;
           const bool live = fi < nfr;
-          double* const tmp = a.stat_tmp + row * 8;
+          double* const tmp = a.stat_tmp + row * kStatTmp;
           if (live && (hq & 1) == 0 && (hq >> 1) < 7) tmp[hq >> 1] = red;
+          if (STORE) {   // slots 7, 8: spectrum bands 26, 27 straight into the record
+            double* const rec = a.rec + row * a.lay.stride;
+            if (live && a.lay.bands >= 0 && (hq == 14 || hq == 16)) rec[a.lay.bands + 26 + ((hq >> 1) - 7)] = red;
+          }
           // ---- rolloff (scalar.c:472-492): bins whose running sum stays below 85 % of the total ----
           const int base_idx = (ln & 32) << 2;       // byte index of lane 32 h for ds_bpermute
           const double total = __hiloint2double(__builtin_amdgcn_ds_bpermute(base_idx, __double2hiint(red)),
@@ -707,6 +762,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           cnt = cnt > kBinCount ? kBinCount : cnt;
           if (live && hq == 0) tmp[7] = (double)cnt;
           __builtin_amdgcn_sched_barrier(0);
+
 #pragma unroll
           for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
         }
@@ -737,11 +793,12 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 
 // Closed forms of the spectral statistics from the raw sums the statistics-class kernel left per frame
 // (SA:1808-1933; the same formulas as afx_kernels.hip, with the second moments expanded around the centroid):
-// tmp[f] = {sum m, sum m^2, sum j m, sum j^2 m, sum m^3, sum m^4, sum log(m + 1e-20), rolloff count}
+// tmp[f] = {sum m, sum m^2, sum j m, sum j^2 m, sum m^3, sum m^4, sum log(m + 1e-20), rolloff count, sum x^2 and
+// max |x| of the hop (full class)}
 __global__ __launch_bounds__(256) void stats32_finish_kernel(const FrameArgs a, int64_t n_frames) {
   const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (f >= n_frames) return;
-  const double* t = a.stat_tmp + f * 8;
+  const double* t = a.stat_tmp + f * kStatTmp;
   const double s1 = t[0], s2 = t[1], sj = t[2], sjj = t[3], s3 = t[4], s4 = t[5], slog = t[6], cnt = t[7];
   double* const rec = a.rec + f * a.lay.stride;
   const double n = (double)kBinCount, inv_n = 1.0 / (double)kBinCount;
@@ -782,11 +839,20 @@ __global__ __launch_bounds__(256) void stats32_finish_kernel(const FrameArgs a, 
 }  // namespace
 
 int frames32_waves_per_block() { return kWaves32; }
+int frames32_stat_tmp_doubles() { return kStatTmp; }
 
-// which (descriptor mask, arithmetic, PCM type) combinations the half-wave kernels serve: MFCC alone, or MFCC with any
-// of the spectral statistics rms / centroid / spread / skewness / kurtosis / rolloff / flatness (bits 1..7)
+// which (descriptor mask, arithmetic, PCM type) combinations the half-wave kernels serve: MFCC alone; MFCC with any
+// of the spectral statistics rms / centroid / spread / skewness / kurtosis / rolloff / flatness (bits 1..7); and the
+// full class: those plus the amplitude of the hop (bits 11, 12) and the stored magnitudes (bit 13) that bands_kernel
+// turns into flux, the 28 spectrum bands and the sub-band descriptors (bits 8..10)
 bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype) {
-  return (mask & 1u) && !(mask & ~0xFFu) && precision == 0 && (pcm_dtype == kPcmF32 || pcm_dtype == kPcmScaledF32);
+  return (mask & 1u) && !(mask & ~(0x3FFFu | kFramesWholeSpectrum)) && precision == 0 && (pcm_dtype == kPcmF32 || pcm_dtype == kPcmScaledF32);
+}
+// 0 = MFCC only, 1 = + spectral statistics, 2 = full with bins 0..768 stored, 3 = full with the whole spectrum stored
+int frames32_class(uint32_t mask) {
+  if (mask == 1u) return 0;
+  if (!(mask & ~0xFFu)) return 1;
+  return (mask & kFramesWholeSpectrum) ? 3 : 2;
 }
 
 template <int FEAT, bool SCALED>
@@ -810,8 +876,15 @@ static hipError_t launch_frames32_class(const FrameArgs& a, int grid_blocks, hip
 // by its closed-form kernel
 hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames, bool scaled) {
   if (a.n_chunks <= 0) return hipSuccess;
-  if (a.mask == 1u) return scaled ? launch_frames32_class<0, true>(a, grid_blocks, stream) : launch_frames32_class<0, false>(a, grid_blocks, stream);
-  hipError_t e = scaled ? launch_frames32_class<1, true>(a, grid_blocks, stream) : launch_frames32_class<1, false>(a, grid_blocks, stream);
+  const int cls = frames32_class(a.mask);
+  if (cls == 0) return scaled ? launch_frames32_class<0, true>(a, grid_blocks, stream) : launch_frames32_class<0, false>(a, grid_blocks, stream);
+  hipError_t e;
+  if (scaled)
+    e = (cls == 1) ? launch_frames32_class<1, true>(a, grid_blocks, stream)
+                   : (cls == 2 ? launch_frames32_class<2, true>(a, grid_blocks, stream) : launch_frames32_class<3, true>(a, grid_blocks, stream));
+  else
+    e = (cls == 1) ? launch_frames32_class<1, false>(a, grid_blocks, stream)
+                   : (cls == 2 ? launch_frames32_class<2, false>(a, grid_blocks, stream) : launch_frames32_class<3, false>(a, grid_blocks, stream));
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(stats32_finish_kernel, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, stream, a, total_frames);
   return hipGetLastError();

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 namespace afx {
+constexpr uint32_t kFramesWholeSpectrum = 1u << 31;
 
 // Geometry the kernels are specialised for: the only one the reference ever instantiates
 // (Crawler.cpp:41-43, 599-600): 44.1 kHz, 2048-sample frame, 1024 hop.
@@ -130,8 +131,9 @@ struct FrameArgs {
   const void* melw32;  // [kMel32Pairs][32] packed mel rows
   unsigned* queue;     // work-queue counter of the half-wave kernels: advances by ceil(n_chunks / 2) per launch
   unsigned queue_base; // its value when this launch starts
-  unsigned long long* stamps;
-  double* stat_tmp;             // half-wave statistics class: [F][8] raw sums per frame (afx_frames32.hip)   // diagnostic builds (AFX_STAMPS): 16 per-stage cycle counters, else nullptr
+  unsigned long long* stamps;   // diagnostic builds (AFX_STAMPS): 16 per-stage cycle counters, else nullptr
+  double* stat_tmp;             // half-wave statistics / full class: [F][frames32_stat_tmp_doubles()] raw sums per frame (afx_frames32.hip)
+  int64_t mag_spare_row;        // half-wave full class: row of mag_out behind the last frame (stores of frames past a chunk's end)
 };
 
 // launchers (afx_kernels.hip).  precision: 0 = f64, 1 = f32; pcm_dtype: kPcm*
@@ -142,6 +144,10 @@ int frames_waves_per_block(uint32_t mask);    // waves (of 64 lanes) per workgro
 bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype);
 hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames, bool scaled);
 int frames32_waves_per_block();
+int frames32_stat_tmp_doubles();
+int frames32_class(uint32_t frames_mask);   // 0 = MFCC only, 1 = + spectral statistics, 2 = full (bins 0..768 stored, amplitude), 3 = full, whole spectrum
+// internal bit of FrameArgs::mask: a consumer of the stored magnitudes needs bins above 768 too (the whitening follower
+// and the fail-safe f0 of afx_whiten.hip, the magnitude output) -- the half-wave full class then produces them
 int frames_feature_class(uint32_t mask);     // 0 = MFCC only, 1 = + statistics, 2 = everything
 
 // band-feature kernel (SampleAnalyser.cpp:2067-2308) working from stored magnitudes
@@ -153,7 +159,7 @@ struct BandArgs {
   RecordLayout lay;
   uint32_t flags;       // kBandsFeatures | kBandsFlux
 };
-enum { kBandsFeatures = 1, kBandsFlux = 2 };
+enum { kBandsFeatures = 1, kBandsFlux = 2, kBandsSpectrum = 4 };   // kBandsSpectrum: the 28 "frequency_bands" (SA:2007-2048)
 hipError_t launch_bands(const BandArgs& a, hipStream_t stream);
 
 // ---- neighbours of the spectral set ----
@@ -169,8 +175,9 @@ struct TimeArgs {
   const void* t1;         // the double FFT tables of FrameArgs
   const void* t2;
   const void* post;
+  uint32_t amplitude;     // hop_kernel, for the half-wave full classes: AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS to write
 };
-hipError_t launch_hop(const TimeArgs& a, hipStream_t stream);      // silence flag, envelope
+hipError_t launch_hop(const TimeArgs& a, hipStream_t stream);      // silence flag, envelope (+ amplitude peak / rms)
 hipError_t launch_acorr(const TimeArgs& a, hipStream_t stream);    // auto_correlation
 hipError_t launch_pitch(const TimeArgs& a, hipStream_t stream);    // f0, f0 confidence (aubio yinfast)
 
@@ -180,10 +187,11 @@ hipError_t launch_pitch(const TimeArgs& a, hipStream_t stream);    // f0, f0 con
 struct WhitenArgs {
   const double* mag;            // [F][1024]
   const int64_t* frame_offset;  // [n_bufs + 1], device
-  const int32_t* chunk_first;   // [n_bufs]: index of the buffer's first chunk
-  const Chunk* chunks;
+  const int32_t* chunk_first;   // [n_bufs + 1]: index of the buffer's first chunk in `chunks`
+  const Chunk* chunks;          // the whitening kernels' own chunk table (afx_capi.cpp, build_batch)
   int32_t n_bufs, n_chunks;
-  int32_t chunk_frames;         // frames per chunk (the last chunk of a buffer may be shorter)
+  int32_t chunk_frames;         // frames per chunk of the buffers that have several (their last chunk may be shorter)
+  int32_t need_follow;          // some buffer has more than one chunk: follow_kernel leaves the state at their starts
   uint32_t mask;                // AFX_D_* bits
   double* rec;
   RecordLayout lay;

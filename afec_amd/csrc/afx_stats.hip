@@ -265,12 +265,61 @@ __device__ void series_stats_long(const double* col, int64_t cstride, int n, int
 }
 
 // ---- short series (2 <= n <= 128 frames): one LANE per series ----
-// A wave takes 64 adjacent record columns of one buffer; frame p of all of them is one coalesced 512-byte
-// row.  The moments are plain sequential sums (the reference's own order), and the median needs no sort:
-// with less_i = #{j : x_j < x_i}, the element at sorted position t is max{x_i : less_i <= t}.  x_j comes
-// from an LDS copy of the tile so that j can be a run-time loop while x_i and less_i stay in registers.
+// A wave takes 64 consecutive series of the batch -- series s = buffer * stride + record column, so the lanes of a wave
+// may belong to two buffers with different frame counts: every lane has its own n -- and frame p of a buffer's
+// columns is one coalesced row.  The moments are plain sequential sums (the reference's own order).  The median of
+// series of up to 64 frames comes from a sorting network in the lane's registers (Batcher's odd-even merge sort: 543
+// min / max pairs for 64 values, slots behind n hold +inf), of longer ones from ranks: with less_i = #{j : x_j < x_i},
+// the element at sorted position t is max{x_i : less_i <= t}, x_j from the LDS copy of the tile.
 constexpr int kSmallMax = 128;     // longest series this kernel takes (64 KiB of LDS per wave)
-constexpr int kRankChunk = 64;     // x_i held in registers at a time
+constexpr int kRankChunk = 16;     // x_i held in registers at a time by the rank method
+constexpr int kNetwork = 64;       // series up to this length are sorted in registers
+
+// Batcher's odd-even merge sort on x[0 .. N), N a power of two, as compile-time recursion: every comparator is one
+// v_min_f64 + one v_max_f64 on two registers (ascending)
+template <int I, int J>
+__device__ __forceinline__ void net_compare(double (&x)[kNetwork]) {
+  const double a = x[I], b = x[J];
+  x[I] = fmin(a, b);
+  x[J] = fmax(a, b);
+}
+template <int I, int END, int R, int M>
+__device__ __forceinline__ void net_merge_row(double (&x)[kNetwork]) {
+  if constexpr (I + R < END) {
+    net_compare<I, I + R>(x);
+    net_merge_row<I + M, END, R, M>(x);
+  }
+}
+template <int LO, int N, int R>
+__device__ __forceinline__ void net_merge(double (&x)[kNetwork]) {
+  constexpr int M = 2 * R;
+  if constexpr (M < N) {
+    net_merge<LO, N, M>(x);
+    net_merge<LO + R, N, M>(x);
+    net_merge_row<LO + R, LO + N, R, M>(x);
+  } else {
+    net_compare<LO, LO + R>(x);
+  }
+}
+template <int LO, int N>
+__device__ __forceinline__ void net_sort(double (&x)[kNetwork]) {
+  if constexpr (N > 1) {
+    net_sort<LO, N / 2>(x);
+    net_sort<LO + N / 2, N / 2>(x);
+    net_merge<LO, N, 1>(x);
+  }
+}
+template <int N>
+__device__ __forceinline__ double network_median(const double* tile, int n, int target) {
+  double x[kNetwork];
+#pragma unroll
+  for (int i = 0; i < N; ++i) x[i] = (i < n) ? tile[64 * i] : __builtin_huge_val();
+  net_sort<0, N>(x);
+  double med = x[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) med = (target == i) ? x[i] : med;
+  return med;
+}
 
 // one wave per workgroup; the tile is small_rows x 64 doubles (small_rows = longest short series of the batch),
 // so a CU holds as many waves as fit its 160 KiB of LDS
@@ -278,36 +327,48 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
   extern __shared__ double tile_raw[];
   const int lane = threadIdx.x;
   double* const tile = tile_raw + lane;
-  const int groups = (a.stride + 63) / 64;
-  const int64_t total = (int64_t)a.n_bufs * groups;
+  const int64_t series = (int64_t)a.n_bufs * a.stride;
+  const int64_t total = (series + 63) / 64;
   for (int64_t w = blockIdx.x; w < total; w += gridDim.x) {
-    const int64_t buf = w / groups;
-    const int col = 64 * (int)(w - buf * groups) + lane;
+    const int64_t s = 64 * w + lane;
+    const int64_t buf = (s < series) ? s / a.stride : 0;
+    const int col = (int)(s - buf * a.stride);
     const int64_t f0 = a.frame_offset[buf];
     const int64_t nn = a.frame_offset[buf + 1] - f0;
-    if (nn < 2 || nn > kSmallMax) continue;               // other lengths: stats_kernel
-    const int n = (int)nn;
-    const bool active = col < a.stride;
+    const bool active = s < series && nn >= 2 && nn <= kSmallMax;     // other lengths: stats_kernel
+    const int n = active ? (int)nn : 0;
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    if (nmax == 0) continue;
     const double* const base = a.rec + f0 * a.stride + (active ? col : 0);
-    // the tile in LDS: frame p of this lane's series at tile[64 p]; slots past n hold -inf (they never win
-    // the median's max and are never visited by the run-time loops below)
+    // the tile in LDS: frame p of this lane's series at tile[64 p], zeros behind the lane's own n.  Rows are asked for
+    // sixteen at a time: one load per row waited for in turn was most of this kernel's time
     wave_lds_fence();
-    for (int p = 0; p < n; ++p) tile[64 * p] = base[(int64_t)p * a.stride];
-    for (int p = n; p < a.small_rows; ++p) tile[64 * p] = -__builtin_huge_val();
+    for (int p0 = 0; p0 < nmax; p0 += 16) {
+      double t[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t[k] = (p0 + k < n) ? base[(int64_t)(p0 + k) * a.stride] : 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k)
+        if (p0 + k < nmax) tile[64 * (p0 + k)] = t[k];
+    }
     wave_lds_fence();
     const double dn = (double)n;
     double mn = tile[0], mx = mn, sum = 0.0, sj = 0.0, slog = 0.0, sd = 0.0;
     {
       double v = tile[0];
 #pragma unroll 4
-      for (int p = 0; p < n; ++p) {
-        const double nxt = (p + 1 < n) ? tile[64 * (p + 1)] : v;
-        mn = fmin(mn, v);
-        mx = fmax(mx, v);
-        sum += v;
+      for (int p = 0; p < nmax; ++p) {
+        const bool ok = p < n, has_next = p + 1 < n;
+        const double nxt = (p + 1 < nmax) ? tile[64 * (p + 1)] : v;
+        mn = ok ? fmin(mn, v) : mn;
+        mx = ok ? fmax(mx, v) : mx;
+        sum += v;                                          // (zeros behind n)
         sj += (double)p * v;
-        slog += fast_log(fabs(v) + 1e-20);                 // GeometricMean, Statistics.cpp:417-455
-        sd += fabs(nxt - v);                               // the last term is |v - v| = 0
+        slog += ok ? fast_log(fabs(v) + 1e-20) : 0.0;      // GeometricMean, Statistics.cpp:417-455
+        sd += has_next ? fabs(nxt - v) : 0.0;
         v = nxt;
       }
     }
@@ -321,13 +382,13 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
     {
       double v = tile[0];
 #pragma unroll 4
-      for (int p = 0; p < n; ++p) {
-        const bool has_next = p + 1 < n;
-        const double nxt = has_next ? tile[64 * (p + 1)] : v;
+      for (int p = 0; p < nmax; ++p) {
+        const bool ok = p < n, has_next = p + 1 < n;
+        const double nxt = (p + 1 < nmax) ? tile[64 * (p + 1)] : v;
         const double t = v - mean;
-        var += t * t;
+        var += ok ? t * t : 0.0;
         const double u = (double)p - cen;
-        sv += u * u * v;
+        sv += u * u * v;                                   // (zeros behind n)
         const double wd = fabs(nxt - v) - dmean;
         dvar += has_next ? wd * wd : 0.0;
         v = nxt;
@@ -342,37 +403,42 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
       const bool on = fabs(spr) > (double)1e-12f;
       const double rspr = on ? 1.0 / spr : 0.0;
 #pragma unroll 4
-      for (int p = 0; p < n; ++p) {
+      for (int p = 0; p < nmax; ++p) {
         const double t = (tile[64 * p] - cen) * rspr;
         const double tt = t * t;
-        sk += tt * t;
-        ku += tt * tt;
+        sk += (p < n) ? tt * t : 0.0;
+        ku += (p < n) ? tt * tt : 0.0;
       }
       sk = on ? sk / dn : 0.0;
       ku = on ? ku / dn - 3.0 : 0.0;
     }
-    // median: element (n-1)/2 of the sorted series = max{x_i : #{j : x_j < x_i} <= (n-1)/2}; x_i in registers
-    // 64 at a time, x_j from the tile
+    // median: element (n-1)/2 of the sorted series (Statistics.cpp:316-413 selects the lower median)
     const int target = (n - 1) / 2;
     double med = mn;
-    for (int i0 = 0; i0 < n; i0 += kRankChunk) {
-      double x[kRankChunk];
-      int less[kRankChunk];
+    if (nmax <= 16) med = network_median<16>(tile, n, target);
+    else if (nmax <= 32) med = network_median<32>(tile, n, target);
+    else if (nmax <= kNetwork) med = network_median<kNetwork>(tile, n, target);
+    else {
+      // ranks: max{x_i : #{j : x_j < x_i} <= target}; x_i in registers sixteen at a time, x_j from the tile
+      for (int i0 = 0; i0 < nmax; i0 += kRankChunk) {
+        double x[kRankChunk];
+        int less[kRankChunk];
 #pragma unroll
-      for (int i = 0; i < kRankChunk; ++i) {
-        x[i] = (i0 + i < a.small_rows) ? tile[64 * (i0 + i)] : -__builtin_huge_val();
-        less[i] = 0;
+        for (int i = 0; i < kRankChunk; ++i) {
+          x[i] = (i0 + i < n) ? tile[64 * (i0 + i)] : -__builtin_huge_val();
+          less[i] = 0;
+        }
+        for (int j = 0; j < nmax; ++j) {
+          const double y = (j < n) ? tile[64 * j] : __builtin_huge_val();
+#pragma unroll
+          for (int i = 0; i < kRankChunk; ++i) less[i] += (y < x[i]) ? 1 : 0;
+        }
+#pragma unroll
+        for (int i = 0; i < kRankChunk; ++i) med = fmax(med, (less[i] <= target) ? x[i] : mn);
       }
-      for (int j = 0; j < n; ++j) {
-        const double y = tile[64 * j];
-#pragma unroll
-        for (int i = 0; i < kRankChunk; ++i) less[i] += (y < x[i]) ? 1 : 0;
-      }
-#pragma unroll
-      for (int i = 0; i < kRankChunk; ++i) med = fmax(med, (less[i] <= target) ? x[i] : mn);
     }
     if (active) {
-      double* const out = a.stats + (buf * a.stride + col) * 13;
+      double* const out = a.stats + s * 13;
       out[0] = mn; out[1] = mx; out[2] = med; out[3] = mean; out[4] = gmean; out[5] = var;
       out[6] = cen; out[7] = spr; out[8] = sk; out[9] = ku;
       out[10] = (mean == 0.0) ? 0.0 : gmean / mean;        // Flatness, Statistics.cpp:565-574
@@ -441,7 +507,7 @@ hipError_t launch_stats(const StatsArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) raised[dev] = true;
   }
-  const int64_t waves = (int64_t)a.n_bufs * ((a.stride + 63) / 64);
+  const int64_t waves = ((int64_t)a.n_bufs * a.stride + 63) / 64;
   hipLaunchKernelGGL(stats_small_kernel, dim3((unsigned)(waves < 16384 ? waves : 16384)), dim3(64), lds, stream, a);
   return hipGetLastError();
 }

@@ -162,6 +162,16 @@ __global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) e += x[i] * x[i];
       e = wave_sum(e);
+      if (a.amplitude) {   // CalcAmplitudePeak / CalcAmplitudeRms on the hop (SA:1760-1783), for the half-wave magnitude class
+        double peak = 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) peak = fmax(peak, fabs(x[i]));
+        peak = wave_max(peak);
+        if (lane == 0) {
+          if ((a.amplitude & (1u << 11)) && a.lay.amp_peak >= 0) rec[a.lay.amp_peak] = peak;
+          if ((a.amplitude & (1u << 12)) && a.lay.amp_rms >= 0) rec[a.lay.amp_rms] = nan_to_zero(sqrt(e / (double)kHop));
+        }
+      }
 
       double loc[16], env = 0.0;
 #pragma unroll

@@ -3,7 +3,8 @@
 // The follower of the adaptive whitening is the only state that crosses frames (SampleAnalyser.cpp (SA)
 // 805-809, 849-858).  follow_kernel runs that recurrence alone -- one wave per (buffer, 64 bins), frames in
 // order -- and leaves the follower at every chunk start; whiten_kernel then takes one chunk of consecutive
-// frames per wave and does, per frame:
+// frames per wave (its own chunk table: in batches of thousands of short files a chunk is a whole file, which starts
+// from the reset state and needs no follow_kernel at all) and does, per frame:
 //
 //   adaptive whitening   aubio_spectral_whitening_do, Aubio spectral/awhitening.c:41-51
 //   peak spectrum        SCreatePeakSpectrum, SA:95-123 -> TStatistics::Peaks, Statistics.cpp:140-232
@@ -52,6 +53,7 @@ __global__ __launch_bounds__(256) void follow_kernel(const WhitenArgs a) {
   constexpr int kAhead = 32;
   for (int64_t w = wave_global; w < (int64_t)a.n_bufs * 16; w += wave_stride) {
     const int b = (int)(w >> 4), k = 64 * (int)(w & 15) + lane;
+    if (a.chunk_first[b + 1] - a.chunk_first[b] <= 1) continue;   // a buffer that is one chunk starts from the reset state
     const int64_t f_begin = a.frame_offset[b], n = a.frame_offset[b + 1] - f_begin;
     const double* const col = a.mag + f_begin * kHalf + k;
     double* const save = a.follower + (int64_t)a.chunk_first[b] * kHalf + k;
@@ -91,7 +93,12 @@ __global__ __launch_bounds__(256) void whiten_kernel(const WhitenArgs a) {
     const Chunk ch = a.chunks[ci];
     const int64_t f_begin = ch.frame0, f_end = f_begin + ch.nframes;
     double follow[16];
-    if (want_cplx) load_bins(a.follower + (int64_t)ci * kHalf + 16 * lane, follow);
+    if (want_cplx) {
+      if (ch.flags & kChunkFirstOfBuffer) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) follow[i] = a.floor_value;     // aubio_spectral_whitening_reset
+      } else load_bins(a.follower + (int64_t)ci * kHalf + 16 * lane, follow);
+    }
     double m[16];
     if ((want_cplx || want_f0) && f_begin < f_end) load_bins(a.mag + f_begin * kHalf + 16 * lane, m);
     for (int64_t f = f_begin; f < f_end; ++f) {
@@ -178,7 +185,7 @@ __global__ __launch_bounds__(256) void whiten_kernel(const WhitenArgs a) {
 
 hipError_t launch_whiten(const WhitenArgs& a, hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
-  if (a.mask & AFX_D_SPECTRAL_COMPLEXITY) {
+  if ((a.mask & AFX_D_SPECTRAL_COMPLEXITY) && a.need_follow) {
     const int64_t want = ((int64_t)a.n_bufs * 16 + 3) / 4;
     hipLaunchKernelGGL(follow_kernel, dim3((unsigned)(want < 8192 ? want : 8192)), dim3(256), 0, stream, a);
     hipError_t e = hipGetLastError();

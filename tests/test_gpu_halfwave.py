@@ -180,3 +180,82 @@ def test_statistics_class_repeated_launches(forced):
     batch.close()
     for f in STAT_FIELDS:
         np.testing.assert_array_equal(again[f], first[f])
+
+
+# ---- the full class of the half-wave kernel: the statistics class + every magnitude stored (all mirrored blocks) + the
+#      amplitude of the hop; flux, the 28 spectrum bands and the sub-band descriptors from bands_kernel ----
+FULL_FIELDS = [f for f in FIELDS if f != "mag"]
+
+
+def check_full(got, ref_rows, what, rows=None):
+    for field in FULL_FIELDS:
+        if field not in got:
+            continue
+        a, b = FIELDS[field]
+        g = got[field] if rows is None else got[field][rows[0]:rows[1]]
+        _tol.check(field, g.reshape(ref_rows.shape[0], -1), ref_rows[:, a:b], *_tol.GPU_TOL[field], what=what)
+
+
+@pytest.mark.parametrize("name", golden_names())
+def test_golden_full_class(forced, name):
+    z = np.load(os.path.join(GOLD, "frames.npz"))
+    x, ref = z["in_" + name], z["ref_" + name]
+    x32 = x.astype(np.float32)
+    if not np.array_equal(x32.astype(np.float64), x):
+        ref = Oracle().run(x32.astype(np.float64))
+    got = forced.extract([x32], afx.D_ALL_LOW_LEVEL | afx.D_MAGNITUDE)
+    # ill-conditioned by construction (tests/test_gpu_parity.py): flux and the sub-band complexity /
+    # flux of an exactly flat spectrum
+    if name == "impulse":
+        got = {k: v for k, v in got.items() if k not in ("sub_complexity", "sub_flux", "spectral_flux")}
+    check_full(got, ref, name + " ")
+    _tol.check_mag(got["magnitude"].reshape(ref.shape[0], 1024), ref[:, :1024], what=name + " ")
+
+
+def test_full_class_ragged_batch_against_oracle_and_the_64_lane_kernel(forced, lanes64, oracle):
+    rng = np.random.default_rng(35)
+    lens = [0, 2048, 3072, 2048 + 1024 * 5, 2048 + 1024 * 33, 2048 + 1024 * 64, 2047, 2048 + 1024 * 31, 2048 + 1024 * 70]
+    bufs = [rng.uniform(-1, 1, n).astype(np.float32) for n in lens]
+    t = np.arange(lens[4])
+    bufs[4] = (0.5 * np.sin(2 * np.pi * 1000.0 * t / 44100) + 0.2 * np.sin(2 * np.pi * 7000.0 * t / 44100)).astype(np.float32)
+    bufs[5][:] = 0.0                                      # silence: every magnitude flushed to exactly 0
+    bufs[8] = (rng.standard_normal(lens[8]) * np.exp(-np.arange(lens[8]) / 9000.0)).astype(np.float32)
+    masks = (afx.D_ALL_LOW_LEVEL | afx.D_MAGNITUDE, afx.D_ALL_LOW_LEVEL, afx.D_MFCC | afx.D_SPECTRUM_BANDS,
+             afx.D_MFCC | afx.D_AMPLITUDE_PEAK | afx.D_AMPLITUDE_RMS, afx.D_MFCC | afx.D_SPECTRAL_FLUX | afx.D_SPECTRAL_ROLLOFF)
+    for mask in masks:
+        got = forced.extract(bufs, mask)
+        ref64 = lanes64.extract(bufs, mask)
+        assert got["frame_offset"].tolist() == ref64["frame_offset"].tolist()
+        off = got["frame_offset"]
+        for i, x in enumerate(bufs):
+            if off[i + 1] == off[i]:
+                continue
+            o = oracle.run(x.astype(np.float64))
+            check_full(got, o, f"mask {mask:#x} buffer {i} ", rows=(off[i], off[i + 1]))
+            if "magnitude" in got:
+                _tol.check_mag(got["magnitude"][off[i]:off[i + 1]].reshape(-1, 1024), o[:, :1024], what=f"buffer {i} ")
+        if "magnitude" in got:
+            silent = got["magnitude"][off[5]:off[6]]
+            assert silent.size > 0 and np.all(silent == 0.0)           # flushed, not sqrt(DBL_MIN)
+        for field in ("spectral_rolloff", "sub_complexity", "amplitude_peak"):
+            if field in got:
+                assert np.array_equal(got[field], ref64[field]), field
+        if "spectrum_bands" in got:
+            # two FFT factorisations: equal to rounding relative to the frame's energy (leakage-floor bands carry the noise)
+            floor = 1e-24 * got["spectrum_bands"].reshape(-1, 28).sum(axis=1, keepdims=True)
+            g, r = got["spectrum_bands"].reshape(-1, 28), ref64["spectrum_bands"].reshape(-1, 28)
+            assert np.all(np.abs(g - r) <= 1e-9 * np.abs(r) + floor + 1e-300)
+
+
+def test_full_class_repeated_launches(forced):
+    rng = np.random.default_rng(39)
+    a = [rng.uniform(-1, 1, 2048 + 1024 * 150).astype(np.float32) for _ in range(5)]
+    first = forced.extract(a, afx.D_ALL_LOW_LEVEL)
+    batch = forced.batch(a, afx.D_ALL_LOW_LEVEL)
+    for _ in range(3):
+        batch.run()
+    batch.sync()
+    again = batch.fetch()
+    batch.close()
+    for f in FULL_FIELDS:
+        np.testing.assert_array_equal(again[f], first[f])

@@ -100,12 +100,15 @@ def test_pcie_inclusive_one_shot_rate_is_reported():
     plan.close()
 
 
-def test_large_call_is_split_internally_and_matches_small_calls():
-    """afx_extract_batch cuts calls of more than 2^19 frames into groups of buffers."""
+@pytest.mark.parametrize("kernel", ["wave64", "halfwave"])
+def test_large_call_is_split_internally_and_matches_small_calls(kernel):
+    """afx_extract_batch cuts calls of more than 2^19 frames into groups of buffers: the same results, bit for bit, as
+    small calls on the same STFT kernel (the layout is pinned: by batch size a default plan would give the groups the
+    half-wave kernel and the small call the 64-lane one, which agree to rounding only)."""
     rng = np.random.default_rng(44)
     base = [rng.uniform(-1, 1, 2048 + 1024 * int(n)).astype(np.float32) for n in (700, 1, 859, 300, 0, 512)]
     bufs = [base[i % len(base)] for i in range(1400)] + [np.zeros(10, np.float32)]   # ~550k frames
-    plan = afx.Plan()
+    plan = afx.Plan(frame_kernel=afx.FRAME_KERNEL_WAVE64 if kernel == "wave64" else afx.FRAME_KERNEL_HALFWAVE)
     mask = afx.D_MFCC | afx.D_SPECTRAL_FLUX | afx.D_SPECTRAL_ROLLOFF
     big = plan.extract(bufs, mask)
     ref = plan.extract(base, mask)

@@ -133,6 +133,34 @@ __device__ __forceinline__ double spectrum_band_sums(const double (&x)[12], int 
   return mine;
 }
 
+// sqrt(denom2) of TStatistics::Correlation (Statistics.cpp:631-635): a product of two sums of squares that rounding
+// made negative gives NaN there, and here
+__device__ __forceinline__ double pearson_root(double denom2) {
+  return denom2 > 0.0 ? mag_sqrt(denom2) : __builtin_nan("");
+}
+
+// natural log for the geometric means of the bands (Statistics.cpp:417-455): the sum of up to 287 of these is divided by
+// the band's bin count and exponentiated, so 1e-13 absolute on one logarithm is far below what the descriptor resolves;
+// the atanh series of fast_log cut after z^7 / 15 (|s| <= 0.1716: the next term is 4e-14 s), the quotient by fast_div
+__device__ __forceinline__ double band_log(double x) {
+  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  int e = __builtin_amdgcn_frexp_exp(x);
+  const bool lowhalf = m < 0.70710678118654752440;
+  m = lowhalf ? m + m : m;
+  e = lowhalf ? e - 1 : e;
+  const double s = fast_div(m - 1.0, m + 1.0);
+  const double z = s * s;
+  double p = 1.0 / 15.0;
+  p = fma(p, z, 1.0 / 13.0);
+  p = fma(p, z, 1.0 / 11.0);
+  p = fma(p, z, 1.0 / 9.0);
+  p = fma(p, z, 1.0 / 7.0);
+  p = fma(p, z, 1.0 / 5.0);
+  p = fma(p, z, 1.0 / 3.0);
+  p = fma(p, z, 1.0);
+  return fma((double)e, 0.693147180559945309417, 2.0 * s * p);
+}
+
 // ---- 1024-slot bitonic sort of 32-bit keys, p = 16 lane + reg, every comparator ascending ----
 // ("flip" form: the first stage of a merge of size K pairs p with p ^ (K-1), the rest with p ^ J).
 // In-lane comparators are v_min_u32 / v_max_u32; cross-lane partners come through DPP where the
@@ -268,9 +296,21 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   __shared__ double s_thr[4][16];
   __shared__ u32 s_sorted[4][1024];
   __shared__ u32 s_cut[4][32];
+  __shared__ double s_cn[4][48];   // per band: 1 / bins, 1 / neighbours, bins
   double* const thr = s_thr[threadIdx.x >> 6];
   u32* const sorted = s_sorted[threadIdx.x >> 6];
   u32* const cut = s_cut[threadIdx.x >> 6];      // [0..15] valley cut key per band, [16..31] peak cut key
+  double* const cn = s_cn[threadIdx.x >> 6];
+  if (lane < 16) {
+    double nb = 1.0, nn = 1.0;
+#pragma unroll
+    for (int i = 0; i < kNumSub; ++i) {
+      nb = (lane == i) ? (double)kSubN[i] : nb;
+      nn = (lane == i) ? (double)kSubNeigh[i] : nn;
+    }
+    cn[lane] = 1.0 / nb; cn[16 + lane] = 1.0 / nn; cn[32 + lane] = nb;
+  }
+  wave_lds_fence();
 
   // lane-only facts, once per wave: membership masks of the (band, row) pairs, the band of each of the
   // lane's bins, the analysis-range masks of the first and last row
@@ -345,11 +385,13 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
         fa += p; faa += p * p; fab += p * y[r];     // y outside the range meets p = 0
       }
       fa = wave_sum(fa); faa = wave_sum(faa); fab = wave_sum(fab);
-      const double n = (double)kBinCount;
-      const double ma = fa / n, mb = fb / n;
+      // (x / 738 as x * (1 / 738), the quotient through fast_div and the root through mag_sqrt: each within an ulp of
+      // the generic expansions, which are three to five times the instructions)
+      const double n = (double)kBinCount, inv_n = 1.0 / (double)kBinCount;
+      const double ma = fa * inv_n, mb = fb * inv_n;
       const double denom2 = (faa - ma * ma * n) * (fbb - mb * mb * n);
       const double num = fab - (ma * mb * n);
-      if (lane_v == 0) a.rec[f * a.lay.stride + a.lay.flux] = (fabs(denom2) > (double)1e-12f) ? num / sqrt(denom2) : 0.0;
+      if (lane_v == 0) a.rec[f * a.lay.stride + a.lay.flux] = (fabs(denom2) > (double)1e-12f) ? fast_div(num, pearson_root(denom2)) : 0.0;
       fb = fa; fbb = faa;
     }
     if (!(a.flags & kBandsFeatures)) {
@@ -366,7 +408,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     // takes logs only when it leaves [1e-64, 1e64]; same value up to rounding)
     double lg[kRows];
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) lg[r] = fast_log(fabs(x[r]) + 1e-20);
+    for (int r = 0; r < kRows; ++r) lg[r] = band_log(fabs(x[r]) + 1e-20);
     const double slog = band_sum([&](int r) { return lg[r]; }, bm, lane_v);
     const double bmax = band_max([&](int r) { return x[r]; }, bm, lane_v);
 
@@ -455,27 +497,26 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     // ---- per-band results: every lane_v finishes the band (lane_v >> 2) & 15 ----
     const int b = (lane_v >> 2) & 15;
     const bool valid = b < kNumSub;
-    const int bb = valid ? b : 0;
-    double nb = 1.0, nn = 1.0;
-#pragma unroll
-    for (int i = 0; i < kNumSub; ++i) {
-      nb = (bb == i) ? (double)kSubN[i] : nb;
-      nn = (bb == i) ? (double)kSubNeigh[i] : nn;
-    }
+    // 1 / n and 1 / neighbours of this lane's band: from the wave's LDS table (a select chain per frame was 60 instructions)
+    const double nb = cn[2 * 16 + b], inv_nb = cn[b], inv_nn = cn[16 + b];
     const double cplx = (double)cnt;
-    const double mean = (nb >= 2.0) ? sx / nb : sx;                    // TStatistics::Mean
-    const double rms = sqrt(sxx / nb);                                 // SA:2154-2159
-    const double gm = fast_exp(slog / nb);                             // Statistics.cpp:442
-    const double fl = (mean == 0.0) ? 0.0 : gm / mean;                 // Statistics.cpp:565-574
-    double fdb = lin_to_db(fl) / -60.0;                                // SFlatnessDb, SA:129-133
+    // quotients by the band's bin count as products with its reciprocal, the others through fast_div (exact when the
+    // quotient is representable, one ulp otherwise), roots through mag_sqrt: the generic expansions of this stage were
+    // 17 divisions and 2 roots of ~25 instructions each
+    const double mean = sx * inv_nb;                                   // TStatistics::Mean (n >= 2 for every band)
+    const double rms = mag_sqrt(sxx * inv_nb);                         // SA:2154-2159
+    const double gm = fast_exp(slog * inv_nb);                         // Statistics.cpp:442
+    const double fl = (mean == 0.0) ? 0.0 : fast_div(gm, mean);        // Statistics.cpp:565-574
+    double fdb = lin_to_db(fl) * (-1.0 / 60.0);                        // SFlatnessDb, SA:129-133
     fdb = fdb < 1.0 ? fdb : 1.0;
-    const double ma = sx / nb, mb = sy / nb;                           // Statistics.cpp:604-638
+    const double ma = mean, mb = sy * inv_nb;                          // Statistics.cpp:604-638
     const double denom2 = (sxx - ma * ma * nb) * (syy - mb * mb * nb);
     const double num = sxy - (ma * mb * nb);
-    const double flux = (fabs(denom2) > (double)1e-12f) ? num / sqrt(denom2) : 0.0;
-    const double valley = vsum / nn + 1e-30, peakv = psum / nn + 1e-30;  // SA:2216, 2228
+    const double flux = (fabs(denom2) > (double)1e-12f) ? fast_div(num, pearson_root(denom2)) : 0.0;
+    const double valley = vsum * inv_nn + 1e-30, peakv = psum * inv_nn + 1e-30;  // SA:2216, 2228
     // pow(a, b) = exp(b log a), a > 0 (SA:2231-2232)
-    const double contrast = -1.0 * fast_exp(fast_log(peakv / valley) / fast_log(mean + 1e-30));
+    // (the exponent's quotient stays the generic one: a band mean of exactly 1.0 makes its denominator 0)
+    const double contrast = -1.0 * fast_exp(fast_log(fast_div(peakv, valley)) / fast_log(mean + 1e-30));
 
     double* const rec = a.rec + f * a.lay.stride;
     if (valid && (lane_v & 3) == 0) {

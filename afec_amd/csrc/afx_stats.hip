@@ -269,10 +269,8 @@ __device__ void series_stats_long(const double* col, int64_t cstride, int n, int
 // may belong to two buffers with different frame counts: every lane has its own n -- and frame p of a buffer's
 // columns is one coalesced row.  The moments are plain sequential sums (the reference's own order).  The median of
 // series of up to 64 frames comes from a sorting network in the lane's registers (Batcher's odd-even merge sort: 543
-// min / max pairs for 64 values, slots behind n hold +inf), of longer ones from ranks: with less_i = #{j : x_j < x_i},
-// the element at sorted position t is max{x_i : less_i <= t}, x_j from the LDS copy of the tile.
+// min / max pairs for 64 values, slots behind n hold +inf), of longer ones from two sorted halves and a bisection.
 constexpr int kSmallMax = 128;     // longest series this kernel takes (64 KiB of LDS per wave)
-constexpr int kRankChunk = 16;     // x_i held in registers at a time by the rank method
 constexpr int kNetwork = 64;       // series up to this length are sorted in registers
 
 // Batcher's odd-even merge sort on x[0 .. N), N a power of two, as compile-time recursion: every comparator is one
@@ -419,23 +417,41 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
     else if (nmax <= 32) med = network_median<32>(tile, n, target);
     else if (nmax <= kNetwork) med = network_median<kNetwork>(tile, n, target);
     else {
-      // ranks: max{x_i : #{j : x_j < x_i} <= target}; x_i in registers sixteen at a time, x_j from the tile
-      for (int i0 = 0; i0 < nmax; i0 += kRankChunk) {
-        double x[kRankChunk];
-        int less[kRankChunk];
+      // 65..128 frames: the two halves of the series are sorted by the same network, one after the other, and written
+      // back over the tile (nothing reads it in frame order any more); the element of rank `target` of their union is
+      // then found by bisection on how many elements the first half contributes (the classic selection from two sorted
+      // arrays): max(A[i - 1], B[target - i]) for the i with A[i - 1] <= B[target + 1 - i] and B[target - i] <= A[i]
+      {
+        double x[kNetwork];
 #pragma unroll
-        for (int i = 0; i < kRankChunk; ++i) {
-          x[i] = (i0 + i < n) ? tile[64 * (i0 + i)] : -__builtin_huge_val();
-          less[i] = 0;
-        }
-        for (int j = 0; j < nmax; ++j) {
-          const double y = (j < n) ? tile[64 * j] : __builtin_huge_val();
+        for (int i = 0; i < kNetwork; ++i) x[i] = (i < n) ? tile[64 * i] : __builtin_huge_val();
+        net_sort<0, kNetwork>(x);
+        wave_lds_fence();
 #pragma unroll
-          for (int i = 0; i < kRankChunk; ++i) less[i] += (y < x[i]) ? 1 : 0;
-        }
+        for (int i = 0; i < kNetwork; ++i) tile[64 * i] = x[i];
 #pragma unroll
-        for (int i = 0; i < kRankChunk; ++i) med = fmax(med, (less[i] <= target) ? x[i] : mn);
+        for (int i = 0; i < kNetwork; ++i) x[i] = (kNetwork + i < n) ? tile[64 * (kNetwork + i)] : __builtin_huge_val();
+        net_sort<0, kNetwork>(x);
+#pragma unroll
+        for (int i = 0; i < kNetwork; ++i)
+          if (kNetwork + i < nmax) tile[64 * (kNetwork + i)] = x[i];
+        wave_lds_fence();
       }
+      const int na = min(n, kNetwork), nb = max(n - kNetwork, 0);      // lengths of the sorted halves A, B
+      // i = elements of A among the target + 1 smallest: in [max(0, target + 1 - nb), min(target + 1, na)]
+      int lo = max(0, target + 1 - nb), hi = min(target + 1, na);
+      const double inf = __builtin_huge_val();
+      auto A = [&](int i) { return (i < 0) ? -inf : ((i >= na) ? inf : tile[64 * i]); };
+      auto B = [&](int j) { return (j < 0) ? -inf : ((j >= nb) ? inf : tile[64 * (kNetwork + j)]); };
+#pragma unroll 1
+      for (int it = 0; it < 8; ++it) {          // 2^7 >= 65 candidates; lanes that are done keep lo == hi
+        const int i = (lo + hi) >> 1, j = target + 1 - i;
+        // too few from A when B[j - 1] > A[i]
+        const bool more = lo < hi && B(j - 1) > A(i);
+        lo = more ? i + 1 : lo;
+        hi = more ? hi : i;
+      }
+      med = fmax(A(lo - 1), B(target - lo));
     }
     if (active) {
       double* const out = a.stats + s * 13;

@@ -7,7 +7,7 @@ timeout 900 python -m pytest ${TESTS:-tests/test_gpu_neighbours.py tests/test_gp
 if [ "${FULL:-0}" = "1" ]; then
   python tools/profile_config.py ${TAG:-c4} --workload c4 --mask ${MASK:-frame}
 else
-  cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-single --no-spot-check --no-side-stream --workload c4 --mask ${MASK:-frame} > /tmp/kt.log 2>&1
+  cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/kt && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -o k -- python3 $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-single --no-spot-check --no-side-stream --workload ${WORKLOAD:-c4} --mask ${MASK:-frame} > /tmp/kt.log 2>&1
   tail -c 300 /tmp/kt.log; echo
   python3 - <<'PY'
 import csv,glob

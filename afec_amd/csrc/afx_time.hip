@@ -26,7 +26,7 @@ namespace afx {
 namespace {
 
 constexpr int kTimeWaves = 8;
-constexpr int kPadSlots = 1088;                 // 1024 + 64 pads, >= kPlaneSlots
+constexpr int kPadSlots = 1344;                 // >= 1024 + 64 pads (blocked layouts), >= kPlaneSlots, >= two staged segments of 640 (acorr_kernel)
 constexpr int kTimePlaneBytes = kPadSlots * 8;
 // shared tables (t2, post: 16 KiB each; t1: 1 KiB -- from global memory its reads were three exposed cache round trips
 // per transform, the vector-memory path being what the frame's own loads wait on), then one plane per wave
@@ -255,6 +255,14 @@ __device__ __forceinline__ void even_odd(cx<double> z, cx<double> p, cx<double>&
 // ---------------------------------------------------------------------------------------------
 // auto_correlation (SA:2312-2398)
 // ---------------------------------------------------------------------------------------------
+// Two frames per pair of transforms.  TAutocorrelation::Calc (Autocorrelation.cpp:84-104) of a segment of w <= 529
+// samples is the inverse transform of its power spectrum.  With circular length N = 1024 the lags k <= N - w come out
+// clean (c[k] = r[k] + r[N - k], r[m] = 0 for m >= w); the few lags above that (k in [w - 32, w), at most 32 terms each)
+// are summed directly, and the one lag that can still be polluted (k = 496 for w = 529: its alias is r[528]) is
+// corrected with the directly summed value.  Two real sequences share one complex transform, z = a + i b:
+// 2 A[k] = Z[k] + conj(Z[N-k]), 2 B[k] = -i (Z[k] - conj(Z[N-k])), and since the power spectra are real and even,
+// the forward transform of |2A|^2 + i |2B|^2 is 4 N (r_a + i r_b).  (Before: each frame's zero-padded 2048-point real
+// transform and its inverse: two complex 1024-point transforms per frame instead of per pair.)
 template <typename TIn, bool SCALED>
 __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -264,136 +272,170 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
   const int wave_stride = gridDim.x * kTimeWaves;
   const TIn* const pcm = reinterpret_cast<const TIn*>(a.pcm);
   // TAudioMath::MsToSamples(44100, 0.8f) = 35, (44100, 12.0f) = 529 (float maths, AudioMath.inl:127-130)
-  constexpr int kMinPeriod = 35, kSeekWidth = 529, kMaxSeek = kFft / 2;
+  constexpr int kMinPeriod = 35, kSeekWidth = 529, kMaxSeek = kFft / 2, kN = 1024, kDirect = 32;
+  constexpr int kSeg = 640;           // staged samples per frame: rows start/64 .. start/64 + 9
+  constexpr double kScale = 1.0 / 4096.0;   // the transforms return 4 N r
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];
     const double sc = SCALED ? wave_uniform(ch.scale) : 1.0;
     const int remaining0 = a.remaining[ci];
-    // Everything the two searches and the correlation may touch -- samples 0 .. 2111 of the frame, as far as
-    // the buffer has them (the arena keeps up to 64 samples past the last frame; zeros behind it) -- is loaded in one
-    // go: a[q] = x[64 q + lane].  "x[p+1] > x[p]" is then one ballot per row -- the row against itself shifted by one
-    // lane (wave_shl:1), lane 63 against lane 0 of the next row -- and the first-index searches are scalar bit scans; no
-    // load depends on a search result.  The rows of frame fi + 1 are asked for as soon as frame fi has staged its
-    // segment: they travel while the two transforms run.
-    constexpr int kRowsHeld = 33;
-    TIn ra[kRowsHeld];
+    // Everything the two searches and the correlations of a pair of frames may touch -- samples 0 .. 3135 of the first
+    // frame, as far as the buffer has them (the arena keeps up to 64 samples past the last frame; zeros behind it) -- is
+    // loaded in one go: rw[q] = x[64 q + lane]; the second frame's rows are rw[16 ..].  "x[p+1] > x[p]" is one ballot
+    // per row -- the row against itself shifted by one lane (wave_shl:1), lane 63 against lane 0 of the next row -- and
+    // the first-index searches are scalar bit scans; no load depends on a search result.  The rows of the next pair are
+    // asked for as soon as this pair has staged its segments: they travel while the two transforms run.
+    constexpr int kRowsFrame = 33, kRowsPair = 49;
+    TIn rw[kRowsPair];
     auto load_rows = [&](int fi) {
       const TIn* const x = pcm + ch.sample_off + (int64_t)fi * kHop;
-      const int lim = min(remaining0 - fi * kHop, 64 * kRowsHeld);
+      const bool second = fi + 1 < ch.nframes;
+      // the second frame's row 32 ends its own limit; without a second frame the first frame's row 32 does
+      const int lim = min(remaining0 - fi * kHop, second ? kHop + 64 * kRowsFrame : 64 * kRowsFrame);
 #pragma unroll
-      for (int q = 0; q < kRowsHeld; ++q) {
+      for (int q = 0; q < kRowsPair; ++q) {
         const int p = 64 * q + lane;
-        ra[q] = (q < 32 || p < lim) ? x[p] : (TIn)0;
+        rw[q] = (q < 32 || p < lim) ? ((q < kRowsFrame || second) ? x[q < kRowsFrame || second ? p : 0] : (TIn)0) : (TIn)0;
       }
     };
-    // bit l of the result: x[64 q + l + 1] > x[64 q + l]
-    auto rising = [&](int q) -> mask64 {
-      const TIn next0 = (q + 1 < kRowsHeld) ? first_lane(ra[q + 1 < kRowsHeld ? q + 1 : q]) : (TIn)0;
-      return __ballot(next_lane(ra[q], next0) > ra[q]);
-    };
-    // (double PCM -- buffers a caller normalised itself -- would hold 66 registers of rows in flight: loaded per frame)
+    // (double PCM -- buffers a caller normalised itself -- would hold 98 registers of rows in flight: loaded per pair)
     constexpr bool kPrefetch = sizeof(TIn) == 4;
     if (kPrefetch) load_rows(0);
-    for (int fi = 0; fi < ch.nframes; ++fi) {
+    for (int fi = 0; fi < ch.nframes; fi += 2) {
       if (!kPrefetch) load_rows(fi);
-      int remaining = remaining0 - fi * kHop;          // mData.Size() - n, >= 2048 for an emitted frame
-      double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
-
-      // first rising step in [0, min(remaining, 1024) - 1)  (SA:2328-2341)
-      int start = 0;
-      {
-        const int bound = min(remaining, kMaxSeek) - 1;
-        bool found = false;
+      const bool have_b = fi + 1 < ch.nframes;
+      // per frame of the pair (s = 0, 1): the two searches and the segment; wave-uniform results
+      int start[2], period[2], width[2], from[2], off[2];
+      bool active[2];
+      wave_lds_fence();
 #pragma unroll
-        for (int q = 0; q < kMaxSeek / 64; ++q) {
-          if (!found && 64 * q < bound) {
-            mask64 m = rising(q);
-            const int valid = bound - 64 * q;
-            if (valid < 64) m &= ((mask64)1 << valid) - 1;
-            if (m) { start = 64 * q + __ffsll((long long)m) - 1; found = true; }
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int row0 = 16 * s2;                          // the frame's first row in rw
+        int remaining = remaining0 - (fi + s2) * kHop;     // mData.Size() - n, >= 2048 for an emitted frame
+        auto rising = [&](int q) -> mask64 {               // bit l: x[64 q + l + 1] > x[64 q + l] of this frame
+          const TIn next0 = (q + 1 < kRowsFrame) ? first_lane(rw[row0 + (q + 1 < kRowsFrame ? q + 1 : q)]) : (TIn)0;
+          return __ballot(next_lane(rw[row0 + q], next0) > rw[row0 + q]);
+        };
+        int st = 0;
+        if (s2 == 0 || have_b) {
+          // first rising step in [0, min(remaining, 1024) - 1)  (SA:2328-2341)
+          const int bound = min(remaining, kMaxSeek) - 1;
+          bool found = false;
+#pragma unroll
+          for (int q = 0; q < kMaxSeek / 64; ++q) {
+            if (!found && 64 * q < bound) {
+              mask64 m = rising(q);
+              const int valid = bound - 64 * q;
+              if (valid < 64) m &= ((mask64)1 << valid) - 1;
+              if (m) { st = 64 * q + __ffsll((long long)m) - 1; found = true; }
+            }
+          }
+          if (found) remaining -= st;
+        }
+        // next rising step after the minimum period (SA:2343-2356): positions [lo, hi) of the frame
+        const int seek_off = min(remaining, kMinPeriod);
+        int per = seek_off;
+        if (s2 == 0 || have_b) {
+          const int bound = min(remaining - seek_off, kMaxSeek) - 1;
+          const int lo = st + seek_off, hi = lo + bound;
+          bool found = false;
+#pragma unroll
+          for (int q = 0; q < kRowsFrame; ++q) {
+            if (!found && 64 * q + 63 >= lo && 64 * q < hi) {
+              mask64 m = rising(q);
+              if (64 * q < lo) m &= ~(((mask64)1 << (lo - 64 * q)) - 1);
+              if (hi - 64 * q < 64) m &= ((mask64)1 << (hi - 64 * q)) - 1;
+              if (m) { per = seek_off + (64 * q + __ffsll((long long)m) - 1 - lo); found = true; }
+            }
           }
         }
-        if (found) remaining -= start;
-      }
-      // next rising step after the minimum period (SA:2343-2356): positions [lo, hi) of the frame
-      const int seek_off = min(remaining, kMinPeriod);
-      int period = seek_off;
-      {
-        const int bound = min(remaining - seek_off, kMaxSeek) - 1;
-        const int lo = start + seek_off, hi = lo + bound;
-        bool found = false;
-#pragma unroll
-        for (int q = 0; q < kRowsHeld; ++q) {
-          if (!found && 64 * q + 63 >= lo && 64 * q < hi) {
-            mask64 m = rising(q);
-            if (64 * q < lo) m &= ~(((mask64)1 << (lo - 64 * q)) - 1);
-            if (hi - 64 * q < 64) m &= ((mask64)1 << (hi - 64 * q)) - 1;
-            if (m) { period = seek_off + (64 * q + __ffsll((long long)m) - 1 - lo); found = true; }
-          }
-        }
-      }
-      double best = 0.0;
-      const bool active = remaining != 0 && period < remaining;
-      const int width = min(remaining, kSeekWidth);
-      const int q0 = start >> 6, off = start & 63;
-      if (active) {
-        // the segment x[start .. start + width) sits in rows start/64 .. start/64 + 9: through the plane
-        wave_lds_fence();
+        start[s2] = st; period[s2] = per;
+        active[s2] = (s2 == 0 || have_b) && remaining != 0 && per < remaining;
+        width[s2] = min(remaining, kSeekWidth);
+        from[s2] = per / 2;
+        off[s2] = st & 63;
+        // the segment x[start .. start + width) sits in rows start/64 .. start/64 + 9: through the plane (zeros for a
+        // frame that has no correlation: its half of the transform's input must be clean)
+        const int q0 = st >> 6;
+        double* const seg = c.plane_d + kSeg * s2;
 #pragma unroll
         for (int q = 0; q < 25; ++q)
-          if (q >= q0 && q < q0 + 10) c.plane_d[64 * (q - q0) + lane] = pcm_double<SCALED>(ra[q], sc);
-        wave_lds_fence();
+          if (q >= q0 && q < q0 + 10) seg[64 * (q - q0) + lane] = active[s2] ? pcm_double<SCALED>(rw[row0 + q], sc) : 0.0;
       }
-      // the rows are dead: the next frame's take their registers (the last frame of a chunk re-reads its own)
+      wave_lds_fence();
+      // the rows are dead: the next pair's take their registers (the last pair of a chunk re-reads its own)
       if (kPrefetch) {
         __builtin_amdgcn_sched_barrier(0);
-        load_rows(fi + 1 < ch.nframes ? fi + 1 : fi);
+        load_rows(fi + 2 < ch.nframes ? fi + 2 : fi);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (active) {
-        // r[i] = sum_j s[j] s[j+i] through the 2048-point transform of the zero-padded segment
+      double best[2] = {0.0, 0.0};
+      if (active[0] || active[1]) {
+        // ---- the lags the circular transform does not give cleanly, summed directly: lane l' = lane & 31 of half
+        //      s = lane >> 5 takes k = w - 32 + l' (32 - l' terms) ----
+        const int hs = lane >> 5, lp = lane & 31;
+        const int w_h = hs ? width[1] : width[0], off_h = hs ? off[1] : off[0];
+        const double* const seg_h = c.plane_d + kSeg * hs + off_h;
+        const int k_h = w_h - kDirect + lp;
+        double direct = 0.0;
+        {
+          const int kk = k_h >= 0 ? k_h : 0;
+#pragma unroll 8
+          for (int j = 0; j < kDirect; ++j) {
+            const double u = seg_h[j], v2 = seg_h[j + kk];     // (within the staged 640: off + 31 + 528 < 640)
+            direct = (j < kDirect - lp) ? fma(u, v2, direct) : direct;
+          }
+          if (k_h < 0) direct = 0.0;
+        }
+        // ---- z = a + i b, m = lane + 64 r (zero from w on) ----
         cx<double> v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int j = 2 * (64 * r + lane);
+          const int m = 64 * r + lane;
           v[r] = {0.0, 0.0};
-          if (r < 5) v[r] = {(j < width) ? c.plane_d[off + j] : 0.0, (j + 1 < width) ? c.plane_d[off + j + 1] : 0.0};
+          if (r < 9) v[r] = {(m < width[0]) ? c.plane_d[off[0] + m] : 0.0, (m < width[1]) ? c.plane_d[kSeg + off[1] + m] : 0.0};
         }
         wave_lds_fence();
         fft(v, c);
-        // power spectrum P[k] = |X[k]|^2, P[1024-k] = |E - w O|^2, then the packed spectrum of the inverse:
-        // Zc = Ec + i Oc, Ec = (P + P')/2, Oc = (P - P')/2 conj(w^k); constant factors dropped (r is used
-        // relative to r[0] only)
         cx<double> g[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const cx<double> p = partner_of(v, r, c);
           cx<double> e, o;
-          even_odd(v[r], p, e, o);
-          const cx<double> w = c.post[64 * r];
-          const cx<double> wo = cmul(w, o);
-          const double xr = e.re + wo.re, xi = e.im + wo.im, yr = e.re - wo.re, yi = e.im - wo.im;
-          const double pk = xr * xr + xi * xi, pp = yr * yr + yi * yi;
-          const double ec = pk + pp, h = pk - pp;
-          g[r] = {ec + h * w.im, -(h * w.re)};           // conj(Zc)
+          even_odd(v[r], p, e, o);                       // 2 A[k], 2 B[k]
+          g[r] = {e.re * e.re + e.im * e.im, o.re * o.re + o.im * o.im};
         }
         fft(g, c);
-        // r[2m] = Re F[m], r[2m+1] = -Im F[m], m = lane + 64 r
-        const double r0 = read_lane<0>(g[0].re);
-        double top = -1.0e300;
-        const int from = period / 2;
+        // g[r] = 4 N (r_a[m] + i r_b[m]), m = lane + 64 r
+        const double r0a = read_lane<0>(g[0].re) * kScale, r0b = read_lane<0>(g[0].im) * kScale;
+        // the alias of lag N - (w - 1) when that lag lies below the directly summed ones: r[w - 1], lane l' = 31's sum
+        const double last_a = read_lane<31>(direct), last_b = read_lane<63>(direct);
+        double top_a = -1.0e300, top_b = -1.0e300;
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-          const int j = 2 * (64 * r + lane);
-          if (j >= from && j < width) top = fmax(top, g[r].re);
-          if (j + 1 >= from && j + 1 < width) top = fmax(top, -g[r].im);
+        for (int r = 0; r < 9; ++r) {
+          const int m = 64 * r + lane;
+          const double ca = g[r].re * kScale - ((m == kN - (width[0] - 1)) ? last_a : 0.0);
+          const double cb = g[r].im * kScale - ((m == kN - (width[1] - 1)) ? last_b : 0.0);
+          if (m >= from[0] && m < width[0] - kDirect) top_a = fmax(top_a, ca);
+          if (m >= from[1] && m < width[1] - kDirect) top_b = fmax(top_b, cb);
         }
-        top = wave_max(top);
-        if (r0 != 0.0) top /= r0;                        // Autocorrelation.cpp:97-105
-        best = fmax(0.0, top);
+        // the directly summed lags of each half
+        const int from_h = hs ? from[1] : from[0];
+        const double dtop = (k_h >= 0 && k_h >= from_h) ? direct : -1.0e300;
+        top_a = fmax(top_a, hs ? -1.0e300 : dtop);
+        top_b = fmax(top_b, hs ? dtop : -1.0e300);
+        top_a = wave_max(top_a);
+        top_b = wave_max(top_b);
+        if (r0a != 0.0) top_a /= r0a;                    // Autocorrelation.cpp:97-105
+        if (r0b != 0.0) top_b /= r0b;
+        best[0] = active[0] ? fmax(0.0, top_a) : 0.0;
+        best[1] = active[1] ? fmax(0.0, top_b) : 0.0;
       }
-      if (lane == 0) rec[a.lay.autocorr] = best;
+      if (lane == 0) {
+        a.rec[((int64_t)ch.frame0 + fi) * a.lay.stride + a.lay.autocorr] = best[0];
+        if (have_b) a.rec[((int64_t)ch.frame0 + fi + 1) * a.lay.stride + a.lay.autocorr] = best[1];
+      }
     }
   }
 }

@@ -11,8 +11,8 @@
 //   rms, flatness(dB), flux      masked per-band sums, reduced 16 bands at a time (wave_sum16)
 //   complexity                   band maximum (wave_max16) -> threshold -> strict local maxima
 //   contrast                     "mean of the n lowest / highest bins of the band" (std::sort + two loops,
-//                                SA:2200-2228) as an exact selection: one 1024-slot bitonic sort in registers
-//                                on the 32-bit key (band << 27 | float bits >> 4) only finds, per band, the
+//                                SA:2200-2228) as an exact selection: bitonic sorts of blocks of 256 positions, in
+//                                registers, on the 32-bit key (band << 27 | float bits >> 4) only find, per band, the
 //                                key at the cut; the sums are then taken over the ORIGINAL doubles of the bins
 //                                whose key lies on the right side of the cut.  Bins whose keys tie with the
 //                                cut's (values equal to 19 mantissa bits) are all on one side in the common
@@ -297,10 +297,12 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   __shared__ u32 s_sorted[4][1024];
   __shared__ u32 s_cut[4][32];
   __shared__ double s_cn[4][48];   // per band: 1 / bins, 1 / neighbours, bins
+  __shared__ u32 s_sel[4][8];      // the cut keys of the two bands that lie across a block boundary of the sort
   double* const thr = s_thr[threadIdx.x >> 6];
   u32* const sorted = s_sorted[threadIdx.x >> 6];
   u32* const cut = s_cut[threadIdx.x >> 6];      // [0..15] valley cut key per band, [16..31] peak cut key
   double* const cn = s_cn[threadIdx.x >> 6];
+  u32* const sel = s_sel[threadIdx.x >> 6];
   if (lane < 16) {
     double nb = 1.0, nn = 1.0;
 #pragma unroll
@@ -440,15 +442,58 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     for (int i = 0; i < kNumSub; ++i) cnt = (((lane_v >> 2) & 15) == i) ? peaks[i] : cnt;
 
     // ---- contrast: sort (band, value) keys to find the key at each band's two cuts, then exact sums ----
+    // The keys go into bin order (position p = bin: lane p / 16, register p % 16) and each block of 256 positions is
+    // sorted on its own (the levels K <= 256 of the network pair positions of one block only): band is the major part of
+    // a key and the bands are runs of consecutive bins, so bands 0..10 and 12 come out sorted inside blocks 0 and 1; only
+    // band 11 (bins 221..316) and band 13 (465..751) lie across a block boundary, as two sorted runs each, and their four
+    // cut keys are order statistics of two sorted runs: a bisection.  The levels K = 512, 1024 of the full sort -- 11
+    // cross-lane and 8 in-lane stages, 830 of its 1 900 instructions -- are not run.
     u32 key[16];
+    wave_lds_fence();
 #pragma unroll
-    for (int r = 0; r < 16; ++r) key[r] = (r < kRows) ? sort_key(bid[r], x[r]) : 0x7FFFFFFFu;
-    sort_level<1024>(key, lane_v);
-    // sorted position p = 16 lane + i; band b sits at [pos0, pos0 + n): the nn lowest end at pos0 + nn - 1, the nn
-    // highest start at pos0 + n - nn
+    for (int r = 0; r < kRows; ++r) sorted[64 * r + lane_v] = sort_key(bid[r], x[r]);
+    wave_lds_fence();
+    {
+      const uint4* const mine = reinterpret_cast<const uint4*>(sorted + 16 * lane_v);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const uint4 q4 = mine[i];
+        key[4 * i] = q4.x; key[4 * i + 1] = q4.y; key[4 * i + 2] = q4.z; key[4 * i + 3] = q4.w;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) key[i] = (lane_v < 4 * kRows) ? key[i] : 0x7FFFFFFFu;   // positions 768..1023: nothing
+    }
+    sort_level<256>(key, lane_v);
     wave_lds_fence();
 #pragma unroll
     for (int i = 0; i < 16; ++i) sorted[16 * lane_v + i] = key[i];
+    wave_lds_fence();
+    // Where the bands sit now.  Block 0 = bins 0..255: bands 0..10 at [start - 1, ..) (bin 0, outside every band, has the
+    // largest key of the block: position 255), the first 35 bins of band 11 at [220, 255).  Block 1 = bins 256..511: the
+    // other 61 bins of band 11 at [256, 317), band 12 at [317, 465), the first 47 bins of band 13 at [465, 512).  Block 2:
+    // the other 240 bins of band 13 at [512, 752).
+    // lanes 16..23: the four cut keys (ranks nn - 1, nn, n - nn - 1, n - nn) of band 11 (lanes 16..19) and band 13 (20..23)
+    // by bisection over the two runs [a0, a0 + na), [b0, b0 + nb)
+    if (lane_v >= 16 && lane_v < 24) {
+      const bool b13 = lane_v >= 20;
+      const int a0 = b13 ? 465 : 220, na = b13 ? 47 : 35, b0 = b13 ? 512 : 256, nb = b13 ? 240 : 61;
+      const int n = na + nb, nn = b13 ? kSubNeigh[13] : kSubNeigh[11];
+      const int which = lane_v & 3;
+      const int t = (which == 0) ? nn - 1 : (which == 1 ? nn : (which == 2 ? n - nn - 1 : n - nn));
+      // i = elements of run A among the t + 1 smallest: the smallest i with B[t - i] <= A[i]
+      int lo = max(0, t + 1 - nb), hi = min(t + 1, na);
+      auto A = [&](int i) -> u32 { return (i < 0) ? 0u : ((i >= na) ? 0xFFFFFFFFu : sorted[a0 + (i < na ? i : 0)]); };
+      auto B = [&](int j) -> u32 { return (j < 0) ? 0u : ((j >= nb) ? 0xFFFFFFFFu : sorted[b0 + (j < nb ? j : 0)]); };
+#pragma unroll 1
+      for (int it = 0; it < 6; ++it) {          // 2^6 > 48 candidates
+        const int i = (lo + hi) >> 1;
+        const bool more = lo < hi && B(t - i) > A(i);
+        lo = more ? i + 1 : lo;
+        hi = more ? hi : i;
+      }
+      const u32 ka = A(lo - 1), kb = B(t - lo);
+      sel[lane_v - 16] = ka > kb ? ka : kb;
+    }
     wave_lds_fence();
     mask64 ties_v, ties_p;   // bands whose cut goes through a class of equal keys
     {
@@ -456,11 +501,18 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       int pv = 0, pp = 1;
 #pragma unroll
       for (int i = 0; i < kNumSub; ++i) {
-        pv = (bl == i) ? sub_pos0(i) + kSubNeigh[i] - 1 : pv;
-        pp = (bl == i) ? sub_pos0(i) + kSubN[i] - kSubNeigh[i] : pp;
+        const int pos0 = (i == 12) ? kSubStart[12] : sub_pos0(i);
+        pv = (bl == i) ? pos0 + kSubNeigh[i] - 1 : pv;
+        pp = (bl == i) ? pos0 + kSubN[i] - kSubNeigh[i] : pp;
       }
       const bool band_lane = lane_v < kNumSub;
-      const u32 kv = sorted[pv], kv_next = sorted[pv + 1], kp = sorted[pp], kp_prev = sorted[pp - 1];
+      u32 kv = sorted[pv], kv_next = sorted[pv + 1], kp = sorted[pp], kp_prev = sorted[pp - 1];
+      const bool two_runs = bl == 11 || bl == 13;
+      const int s0 = (bl == 13) ? 4 : 0;
+      kv = two_runs ? sel[s0] : kv;
+      kv_next = two_runs ? sel[s0 + 1] : kv_next;
+      kp_prev = two_runs ? sel[s0 + 2] : kp_prev;
+      kp = two_runs ? sel[s0 + 3] : kp;
       // a bin outside every band (bid 15) meets cut keys 0 / ~0: never below the one, never above the other
       if (lane_v < 16) {
         cut[lane_v] = band_lane ? kv : 0u;

@@ -321,6 +321,8 @@ __device__ __forceinline__ double network_median(const double* tile, int n, int 
 
 // one wave per workgroup; the tile is small_rows x 64 doubles (small_rows = longest short series of the batch),
 // so a CU holds as many waves as fit its 160 KiB of LDS
+// (LONG: the batch has series of 65..128 frames; the variant without that path keeps 20 registers more for the rest)
+template <bool LONG>
 __global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
   extern __shared__ double tile_raw[];
   const int lane = threadIdx.x;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
     double med = mn;
     if (nmax <= 16) med = network_median<16>(tile, n, target);
     else if (nmax <= 32) med = network_median<32>(tile, n, target);
-    else if (nmax <= kNetwork) med = network_median<kNetwork>(tile, n, target);
+    else if (!LONG || nmax <= kNetwork) med = network_median<kNetwork>(tile, n, target);
     else {
       // 65..128 frames: the two halves of the series are sorted by the same network, one after the other, and written
       // back over the tile (nothing reads it in frame order any more); the element of rank `target` of their union is
@@ -519,12 +521,15 @@ hipError_t launch_stats(const StatsArgs& a, hipStream_t stream) {
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev < 0 || dev >= 16 || !raised[dev]) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(stats_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(stats_small_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(stats_small_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_max);
     if (e != hipSuccess) return e;
     if (dev >= 0 && dev < 16) raised[dev] = true;
   }
   const int64_t waves = ((int64_t)a.n_bufs * a.stride + 63) / 64;
-  hipLaunchKernelGGL(stats_small_kernel, dim3((unsigned)(waves < 16384 ? waves : 16384)), dim3(64), lds, stream, a);
+  if (a.small_rows > kNetwork) hipLaunchKernelGGL(stats_small_kernel<true>, dim3((unsigned)(waves < 16384 ? waves : 16384)), dim3(64), lds, stream, a);
+  else hipLaunchKernelGGL(stats_small_kernel<false>, dim3((unsigned)(waves < 16384 ? waves : 16384)), dim3(64), lds, stream, a);
   return hipGetLastError();
 }
 

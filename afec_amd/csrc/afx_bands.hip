@@ -73,6 +73,14 @@ __device__ __forceinline__ double keep_where(double v, mask64 m) {
   return __hiloint2double(hi, lo);
 }
 
+// v where the mask's bit is set, 1.0 elsewhere (factors of a product)
+__device__ __forceinline__ double keep_or_one(double v, mask64 m) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(v)), "s"(m));
+  asm("v_cndmask_b32_e64 %0, %3, %1, %2" : "=v"(hi) : "v"(__double2hiint(v)), "s"(m), "v"(0x3FF00000));
+  return __hiloint2double(hi, lo);
+}
+
 // per-band sum of one value per row; lane L receives the total of band (L >> 2) & 15
 template <typename F>
 __device__ __forceinline__ double band_sum(F value_of_row, const mask64 (&bm)[kSubPairs], int lane) {
@@ -298,11 +306,13 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   __shared__ u32 s_cut[4][32];
   __shared__ double s_cn[4][48];   // per band: 1 / bins, 1 / neighbours, bins
   __shared__ u32 s_sel[4][8];      // the cut keys of the two bands that lie across a block boundary of the sort
+  __shared__ double s_nat[4][64 * kRows];   // kBandsStats: the frame's bins in natural order for the rolloff walk
   double* const thr = s_thr[threadIdx.x >> 6];
   u32* const sorted = s_sorted[threadIdx.x >> 6];
   u32* const cut = s_cut[threadIdx.x >> 6];      // [0..15] valley cut key per band, [16..31] peak cut key
   double* const cn = s_cn[threadIdx.x >> 6];
   u32* const sel = s_sel[threadIdx.x >> 6];
+  double* const nat = s_nat[threadIdx.x >> 6];
   if (lane < 16) {
     double nb = 1.0, nn = 1.0;
 #pragma unroll
@@ -374,6 +384,66 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       const double mine = spectrum_band_sums(x, lane_v);
       const int b = 16 * (lane_v & 3) + (lane_v >> 2);
       if ((lane_v & 3) < 2 && b < kBandsHere) a.rec[f * a.lay.stride + a.lay.bands + b] = mine;
+    }
+    // ---- the raw sums of the spectral statistics over bins 1..738, j = bin - 1 (SA:1808-1915), for the half-wave
+    //      frame kernel's magnitude class: sum m, m^2, j m, j^2 m, m^3, m^4, sum log(m + 1e-20) and the rolloff count, as
+    //      its statistics class leaves them for stats32_finish_kernel (the stored magnitudes are flushed already) ----
+    if (a.flags & kBandsStats) {
+      double s1 = 0.0, s2 = 0.0, sj = 0.0, sjj = 0.0, s3 = 0.0, s4 = 0.0, prod = 1.0;
+      double jq = (double)(lane_v - 1);
+      double mrow[kRows];
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) {
+        const double m = (r == 0) ? keep_where(x[r], first_row_ok) : (r == kRows - 1 ? keep_where(x[r], last_row_ok) : x[r]);
+        mrow[r] = m;
+        const double m2 = m * m, jm = jq * m;
+        s1 += m;
+        s2 += m2;
+        sj += jm;
+        sjj = fma(jq, jm, sjj);
+        s3 = fma(m2, m, s3);
+        s4 = fma(m2, m2, s4);
+        // (bins outside the range: factor 1)
+        const double f = m + 1e-20;
+        prod *= (r == 0) ? keep_or_one(f, first_row_ok) : (r == kRows - 1 ? keep_or_one(f, last_row_ok) : f);
+        jq += 64.0;
+      }
+      double st[16];
+      st[0] = s1; st[1] = s2; st[2] = sj; st[3] = sjj; st[4] = s3; st[5] = s4; st[6] = fast_log(prod);
+#pragma unroll
+      for (int i = 7; i < 16; ++i) st[i] = 0.0;
+      const double red = wave_sum16(st, lane_v);          // lane L: st[(L >> 2) & 15]
+      double* const tmp = a.stat_tmp + f * kStatTmp;
+      if ((lane_v & 3) == 0 && (lane_v >> 2) < 7) tmp[lane_v >> 2] = red;
+      // rolloff (scalar.c:472-492): bins whose running sum stays below 85 % of the total: natural-order copy in LDS, each
+      // lane walks 12 consecutive bins
+      const double total = read_lane<0>(red);
+      wave_lds_fence();
+#pragma unroll
+      for (int r = 0; r < kRows; ++r) nat[64 * r + lane_v] = mrow[r];
+      wave_lds_fence();
+      double seg[12], segsum = 0.0;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const int k = kFirstBin + 12 * lane_v + i;
+        seg[i] = (k <= kLastBin) ? nat[k < 64 * kRows ? k : 0] : 0.0;
+        segsum += seg[i];
+      }
+      const double incl = wave_scan_incl(segsum, lane_v);
+      double run = incl - segsum;
+      const double pivot = total * (85.0f / 100.0);
+      int below = 0;
+#pragma unroll
+      for (int i = 0; i < 12; ++i) {
+        const int k = kFirstBin + 12 * lane_v + i;
+        run += seg[i];
+        below += (k <= kLastBin && run < pivot) ? 1 : 0;
+      }
+      below = wave_sum_i(below);
+      int cnt = (pivot > 0.0) ? below + 1 : 0;
+      if (cnt > kBinCount) cnt = kBinCount;
+      if (lane_v == 0) tmp[7] = (double)cnt;
+      wave_lds_fence();
     }
     if (!(a.flags & (kBandsFeatures | kBandsFlux))) continue;
 

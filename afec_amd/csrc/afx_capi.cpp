@@ -549,6 +549,9 @@ uint32_t frames_mask(uint32_t mask) {
   if (mask & kNeedsMagnitudes) m |= AFX_D_MAGNITUDE;
   // who reads bins above 768 of the stored magnitudes: the caller (AFX_D_MAGNITUDE) and the whitening kernels
   if (mask & (AFX_D_MAGNITUDE | AFX_D_SPECTRAL_COMPLEXITY | AFX_D_F0)) m |= afx::kFramesWholeSpectrum;
+  // bands_kernel runs for this mask anyway and the spectral statistics are wanted: on the half-wave layout it takes them
+  // from the stored magnitudes (seven sums more over rows it holds), the frame kernel only stores (magnitude class)
+  if ((mask & 0xFEu) && (mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX | AFX_D_SPECTRUM_BANDS))) m |= afx::kFramesStatsLater;
   return m;
 }
 
@@ -823,13 +826,22 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   if (b->halfwave && afx::frames32_class(fmask) >= 2) b->mag_wanted = true;
   const int waves_per_block = b->halfwave ? afx::frames32_waves_per_block() : afx::frames_waves_per_block(fmask);
   const int64_t slots = (int64_t)plan->cu_count * waves_per_block * (b->halfwave ? 2 : 1);
+  // what a chunk costs before its first frame, in frames: the 64-lane kernel loads one hop; the half-wave kernel loads
+  // the overlap rows and the window table and starts its hop DMA (measured on the C4 share, profiles/r04)
+  constexpr double kHalfwavePrologue = 0.5;
   int K = 32;
   {
     double best = 1e300;
     for (int k = 1; k <= 32; ++k) {
       int64_t nchunks = 0;
       for (int i = 0; i < n_bufs; ++i) nchunks += (b->frame_offset[i + 1] - b->frame_offset[i] + k - 1) / k;
-      const double cost = (double)((nchunks + slots - 1) / slots) * (k + 0.5);
+#if defined(AFX_X_TUNE)   // timing experiments only (never the shipped library)
+      static const double x_prologue = std::getenv("AFX_X_PROLOGUE") ? std::atof(std::getenv("AFX_X_PROLOGUE")) : -1.0;
+      const double prologue = x_prologue >= 0.0 ? x_prologue : (b->halfwave ? kHalfwavePrologue : 0.5);
+#else
+      const double prologue = b->halfwave ? kHalfwavePrologue : 0.5;
+#endif
+      const double cost = (double)((nchunks + slots - 1) / slots) * (k + prologue);
       if (cost < best - 1e-9 || (std::fabs(cost - best) <= 1e-9 && k > K)) { best = cost; K = k; }
     }
   }
@@ -1591,12 +1603,20 @@ int afx_batch_run(afx_batch* b) {
   }
   // the half-wave full class leaves the 28 spectrum bands to bands_kernel (it stores the magnitudes for it)
   const bool bands28_later = b->halfwave && (b->mask & AFX_D_SPECTRUM_BANDS);
+  // ... and its magnitude class the spectral statistics
+  const bool stats_later = b->halfwave && afx::frames32_class(frames_mask(b->mask)) == 4;
   if ((b->mask & (AFX_D_BAND_FEATURES | AFX_D_SPECTRAL_FLUX)) || bands28_later) {
     afx::BandArgs ba{};
     ba.mag = b->d_mag; ba.chunks = b->d_chunks; ba.n_chunks = b->n_chunks; ba.rec = b->d_rec; ba.lay = b->lay;
     ba.flags = ((b->mask & AFX_D_BAND_FEATURES) ? afx::kBandsFeatures : 0) | ((b->mask & AFX_D_SPECTRAL_FLUX) ? afx::kBandsFlux : 0) |
-               (bands28_later ? afx::kBandsSpectrum : 0);
+               (bands28_later ? afx::kBandsSpectrum : 0) | (stats_later ? afx::kBandsStats : 0);
+    ba.stat_tmp = b->d_stat_tmp;
     HIP_TRY(afx::launch_bands(ba, b->stream));
+    if (stats_later) {
+      afx::FrameArgs fa{};
+      fa.mask = frames_mask(b->mask); fa.rec = b->d_rec; fa.lay = b->lay; fa.stat_tmp = b->d_stat_tmp;
+      HIP_TRY(afx::launch_stats32_finish(fa, b->stream, b->total_frames));
+    }
   }
   // the half-wave full classes leave the amplitude of the hop to hop_kernel
   const uint32_t post_amplitude = (b->halfwave && afx::frames32_class(frames_mask(b->mask)) >= 2) ? (b->mask & (AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS)) : 0u;

@@ -39,7 +39,6 @@ constexpr int kPlane32Bytes = 2 * kHalfSlots * 8;     // 16 896 per wave
 constexpr int kWaves32 = 8;
 // raw sums per frame the statistics / full classes leave for stats32_finish_kernel: sum m, m^2, j m, j^2 m, m^3, m^4,
 // sum log(m + 1e-20), rolloff count, sum x^2 of the hop, max |x| of the hop
-constexpr int kStatTmp = 10;
 
 template <int POST_ROWS>
 struct Lds32 {
@@ -224,14 +223,23 @@ __device__ __forceinline__ void finish_mfcc32(double acc, double*& recp, int& le
 
 template <int FEAT, bool SCALED>
 __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs a) {
-  constexpr bool PAIRS = (FEAT >= 1);
+  // FEAT 4 ("magnitude" class, for the same masks when bands_kernel runs anyway: flux, spectrum bands or sub-band
+  // descriptors are wanted): the MFCC class that also leaves the whole magnitude spectrum in a.mag_out -- every row
+  // untangled in pairs, bins 0..511 from the direct halves, 513..1023 from the mirrored ones, flushed like the
+  // reference's -- plus the two spectrum bands above bin 737.  It keeps no sums across rows: the spectral statistics
+  // are bands_kernel's (seven sums more in a kernel that has the rows in its registers anyway), the amplitude of the
+  // hop hop_kernel's.  The statistics of the full classes cost this kernel 250-300 bytes of scratch per lane and more
+  // than half of its time.
+  constexpr bool MAGS = (FEAT == 4);
+  constexpr bool STATS = (FEAT >= 1 && FEAT <= 3);
+  constexpr bool PAIRS = STATS;
   // FEAT 2, 3 ("full" classes, for masks with flux / spectrum bands / sub-band descriptors / amplitude): the statistics
   // class that also leaves the magnitudes in a.mag_out for bands_kernel and the whitening kernels, the amplitude peak /
   // rms of the hop (SA:1760-1783) and the two spectrum bands above the analysis range (bins 738..904, 905..1023: sums
   // of |X|^2 straight from the mirrored halves of rows 0..8, no square root).  FEAT 2 stores what the statistics class
   // computes anyway: bins 0..768, all bands_kernel reads.  FEAT 3 also produces and stores the mirrored blocks of rows
   // 0..7 (bins 769..1023): the whole spectrum, for the whitening follower / fail-safe f0 and the magnitude output.
-  constexpr bool STORE = (FEAT >= 2);
+  constexpr bool STORE = (FEAT == 2 || FEAT == 3);
   constexpr bool UPPER = (FEAT == 3);
   // rows of 32 bins that are untangled directly: bins 0..383 for the mel filters, 0..511 (+ their mirrored blocks) for
   // the spectral statistics
@@ -457,7 +465,22 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         return a.mag_out + mrow * 1024 + (ql & 31);          // + 32 r: bin 32 r + q;  + 1024 - 2 q - 32 r: bin 1024 - 32 r - q
       };
       double band26 = 0.0, band27 = 0.0;   // full classes: sums of |X|^2 over bins 738..904 and 905..1023 (spectrum bands 26, 27)
-      if (FEAT >= 1) {
+      // magnitude class: the two pointers of this half's row (+ 32 r: bin 32 r + q; - 32 r: bin 1024 - 32 r - q), rebuilt
+      // before every group of rows, and the store that flushes like TAudioMath::Magnitude under DAZ + FZ
+      double* rowd = nullptr;
+      double* rowm = nullptr;
+      auto mag_rows = [&]() {
+        rowd = mag_row();
+        int ql = lane;
+        asm volatile("" : "+v"(ql));
+        rowm = rowd + 1024 - 2 * (ql & 31);
+      };
+#if defined(AFX_X_NOSTORE)   // timing experiment only (never the shipped library): what the magnitude stores cost
+      auto store_mag = [&](double* p, double value) { asm volatile("" :: "v"(p), "v"(value)); };
+#else
+      auto store_mag = [&](double* p, double value) { *p = value > logc[kCSqrtMin] ? value : 0.0; };
+#endif
+      if (STATS) {
         int ql = lane;
         asm volatile("" : "+v"(ql));
         jq = (double)((ql & 31) - 1);
@@ -517,7 +540,23 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         }
         const double er = z.re + p.re, ei = z.im - p.im;   // E = Z + conj(P)
         const double orr = z.im + p.im, oi = p.re - z.re;  // O = -i (Z - conj(P))
-        if (PAIRS && (STORE || r >= 8)) {
+        if (MAGS) {
+          const double tr = fma(wq.x, orr, -wq.y * oi), ti = fma(wq.x, oi, wq.y * orr);   // w O
+          const double xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
+          const double md = mag_sqrt_mel(xr, xi, k_tiny, k_three);                        // |X[32 r + q]|
+          const double mv = mag_sqrt_mel(yr, yi, k_tiny, k_three);                        // |X[1024 - 32 r - q]|
+          if (r < kMel32Rows) park[32 * r + q] = md;    // rows 0..11 wait in LDS for the mel stage (no register to spare here)
+          store_mag(rowd + 32 * r, md);
+          if (!(r == 0 && q == 0)) store_mag(rowm - 32 * r, mv);                          // (row 0, lane 0 would be bin 1024)
+          // spectrum bands 26 = bins 738..904 and 27 = bins 905..1023 lie in the mirrored halves of rows 0..8
+          if (r <= 8) {
+            const double sq = fma(yi, yi, yr * yr);
+            if (r < 3) band27 += (r == 0 && q == 0) ? 0.0 : sq;
+            else if (r == 3) { band27 += (q <= 23) ? sq : 0.0; band26 += (q <= 23) ? 0.0 : sq; }
+            else if (r < 8) band26 += sq;
+            else band26 += (q <= 30) ? sq : 0.0;                                          // M_8 = bins 737..768
+          }
+        } else if (PAIRS && (STORE || r >= 8)) {
           const double tr = fma(wq.x, orr, -wq.y * oi), ti = fma(wq.x, oi, wq.y * orr);   // w O
           const double xr = er + tr, xi = ei + ti, yr = er - tr, yi = ei - ti;
           mag[r] = mag_sqrt_mel(xr, xi, k_tiny, k_three);
@@ -547,9 +586,30 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           const double xi = fma(wq.x, oi, fma(wq.y, orr, ei));
           mag[r] = mag_sqrt_mel(xr, xi, k_tiny, k_three);
         }
-        if (FEAT >= 1 && r >= kMel32Rows) accumulate(r, STORE ? mag_row() + 32 * r : nullptr);
+        if (STATS && r >= kMel32Rows) accumulate(r, STORE ? mag_row() + 32 * r : nullptr);
       };
-      if constexpr (FEAT >= 1) {
+      if constexpr (MAGS) {
+        // magnitude class: sixteen rows in pairs of two, one pair of fetches ahead (the paired form keeps more live per
+        // row than the other classes' and every value leaves at once: short groups keep the register file below its limit)
+        fetch(0); fetch(1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+          if (g < 7) { fetch(2 * g + 2); fetch(2 * g + 3); }
+          mag_rows();
+          untangle(2 * g);
+          untangle(2 * g + 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        // bin 512 = lane 0 of row 16 is its own partner: E = 2 Re Z, w O = -2i Im Z (the window carries the 1/2)
+        const double er = v[16].re + v[16].re, orr = v[16].im + v[16].im;
+        const double cm = mag_sqrt_mel(er, orr, k_tiny, k_three);
+        if (q == 0) store_mag(rowd + 512, cm);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < kMel32Rows; ++r) mag[r] = park[32 * r + q];
+        __builtin_amdgcn_sched_barrier(0);
+      } else if constexpr (STATS) {
         // statistics and full classes: rows in groups of two, one group of fetches ahead.  They keep eighteen doubles of sums
         // next to the FFT registers; with four rows in flight (as below) the allocator spilled 88 bytes per lane, with two 36,
         // and the shorter groups cost less than the spills did (285 -> 291 M frames/s on the star set).
@@ -586,7 +646,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       for (int r = 8; r < 12; ++r) untangle(r);
       __builtin_amdgcn_sched_barrier(0);
       }
-      if (FEAT >= 1) {   // statistics class: behind the last rows (62 registers in flight that it cannot spare earlier)
+      if (STATS || MAGS) {   // statistics / magnitude classes: behind the last rows (62 registers in flight that they cannot spare earlier)
 #pragma unroll
         for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
       }
@@ -604,7 +664,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
             if (mel32_touches(f, r)) e[f] += mag[r] * mwt[mel32_pair_index(r, f)];
         __builtin_amdgcn_sched_barrier(0);
         AFX_STAMP(7);   // mel rows (waits for the table loads)
-        if (FEAT >= 1) {
+        if (STATS) {
           // statistics class: the mel sums are reduced first (their registers are needed), then rows 12..15 and their mirrors
           const double tot1 = half_sum16(e, lane);
           if ((lane & 1) == (fi & 1)) mel_acc = tot1;
@@ -651,16 +711,27 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         }
         // the next frame's window pairs, under the reduction and the log / DCT (statistics class: behind its sums,
         // which need the registers)
-        if (FEAT == 0) {
+        if (FEAT == 0 || MAGS) {
 #pragma unroll
           for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
         }
-        if (FEAT == 0) {
+        if (FEAT == 0 || MAGS) {
+          if (MAGS) {   // the two free slots of the reduction: spectrum bands 26, 27 (x 4: the window carries an extra 1/2)
+            e[14] = 4.0 * band26;
+            e[15] = 4.0 * band27;
+          }
           const double tot = half_sum16(e, lane);  // lane L: filter (L & 31) >> 1 of this half's frame
           if ((lane & 1) == (fi & 1)) mel_acc = tot;
+          if (MAGS) {
+            int ql = lane;
+            asm volatile("" : "+v"(ql));
+            const int hq = ql & 31;
+            double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
+            if (fi < nfr && a.lay.bands >= 0 && (hq == 28 || hq == 30)) rec[a.lay.bands + 26 + ((hq - 28) >> 1)] = tot;
+          }
         }
         AFX_STAMP(8);   // window issue + reduction
-        if (FEAT >= 1) {
+        if (STATS) {
           // ---- spectral statistics (SA:1808-1933): the sums of this half's frame, reduced over its 32 lanes; the
           //      closed forms (sqrt, divisions, exp / log of the flatness) are left to stats32_finish_kernel ----
           int ln = lane;
@@ -846,12 +917,15 @@ int frames32_stat_tmp_doubles() { return kStatTmp; }
 // full class: those plus the amplitude of the hop (bits 11, 12) and the stored magnitudes (bit 13) that bands_kernel
 // turns into flux, the 28 spectrum bands and the sub-band descriptors (bits 8..10)
 bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype) {
-  return (mask & 1u) && !(mask & ~(0x3FFFu | kFramesWholeSpectrum)) && precision == 0 && (pcm_dtype == kPcmF32 || pcm_dtype == kPcmScaledF32);
+  return (mask & 1u) && !(mask & ~(0x3FFFu | kFramesWholeSpectrum | kFramesStatsLater)) && precision == 0 && (pcm_dtype == kPcmF32 || pcm_dtype == kPcmScaledF32);
 }
-// 0 = MFCC only, 1 = + spectral statistics, 2 = full with bins 0..768 stored, 3 = full with the whole spectrum stored
+// 0 = MFCC only, 1 = + spectral statistics, 2 = full with bins 0..768 stored, 3 = full with the whole spectrum stored,
+// 4 = magnitude class (MFCC + the whole spectrum stored + spectrum bands 26 / 27; kFramesStatsLater: the spectral
+// statistics are taken from the stored magnitudes by bands_kernel, which runs for this mask anyway)
 int frames32_class(uint32_t mask) {
   if (mask == 1u) return 0;
   if (!(mask & ~0xFFu)) return 1;
+  if (mask & kFramesStatsLater) return 4;
   return (mask & kFramesWholeSpectrum) ? 3 : 2;
 }
 
@@ -878,6 +952,7 @@ hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stre
   if (a.n_chunks <= 0) return hipSuccess;
   const int cls = frames32_class(a.mask);
   if (cls == 0) return scaled ? launch_frames32_class<0, true>(a, grid_blocks, stream) : launch_frames32_class<0, false>(a, grid_blocks, stream);
+  if (cls == 4) return scaled ? launch_frames32_class<4, true>(a, grid_blocks, stream) : launch_frames32_class<4, false>(a, grid_blocks, stream);
   hipError_t e;
   if (scaled)
     e = (cls == 1) ? launch_frames32_class<1, true>(a, grid_blocks, stream)
@@ -886,6 +961,11 @@ hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stre
     e = (cls == 1) ? launch_frames32_class<1, false>(a, grid_blocks, stream)
                    : (cls == 2 ? launch_frames32_class<2, false>(a, grid_blocks, stream) : launch_frames32_class<3, false>(a, grid_blocks, stream));
   if (e != hipSuccess) return e;
+  return launch_stats32_finish(a, stream, total_frames);
+}
+
+hipError_t launch_stats32_finish(const FrameArgs& a, hipStream_t stream, int64_t total_frames) {
+  if (total_frames <= 0) return hipSuccess;
   hipLaunchKernelGGL(stats32_finish_kernel, dim3((unsigned)((total_frames + 255) / 256)), dim3(256), 0, stream, a, total_frames);
   return hipGetLastError();
 }

@@ -6,6 +6,12 @@
 
 namespace afx {
 constexpr uint32_t kFramesWholeSpectrum = 1u << 31;
+// internal bit of FrameArgs::mask: bands_kernel runs for this batch anyway and takes the spectral statistics (bits 1..7)
+// from the stored magnitudes; the half-wave frame kernel then only stores them (its magnitude class)
+constexpr uint32_t kFramesStatsLater = 1u << 30;
+// raw sums per frame the half-wave statistics classes (or bands_kernel for them) leave for stats32_finish_kernel: sum m,
+// m^2, j m, j^2 m, m^3, m^4, sum log(m + 1e-20), rolloff count (+ two spare slots)
+constexpr int kStatTmp = 10;
 
 // Geometry the kernels are specialised for: the only one the reference ever instantiates
 // (Crawler.cpp:41-43, 599-600): 44.1 kHz, 2048-sample frame, 1024 hop.
@@ -143,6 +149,8 @@ int frames_waves_per_block(uint32_t mask);    // waves (of 64 lanes) per workgro
 // half-wave kernels (afx_frames32.hip): a wave walks two chunks at a time, one per 32-lane half
 bool frames_use_halfwave(uint32_t mask, int precision, int pcm_dtype);
 hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stream, int64_t total_frames, bool scaled);
+// closed forms of the spectral statistics from the raw sums in FrameArgs::stat_tmp (after bands_kernel with kBandsStats)
+hipError_t launch_stats32_finish(const FrameArgs& a, hipStream_t stream, int64_t total_frames);
 int frames32_waves_per_block();
 int frames32_stat_tmp_doubles();
 int frames32_class(uint32_t frames_mask);   // 0 = MFCC only, 1 = + spectral statistics, 2 = full (bins 0..768 stored, amplitude), 3 = full, whole spectrum
@@ -157,9 +165,12 @@ struct BandArgs {
   int32_t n_chunks;
   double* rec;          // same per-frame records the frame kernel writes
   RecordLayout lay;
-  uint32_t flags;       // kBandsFeatures | kBandsFlux
+  uint32_t flags;       // kBands*
+  double* stat_tmp;     // kBandsStats: [F][frames32_stat_tmp_doubles()] raw sums per frame (as the half-wave statistics class leaves them)
 };
-enum { kBandsFeatures = 1, kBandsFlux = 2, kBandsSpectrum = 4 };   // kBandsSpectrum: the 28 "frequency_bands" (SA:2007-2048)
+// kBandsSpectrum: the 28 "frequency_bands" (SA:2007-2048); kBandsStats: the raw sums of the spectral statistics over bins
+// 1..738 (SA:1808-1915) into BandArgs::stat_tmp, for stats32_finish_kernel
+enum { kBandsFeatures = 1, kBandsFlux = 2, kBandsSpectrum = 4, kBandsStats = 8 };
 hipError_t launch_bands(const BandArgs& a, hipStream_t stream);
 
 // ---- neighbours of the spectral set ----

@@ -832,7 +832,11 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
   int K = 32;
   {
     double best = 1e300;
-    for (int k = 1; k <= 32; ++k) {
+    // (acorr_kernel transforms frames two at a time, frames 2 i and 2 i + 1 of a buffer as the real and imaginary part of
+    // one complex sequence: chunks of an even number of frames keep a frame's partner -- and with it the rounding of
+    // its result -- independent of how the batch was cut)
+    const int k_step = (mask & AFX_D_AUTO_CORRELATION) ? 2 : 1;
+    for (int k = k_step; k <= 32; k += k_step) {
       int64_t nchunks = 0;
       for (int i = 0; i < n_bufs; ++i) nchunks += (b->frame_offset[i + 1] - b->frame_offset[i] + k - 1) / k;
 #if defined(AFX_X_TUNE)   // timing experiments only (never the shipped library)
@@ -1537,7 +1541,7 @@ int afx_batch_get_info(const afx_batch* b, afx_batch_info* info) {
   if (!b || !info) return fail(AFX_ERR_INVALID_ARG, "null argument");
   const uint32_t fmask = frames_mask(b->mask);
   info->frame_kernel = b->halfwave ? AFX_FRAME_KERNEL_HALFWAVE : AFX_FRAME_KERNEL_WAVE64;
-  info->feature_class = afx::frames_feature_class(fmask);
+  info->feature_class = b->halfwave ? afx::frames32_class(fmask) : afx::frames_feature_class(fmask);
   info->pcm_kind = b->pcm_dtype;
   info->chunk_frames = b->chunk_frames;
   info->n_chunks = b->n_chunks;

@@ -390,13 +390,30 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
         }
         // ---- z = a + i b, m = lane + 64 r (zero from w on) ----
         cx<double> v[16];
+        double mxa = 0.0, mxb = 0.0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int m = 64 * r + lane;
           v[r] = {0.0, 0.0};
-          if (r < 9) v[r] = {(m < width[0]) ? c.plane_d[off[0] + m] : 0.0, (m < width[1]) ? c.plane_d[kSeg + off[1] + m] : 0.0};
+          if (r < 9) {
+            v[r] = {(m < width[0]) ? c.plane_d[off[0] + m] : 0.0, (m < width[1]) ? c.plane_d[kSeg + off[1] + m] : 0.0};
+            mxa = fmax(mxa, fabs(v[r].re));
+            mxb = fmax(mxb, fabs(v[r].im));
+          }
         }
         wave_lds_fence();
+        // The two frames share one complex transform, whose rounding errors are relative to the larger of the two: each
+        // segment is brought to [0.5, 1) by a power of two first (exact, and the result -- a ratio of two of its
+        // correlation values -- does not see it).  A segment of zeros has r[0] = 0 and the result 0
+        // (Autocorrelation.cpp:97-105), not rounding noise of its partner over rounding noise.
+        mxa = wave_max(mxa);
+        mxb = wave_max(mxb);
+        const bool live_a = active[0] && mxa > 0.0, live_b = active[1] && mxb > 0.0;
+        const double ua = ldexp(1.0, -__builtin_amdgcn_frexp_exp(mxa > 0.0 ? mxa : 1.0));
+        const double ub = ldexp(1.0, -__builtin_amdgcn_frexp_exp(mxb > 0.0 ? mxb : 1.0));
+#pragma unroll
+        for (int r = 0; r < 9; ++r) v[r] = {v[r].re * ua, v[r].im * ub};
+        direct *= hs ? ub * ub : ua * ua;
         fft(v, c);
         cx<double> g[16];
 #pragma unroll
@@ -429,8 +446,8 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
         top_b = wave_max(top_b);
         if (r0a != 0.0) top_a /= r0a;                    // Autocorrelation.cpp:97-105
         if (r0b != 0.0) top_b /= r0b;
-        best[0] = active[0] ? fmax(0.0, top_a) : 0.0;
-        best[1] = active[1] ? fmax(0.0, top_b) : 0.0;
+        best[0] = live_a ? fmax(0.0, top_a) : 0.0;
+        best[1] = live_b ? fmax(0.0, top_b) : 0.0;
       }
       if (lane == 0) {
         a.rec[((int64_t)ch.frame0 + fi) * a.lay.stride + a.lay.autocorr] = best[0];

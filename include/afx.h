@@ -265,7 +265,8 @@ void afx_batch_destroy(afx_batch* batch);
 typedef struct {
   int32_t frame_kernel;  /* AFX_FRAME_KERNEL_WAVE64 or AFX_FRAME_KERNEL_HALFWAVE */
   int32_t feature_class; /* of the STFT kernel: 0 = MFCC only, 1 = + spectral statistics, 2 = + spectrum bands /
-                            amplitude / stored magnitudes ("full")                                            */
+                            amplitude / stored magnitudes ("full"); half-wave kernel only: 3 = full with the whole
+                            spectrum stored, 4 = MFCC + the whole spectrum stored (statistics from the band kernel)  */
   int32_t pcm_kind;      /* 0 = float, 1 = double, 2 = float + one double scale per buffer (LoadSample front end) */
   int32_t chunk_frames;  /* frames per chunk (the unit of work of a wave / half-wave)                          */
   int32_t n_chunks;

@@ -217,3 +217,33 @@ def test_the_arena_behind_loadsample_holds_floats_and_one_scale_per_file():
         np.testing.assert_array_equal(res[field], res64[field], err_msg=field)
     again.close()
     plan.close()
+
+
+def test_large_batches_behind_loadsample_take_the_half_wave_frame_kernel():
+    """A batch of the crawl's size class (BASELINE configs[2]: a thousand two-second files) with every per-frame descriptor
+    runs its STFT on the half-wave kernel's magnitude class (MFCC + the stored spectrum; the statistics, flux and band
+    descriptors come from bands_kernel), a small one on the 64-lane kernel -- the crossover is measured
+    (tools/x_batchsize.py, profiles/r04); the results of the two agree to rounding (both against the oracle elsewhere)."""
+    rng = np.random.default_rng(12)
+    pool = [np.round(8000 * rng.uniform(-1, 1, 88200)).astype(np.int16) for _ in range(8)]
+    plan = afx.Plan()
+    mask = afx.D_ALL_PER_FRAME | afx.D_STATISTICS
+    big, _ = plan.batch_from_raw([(pool[i % 8], 1) for i in range(600)], mask)
+    small, _ = plan.batch_from_raw([(pool[i % 8], 1) for i in range(8)], mask)
+    bi, si = big.info(), small.info()
+    assert bi["pcm_kind"] == si["pcm_kind"] == 2
+    assert bi["frame_kernel"] == afx.FRAME_KERNEL_HALFWAVE and bi["feature_class"] == 4
+    assert si["frame_kernel"] == afx.FRAME_KERNEL_WAVE64 and si["feature_class"] == 2
+    big.run(); small.run()
+    rb, rs = big.fetch(), small.fetch()
+    nf = small.total_frames
+    assert big.total_frames == 75 * nf
+    for field in rs:
+        if field in ("frame_offset", "buf_status"):
+            continue
+        a, b = rb[field][:nf].astype(np.float64), rs[field].astype(np.float64)
+        scale = np.maximum(np.abs(b), 1e-9)
+        if field in ("sub_complexity", "spectral_complexity", "sub_flux", "spectral_flux", "f0", "failsafe_f0", "f0_confidence"):
+            continue          # discrete / ill-conditioned on noise: compared with the oracle's tolerances in their own tests
+        assert np.max(np.abs(a - b) / scale) < 1e-6, field
+    big.close(); small.close(); plan.close()

@@ -1630,7 +1630,10 @@ int afx_batch_run(afx_batch* b) {
     ta.pcm_dtype = b->pcm_dtype; ta.rec = b->d_rec; ta.lay = b->lay;
     ta.t1 = t.t1_f64; ta.t2 = t.t2_f64; ta.post = t.post_f64;
     ta.amplitude = post_amplitude;
-    if ((b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) || post_amplitude) HIP_TRY(afx::launch_hop(ta, b->stream));
+    // with f0 selected the pitch kernel has the hop's samples in registers anyway and writes its descriptors too
+    const bool want_hop = (b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) || post_amplitude;
+    ta.hop_here = (want_hop && (b->mask & AFX_D_F0)) ? 1u : 0u;
+    if (want_hop && !ta.hop_here) HIP_TRY(afx::launch_hop(ta, b->stream));
     if (b->mask & AFX_D_AUTO_CORRELATION) HIP_TRY(afx::launch_acorr(ta, b->stream));
     if (b->mask & AFX_D_F0) HIP_TRY(afx::launch_pitch(ta, b->stream));
   }

@@ -187,6 +187,7 @@ struct TimeArgs {
   const void* t2;
   const void* post;
   uint32_t amplitude;     // hop_kernel, for the half-wave full classes: AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS to write
+  uint32_t hop_here;      // pitch_kernel also writes the hop's descriptors (silence, envelope, amplitude): no hop_kernel launch
 };
 hipError_t launch_hop(const TimeArgs& a, hipStream_t stream);      // silence flag, envelope (+ amplitude peak / rms)
 hipError_t launch_acorr(const TimeArgs& a, hipStream_t stream);    // auto_correlation

@@ -30,7 +30,7 @@ constexpr int kPadSlots = 1344;                 // >= 1024 + 64 pads (blocked la
 constexpr int kTimePlaneBytes = kPadSlots * 8;
 // shared tables (t2, post: 16 KiB each; t1: 1 KiB -- from global memory its reads were three exposed cache round trips
 // per transform, the vector-memory path being what the frame's own loads wait on), then one plane per wave
-constexpr int kLdsT2 = 0, kLdsPost = 16384, kLdsT1 = 32768, kLdsPlanes = 32768 + 1024;
+constexpr int kLdsT2 = 0, kLdsPost = 16384, kLdsT1 = 32768, kLdsCpow = 32768 + 1024, kLdsPlanes = 32768 + 1024 + 256;
 constexpr int kTimeLdsBytes = kLdsPlanes + kTimeWaves * kTimePlaneBytes;
 
 __device__ __forceinline__ int pad_slot(int e) { return e + (e >> 4); }
@@ -130,6 +130,58 @@ __device__ __forceinline__ bool au_silent(double sum_sq, int n) {
   return sum_sq / (double)n < 1.5848931924611134e-05;
 }
 
+// The descriptors of a hop (the first 1024 samples of a frame) from its samples in the blocked layout, x[i] = sample
+// 16 lane + i, and their sum of squares e: the silence flag, the envelope maximum (TEnvelopeDetector kFast, reset per
+// frame: SA:1787-1804) and, when `amplitude` asks for them, CalcAmplitudePeak / CalcAmplitudeRms (SA:1760-1783).
+// env_i = in_i + c (env_{i-1} - in_i) is affine in env_{i-1} with slope c: a lane runs its 16 samples from 0, the carries
+// are an affine scan over the lanes (slope c^16), and env_i = local_i + c^(i+1) carry.
+__device__ __forceinline__ double hop_energy(const double (&x)[16]) {
+  double e = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) e += x[i] * x[i];
+  return wave_sum(e);
+}
+// cpow[i] = coef^i, i <= 16 (registers in hop_kernel, an LDS table in pitch_kernel)
+template <typename Pow>
+__device__ __forceinline__ void hop_descriptors(const double (&x)[16], double e, double coef, const Pow& cpow,
+                                                uint32_t amplitude, const RecordLayout& lay, double* rec, int lane) {
+  if (amplitude) {
+    double peak = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) peak = fmax(peak, fabs(x[i]));
+    peak = wave_max(peak);
+    if (lane == 0) {
+      if ((amplitude & (1u << 11)) && lay.amp_peak >= 0) rec[lay.amp_peak] = peak;
+      if ((amplitude & (1u << 12)) && lay.amp_rms >= 0) rec[lay.amp_rms] = nan_to_zero(sqrt(e / (double)kHop));
+    }
+  }
+  if (lay.silence < 0 && lay.envelope < 0) return;
+  double loc[16], env = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const double in = fabs(x[i]);
+    env = in + coef * (env - in);        // TEnvelopeDetector::Run, Envelopes.inl:14-18
+    loc[i] = env;
+  }
+  double carry = env, slope = cpow[16];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const double t = __shfl_up(carry, o);
+    if (lane >= o) carry = fma(slope, t, carry);
+    slope *= slope;
+  }
+  double in_carry = __shfl_up(carry, 1);
+  if (lane == 0) in_carry = 0.0;
+  double top = 0.0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) top = fmax(top, fma(cpow[i + 1], in_carry, loc[i]));
+  top = wave_max(top);
+  if (lane == 0) {
+    if (lay.silence >= 0) rec[lay.silence] = au_silent(e, kHop) ? 1.0 : 0.0;   // SA:865-868
+    if (lay.envelope >= 0) rec[lay.envelope] = top;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // hop kernel: silence flag + envelope maximum of the hop (first 1024 samples of the frame)
 // ---------------------------------------------------------------------------------------------
@@ -158,46 +210,7 @@ __global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
       scale16<SCALED>(x, sc);
       double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
 
-      double e = 0.0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) e += x[i] * x[i];
-      e = wave_sum(e);
-      if (a.amplitude) {   // CalcAmplitudePeak / CalcAmplitudeRms on the hop (SA:1760-1783), for the half-wave magnitude class
-        double peak = 0.0;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) peak = fmax(peak, fabs(x[i]));
-        peak = wave_max(peak);
-        if (lane == 0) {
-          if ((a.amplitude & (1u << 11)) && a.lay.amp_peak >= 0) rec[a.lay.amp_peak] = peak;
-          if ((a.amplitude & (1u << 12)) && a.lay.amp_rms >= 0) rec[a.lay.amp_rms] = nan_to_zero(sqrt(e / (double)kHop));
-        }
-      }
-
-      double loc[16], env = 0.0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const double in = fabs(x[i]);
-        env = in + coef * (env - in);        // TEnvelopeDetector::Run, Envelopes.inl:14-18
-        loc[i] = env;
-      }
-      double carry = env, slope = cpow[16];
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const double t = __shfl_up(carry, o);
-        if (lane >= o) carry = fma(slope, t, carry);
-        slope *= slope;
-      }
-      double in_carry = __shfl_up(carry, 1);
-      if (lane == 0) in_carry = 0.0;
-      double top = 0.0;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) top = fmax(top, fma(cpow[i + 1], in_carry, loc[i]));
-      top = wave_max(top);
-
-      if (lane == 0) {
-        if (a.lay.silence >= 0) rec[a.lay.silence] = au_silent(e, kHop) ? 1.0 : 0.0;   // SA:865-868
-        if (a.lay.envelope >= 0) rec[a.lay.envelope] = top;
-      }
+      hop_descriptors(x, hop_energy(x), coef, cpow, a.amplitude, a.lay, rec, lane);
     }
   }
 }
@@ -478,6 +491,15 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
   const TIn* const pcm = reinterpret_cast<const TIn*>(a.pcm);
   constexpr int W = kFft / 2;
   constexpr double kTol = 0.75;                 // MPitchTolerance, SA:62, 801
+  // TEnvelopeDetector(kFast, MEnvelopeTimeInMs = 8, rate): mCoef = pow(0.01, 1000 / (ms rate)), Envelopes.cpp:55-70; its
+  // powers in LDS (hop_descriptors)
+  const double env_coef = pow(0.01, 1000.0 / (8.0 * (double)kSampleRate));
+  double* const env_pow = reinterpret_cast<double*>(lds_raw + kLdsCpow);
+  if (a.hop_here && threadIdx.x == 0) {
+    double pw = 1.0;
+    for (int i = 0; i <= 16; ++i) { env_pow[i] = pw; pw *= env_coef; }
+  }
+  __syncthreads();
   constexpr int kBig = 1 << 30;
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
@@ -690,6 +712,15 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
         rec[a.lay.f0_conf] = conf;
         // hop silence (SA:865-868) parked in the fail-safe slot for afx_whiten.hip, which replaces it
         rec[a.lay.f0_safe] = au_silent(s0, kHop) ? 1.0 : 0.0;
+      }
+      // the hop's own descriptors (silence flag, envelope, amplitude: hop_kernel's, SA:865-872, 1760-1804): a batch that
+      // computes f0 does not launch a kernel and read the PCM from HBM once more for them; at the end of the frame, where
+      // few registers are live -- the samples are read again, from the cache this frame's loads left them in
+      if (a.hop_here) {
+        double xh[16];
+        load16(x + 16 * lane, xh);
+        scale16<SCALED>(xh, sc);
+        hop_descriptors(xh, hop_energy(xh), env_coef, env_pow, a.amplitude, a.lay, rec, lane);
       }
     }
   }

@@ -11,11 +11,11 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r03"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
-CLOCK_GHZ = 2.0    # in-kernel (s_memtime / s_memrealtime, stamps build) at steady state under the f64 load: 1.92-2.07 over boxes
-                   # (profiles/r03/clock_ramp.txt; 1.8-1.9 during the first ~30 ms from an idle GPU)
+CLOCK_GHZ = 2.0    # fallback when a profile has no GRBM_GUI_ACTIVE: in-kernel (s_memtime / s_memrealtime, stamps build) at steady
+                   # state under the f64 load: 1.92-2.07 over boxes (profiles/r03/clock_ramp.txt)
 LIMITER = {"c2_f64": "f64 VALU work; sustained clock 1.9-2.1 of 2.4 GHz under this f64 + LDS + HBM load; LDS ~70 % busy beside it"}
 
 os.makedirs(DST, exist_ok=True)
@@ -23,7 +23,7 @@ out = {"_comment": "Per bench configuration, from rocprofv3 passes on MI355X (to
                    f"profiles/{ROUND}/profile_<tag>.json): HBM bytes per frame = (2*FETCH_SIZE + WRITE_SIZE)*1024/frames (gfx950 "
                    "FETCH_SIZE half-count correction, calibrated for 16-B streaming reads only), VALU pipe cycles per frame = "
                    "4*SQ_ACTIVE_INST_VALU/frames summed over the kernels of one step (rhythm kernels on the batch's own stream: "
-                   "bench.py --no-side-stream), clock = in-kernel s_memtime/s_memrealtime of the stamps build under this load."}
+                   "bench.py --no-side-stream), clock = GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the same profiled run."}
 builds = set()
 for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
     builds.add(json.load(open(f)).get("build_info"))
@@ -40,7 +40,8 @@ for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
         "bytes_per_frame": d["per_frame"]["hbm_bytes"],
         "valu_cycles_per_frame": d["per_frame"]["valu_cycles"],
         "valu_instructions_per_frame": d["per_frame"]["valu_instructions"],
-        "clock_ghz": CLOCK_GHZ,
+        # the clock the counters themselves saw: GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the profiled run
+        "clock_ghz": round(d.get("clock_ghz_grbm") or CLOCK_GHZ, 3),
         "frames_profiled": d["frames_per_step"],
         "limiter": LIMITER.get(tag, "f64 VALU issue"),
         "kernels": kernels,
@@ -50,7 +51,8 @@ for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
     }
     shutil.copy(f, DST)
 for pat in ("*_kernel_stats.csv", "*_kernel_steady.csv", "*_pmc_summary.csv", "*_pmc.csv", "rhythm_report.md", "parity_report.md", "ubench_*.txt",
-            "bench_default.json", "pytest_gpu.log"):
+            "bench_default.json", "pytest_gpu.log", "*_pmc_kernels.csv", "single_buffer.txt", "kernel_choice_by_batch_size.txt",
+            "halfwave_classes_on_c4.txt", "e2e_cpu_accounting.txt", "shards8_busy_cpus.txt", "fuzz_*.log", "crawl_soak.log"):
     for f in glob.glob(os.path.join(SRC, pat)):
         shutil.copy(f, DST)
 json.dump(out, open(os.path.join(ROOT, "profiles", "kernel_profiles.json"), "w"), indent=1)

@@ -32,6 +32,9 @@ constexpr int kSubStart[kNumSub + 1] = {1, 3, 7, 13, 23, 35, 50, 67, 90, 119, 16
 // max(1, (int)(0.3 * n)), SA:2204
 constexpr int kSubNeigh[kNumSub] = {1, 1, 1, 3, 3, 4, 5, 6, 8, 12, 18, 28, 44, 86};
 constexpr int kRows = 12;  // bins 0..767
+// spectral_flux is the sub-bands' flux formula over bins 1..738: its sums ride along as band 14 of the per-band results
+constexpr int kWholeBand = 14;
+constexpr int kParked = 9;   // per-band sums of a frame that wait for the group's closed forms
 
 __attribute__((always_inline)) constexpr bool sub_touches(int b, int r) { return kSubStart[b] <= 64 * r + 63 && kSubStart[b + 1] - 1 >= 64 * r; }
 // position range of band b in the sorted array (bands are sorted by id first)
@@ -82,16 +85,22 @@ __device__ __forceinline__ double keep_or_one(double v, mask64 m) {
 }
 
 // per-band sum of one value per row; lane L receives the total of band (L >> 2) & 15
+// whole: one more per-lane value, summed over the wave into "band" kWholeBand
 template <typename F>
-__device__ __forceinline__ double band_sum(F value_of_row, const mask64 (&bm)[kSubPairs], int lane) {
+__device__ __forceinline__ double band_sum(F value_of_row, const mask64 (&bm)[kSubPairs], int lane, double whole = 0.0) {
   double acc[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
-    acc[b] = 0.0;
+    acc[b] = (b == kWholeBand) ? whole : 0.0;
     if (b < kNumSub) {
+      bool first = true;   // (0.0 + v is not v for the compiler: v may be -0.0)
 #pragma unroll
       for (int r = 0; r < kRows; ++r)
-        if (sub_touches(b, r)) acc[b] += sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), bm[sub_pair_index(b, r)]);
+        if (sub_touches(b, r)) {
+          const double v = sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), bm[sub_pair_index(b, r)]);
+          acc[b] = first ? v : acc[b] + v;
+          first = false;
+        }
     }
   }
   return wave_sum16(acc, lane);
@@ -103,10 +112,14 @@ __device__ __forceinline__ double band_max(F value_of_row, const mask64 (&bm)[kS
   for (int b = 0; b < 16; ++b) {
     acc[b] = 0.0;
     if (b < kNumSub) {
+      bool first = true;   // the values are magnitudes: >= 0
 #pragma unroll
       for (int r = 0; r < kRows; ++r)
-        if (sub_touches(b, r))
-          acc[b] = fmax(acc[b], sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), bm[sub_pair_index(b, r)]));
+        if (sub_touches(b, r)) {
+          const double v = sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), bm[sub_pair_index(b, r)]);
+          acc[b] = first ? v : fmax(acc[b], v);
+          first = false;
+        }
     }
   }
   return wave_max16(acc, lane);
@@ -114,9 +127,9 @@ __device__ __forceinline__ double band_max(F value_of_row, const mask64 (&bm)[kS
 
 // The spectrum bands ("frequency_bands", SA:2007-2048) that lie inside the stored rows: bands 0..25 = bins 1..737 (the
 // half-wave frame kernel sums bands 26, 27 = bins 738..1023 itself, from the mirrored halves it does not store).
-// x[r] = |X[64 r + lane]|; lanes with (lane & 3) == h, h = 0 / 1, receive band 16 h + (lane >> 2).
 constexpr int kBandsHere = 26;
-__device__ __forceinline__ double spectrum_band_sums(const double (&x)[12], int lane) {
+// xx[r] = |X[64 r + lane]|^2; lanes with (lane & 3) == h, h = 0 / 1, receive band 16 h + (lane >> 2).
+__device__ __forceinline__ double spectrum_band_sums(const double (&xx)[12], int lane) {
   double mine = 0.0;
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
@@ -126,12 +139,15 @@ __device__ __forceinline__ double spectrum_band_sums(const double (&x)[12], int 
       const int b = 16 * half + i;
       acc[i] = 0.0;
       if (b < kBandsHere) {
+        bool first = true;
 #pragma unroll
         for (int r = 0; r < 12; ++r)
           if (band_touches(b, r)) {
             const int k = 64 * r + lane;
             const bool whole = kBandEdge[b] <= 64 * r && kBandEdge[b + 1] - 1 >= 64 * r + 63;
-            acc[i] += (whole || (k >= kBandEdge[b] && k < kBandEdge[b + 1])) ? x[r] * x[r] : 0.0;
+            const double v = (whole || (k >= kBandEdge[b] && k < kBandEdge[b + 1])) ? xx[r] : 0.0;
+            acc[i] = first ? v : acc[i] + v;
+            first = false;
           }
       }
     }
@@ -148,25 +164,25 @@ __device__ __forceinline__ double pearson_root(double denom2) {
 }
 
 // natural log for the geometric means of the bands (Statistics.cpp:417-455): the sum of up to 287 of these is divided by
-// the band's bin count and exponentiated, so 1e-13 absolute on one logarithm is far below what the descriptor resolves;
-// the atanh series of fast_log cut after z^7 / 15 (|s| <= 0.1716: the next term is 4e-14 s), the quotient by fast_div
-__device__ __forceinline__ double band_log(double x) {
-  double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
-  int e = __builtin_amdgcn_frexp_exp(x);
-  const bool lowhalf = m < 0.70710678118654752440;
-  m = lowhalf ? m + m : m;
-  e = lowhalf ? e - 1 : e;
-  const double s = fast_div(m - 1.0, m + 1.0);
-  const double z = s * s;
-  double p = 1.0 / 15.0;
-  p = fma(p, z, 1.0 / 13.0);
-  p = fma(p, z, 1.0 / 11.0);
-  p = fma(p, z, 1.0 / 9.0);
-  p = fma(p, z, 1.0 / 7.0);
-  p = fma(p, z, 1.0 / 5.0);
-  p = fma(p, z, 1.0 / 3.0);
-  p = fma(p, z, 1.0);
-  return fma((double)e, 0.693147180559945309417, 2.0 * s * p);
+// the band's bin count and exponentiated, so 1e-13 absolute on one logarithm is far below what the descriptor resolves.
+// x = 2^e m, m in [0.5, 1); the top six mantissa bits pick an interval with centre c: log m = log1p(m / c - 1) + log c,
+// with 1 / c (rounded) and -log(1 / c) from a 64-entry table in LDS, |m / c - 1| < 2^-7 and the series cut after r^6 / 6
+// (the next term is 3e-16).  15 instructions and one LDS read against the 30 of the atanh form with its quotient.
+struct LogEntry { double inv_c, log_c; };
+__device__ __forceinline__ void band_log_table(LogEntry* table, int lane) {
+  const double inv_c = 1.0 / (0.5 + ((double)lane + 0.5) * (1.0 / 128.0));
+  table[lane] = {inv_c, -fast_log(inv_c)};
+}
+__device__ __forceinline__ double band_log(double x, const LogEntry* table) {
+  const double m = __builtin_amdgcn_frexp_mant(x);   // [0.5, 1)
+  const int e = __builtin_amdgcn_frexp_exp(x);
+  const LogEntry t = table[((unsigned)__double2hiint(m) >> 14) & 63u];
+  const double r = fma(m, t.inv_c, -1.0);
+  double q = fma(r, -1.0 / 6.0, 1.0 / 5.0);
+  q = fma(q, r, -1.0 / 4.0);
+  q = fma(q, r, 1.0 / 3.0);
+  q = fma(q, r, -1.0 / 2.0);
+  return fma((double)e, 0.693147180559945309417, t.log_c) + fma(q, r * r, r);
 }
 
 // ---- 1024-slot bitonic sort of 32-bit keys, p = 16 lane + reg, every comparator ascending ----
@@ -202,14 +218,14 @@ __device__ __forceinline__ void inlane_stage(u32 (&key)[16]) {
 template <int M, int RX>
 __device__ __forceinline__ void crosslane_stage(u32 (&key)[16], int lane) {
   constexpr int TOP = (M + 1) >> 1 > 0 ? ((M & (M + 1)) == 0 ? (M + 1) >> 1 : M) : M;  // highest set bit of M
-  const bool lower = (lane & TOP) == 0;
+  // the lane of a pair with the TOP bit clear keeps the smaller key, the other the larger: median of (own, partner, 0) and
+  // of (own, partner, ~0) -- one v_med3_u32 per key instead of minimum, maximum and a select
+  const u32 lim = (u32)__builtin_amdgcn_sbfe(lane, __builtin_ctz(TOP), 1);
   u32 out[16];
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const u32 a = key[i];
     const u32 p = lane_xor_u32<M>(key[i ^ RX]);
-    const u32 lo = a < p ? a : p, hi = a < p ? p : a;
-    out[i] = lower ? lo : hi;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(out[i]) : "v"(key[i]), "v"(p), "v"(lim));
   }
 #pragma unroll
   for (int i = 0; i < 16; ++i) key[i] = out[i];
@@ -297,7 +313,11 @@ __device__ __noinline__ double exact_cut_sum(const double* cur, int b, u32 cut_k
   return strict + tsum;
 }
 
+// FLAGS: the kBands* bits as a compile-time constant for the combinations the planner produces for whole descriptor
+// sets (what is not selected costs neither instructions nor registers), -1: read BandArgs::flags
+template <int FLAGS>
 __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
+  const int flags = FLAGS >= 0 ? FLAGS : a.flags;
   const int lane = threadIdx.x & 63;
   const int wave0 = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int stride = gridDim.x * 4;
@@ -307,12 +327,17 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   __shared__ double s_cn[4][48];   // per band: 1 / bins, 1 / neighbours, bins
   __shared__ u32 s_sel[4][8];      // the cut keys of the two bands that lie across a block boundary of the sort
   __shared__ double s_nat[4][64 * kRows];   // kBandsStats: the frame's bins in natural order for the rolloff walk
+  __shared__ LogEntry s_log[4][64];
+  __shared__ double s_park[4][4 * kParked * 16];   // [frame of the group][quantity][band]
   double* const thr = s_thr[threadIdx.x >> 6];
   u32* const sorted = s_sorted[threadIdx.x >> 6];
   u32* const cut = s_cut[threadIdx.x >> 6];      // [0..15] valley cut key per band, [16..31] peak cut key
   double* const cn = s_cn[threadIdx.x >> 6];
   u32* const sel = s_sel[threadIdx.x >> 6];
   double* const nat = s_nat[threadIdx.x >> 6];
+  LogEntry* const logt = s_log[threadIdx.x >> 6];
+  double* const park = s_park[threadIdx.x >> 6];
+  band_log_table(logt, lane);
   if (lane < 16) {
     double nb = 1.0, nn = 1.0;
 #pragma unroll
@@ -320,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       nb = (lane == i) ? (double)kSubN[i] : nb;
       nn = (lane == i) ? (double)kSubNeigh[i] : nn;
     }
+    nb = (lane == kWholeBand) ? (double)kBinCount : nb;   // the whole analysis range as one more band (spectral_flux)
     cn[lane] = 1.0 / nb; cn[16 + lane] = 1.0 / nn; cn[32 + lane] = nb;
   }
   wave_lds_fence();
@@ -346,26 +372,38 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   for (int ci = wave0; ci < a.n_chunks; ci += stride) {
     const Chunk ch = a.chunks[ci];
     double x[kRows], y[kRows];
-    if (a.flags & (kBandsFeatures | kBandsFlux)) {
-      // the frame before the chunk; the first frame of a buffer is compared with itself (SA:937-940)
-      const int64_t prow = (ch.flags & kChunkFirstOfBuffer) ? (int64_t)ch.frame0 : (int64_t)ch.frame0 - 1;
-      const double* const prv = a.mag + prow * kHalf;
+    // the frame before the chunk; the first frame of a buffer is compared with itself (SA:937-940)
+    const int first_back = (ch.flags & kChunkFirstOfBuffer) ? 0 : 1;
+    if (flags & (kBandsFeatures | kBandsFlux)) {
+      const double* const prv = a.mag + ((int64_t)ch.frame0 - first_back) * kHalf;
 #pragma unroll
       for (int r = 0; r < kRows; ++r) y[r] = prv[64 * r + lane];
     }
     // sums of the previous frame, carried from frame to frame inside the chunk
+    // Sums of products are sums of rounded products (mul_rn) here and in the loop: the previous frame's sums reach a
+    // frame either from this prologue or carried from the iteration before, and both must be the same bits.
     double fb = 0.0, fbb = 0.0, sy = 0.0, syy = 0.0;
-    if (a.flags & kBandsFlux) {
+    if (flags & (kBandsFeatures | kBandsFlux)) {
+      double yy[kRows];
 #pragma unroll
-      for (int r = 0; r < kRows; ++r) {
-        const double q = (r == 0) ? keep_where(y[r], first_row_ok) : (r == kRows - 1 ? keep_where(y[r], last_row_ok) : y[r]);
-        fb += q; fbb += q * q;
+      for (int r = 0; r < kRows; ++r) yy[r] = mul_rn(y[r], y[r]);
+      if (flags & kBandsFlux) {
+#pragma unroll
+        for (int r = 0; r < kRows; ++r) {
+          const bool edge = r == 0 || r == kRows - 1;
+          const mask64 ok = (r == 0) ? first_row_ok : last_row_ok;
+          fb += edge ? keep_where(y[r], ok) : y[r];
+          fbb += edge ? keep_where(yy[r], ok) : yy[r];
+        }
       }
-      fb = wave_sum(fb); fbb = wave_sum(fbb);
+      if (flags & kBandsFeatures) {
+        // (with the sub-bands selected the sums of spectral_flux over the whole range are band kWholeBand of the reductions)
+        sy = band_sum([&](int r) { return y[r]; }, bm, lane, fb);
+        syy = band_sum([&](int r) { return yy[r]; }, bm, lane, fbb);
+      }
     }
-    if (a.flags & kBandsFeatures) {
-      sy = band_sum([&](int r) { return y[r]; }, bm, lane);
-      syy = band_sum([&](int r) { return y[r] * y[r]; }, bm, lane);
+    if (!(flags & kBandsFeatures) && (flags & kBandsFlux)) {
+      fb = wave_sum(fb); fbb = wave_sum(fbb);
     }
 
   for (int fi = 0; fi < ch.nframes; ++fi) {
@@ -378,17 +416,23 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     const double* const cur = a.mag + f * kHalf;
 #pragma unroll
     for (int r = 0; r < kRows; ++r) x[r] = cur[64 * r + lane_v];
-
+    // products rounded on their own (mul_rn): see the chunk prologue
+    double xx[kRows], xy[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      xx[r] = mul_rn(x[r], x[r]);
+      xy[r] = mul_rn(x[r], y[r]);
+    }
     // ---- spectrum bands 0..25 for the half-wave frame kernel, which only stores the magnitudes ----
-    if (a.flags & kBandsSpectrum) {
-      const double mine = spectrum_band_sums(x, lane_v);
+    if (flags & kBandsSpectrum) {
+      const double mine = spectrum_band_sums(xx, lane_v);
       const int b = 16 * (lane_v & 3) + (lane_v >> 2);
       if ((lane_v & 3) < 2 && b < kBandsHere) a.rec[f * a.lay.stride + a.lay.bands + b] = mine;
     }
     // ---- the raw sums of the spectral statistics over bins 1..738, j = bin - 1 (SA:1808-1915), for the half-wave
     //      frame kernel's magnitude class: sum m, m^2, j m, j^2 m, m^3, m^4, sum log(m + 1e-20) and the rolloff count, as
     //      its statistics class leaves them for stats32_finish_kernel (the stored magnitudes are flushed already) ----
-    if (a.flags & kBandsStats) {
+    if (flags & kBandsStats) {
       double s1 = 0.0, s2 = 0.0, sj = 0.0, sjj = 0.0, s3 = 0.0, s4 = 0.0, prod = 1.0;
       double jq = (double)(lane_v - 1);
       double mrow[kRows];
@@ -445,42 +489,47 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       if (lane_v == 0) tmp[7] = (double)cnt;
       wave_lds_fence();
     }
-    if (!(a.flags & (kBandsFeatures | kBandsFlux))) continue;
+    if (!(flags & (kBandsFeatures | kBandsFlux))) continue;
 
     // ---- spectral_flux: Pearson r with the previous frame over bins 1..738 (SA:1919-1933,
     //      Statistics.cpp:604-638) ----
-    if (a.flags & kBandsFlux) {
+    double flux_a = 0.0, flux_aa = 0.0, flux_ab = 0.0;   // this lane's share of the whole-range sums
+    if (flags & kBandsFlux) {
       double fa = 0.0, faa = 0.0, fab = 0.0;
 #pragma unroll
       for (int r = 0; r < kRows; ++r) {
-        const double p = (r == 0) ? keep_where(x[r], first_row_ok) : (r == kRows - 1 ? keep_where(x[r], last_row_ok) : x[r]);
-        fa += p; faa += p * p; fab += p * y[r];     // y outside the range meets p = 0
+        const bool edge = r == 0 || r == kRows - 1;
+        const mask64 ok = (r == 0) ? first_row_ok : last_row_ok;
+        fa += edge ? keep_where(x[r], ok) : x[r];
+        faa += edge ? keep_where(xx[r], ok) : xx[r];
+        fab += edge ? keep_where(xy[r], ok) : xy[r];
       }
-      fa = wave_sum(fa); faa = wave_sum(faa); fab = wave_sum(fab);
       // (x / 738 as x * (1 / 738), the quotient through fast_div and the root through mag_sqrt: each within an ulp of
       // the generic expansions, which are three to five times the instructions)
-      const double n = (double)kBinCount, inv_n = 1.0 / (double)kBinCount;
-      const double ma = fa * inv_n, mb = fb * inv_n;
-      const double denom2 = (faa - ma * ma * n) * (fbb - mb * mb * n);
-      const double num = fab - (ma * mb * n);
-      if (lane_v == 0) a.rec[f * a.lay.stride + a.lay.flux] = (fabs(denom2) > (double)1e-12f) ? fast_div(num, pearson_root(denom2)) : 0.0;
-      fb = fa; fbb = faa;
-    }
-    if (!(a.flags & kBandsFeatures)) {
+      if (!(flags & kBandsFeatures)) {
+        fa = wave_sum(fa); faa = wave_sum(faa); fab = wave_sum(fab);
+        const double n = (double)kBinCount, inv_n = 1.0 / (double)kBinCount;
+        const double ma = fa * inv_n, mb = fb * inv_n;
+        const double denom2 = (faa - ma * ma * n) * (fbb - mb * mb * n);
+        const double num = fab - (ma * mb * n);
+        if (lane_v == 0) a.rec[f * a.lay.stride + a.lay.flux] = (fabs(denom2) > (double)1e-12f) ? fast_div(num, pearson_root(denom2)) : 0.0;
+        fb = fa; fbb = faa;
 #pragma unroll
-      for (int r = 0; r < kRows; ++r) y[r] = x[r];
-      continue;
+        for (int r = 0; r < kRows; ++r) y[r] = x[r];
+        continue;
+      }
+      flux_a = fa; flux_aa = faa; flux_ab = fab;
     }
 
     // ---- masked per-band sums: lane L ends up with band (L >> 2) & 15 ----
-    const double sx = band_sum([&](int r) { return x[r]; }, bm, lane_v);
-    const double sxx = band_sum([&](int r) { return x[r] * x[r]; }, bm, lane_v);
-    const double sxy = band_sum([&](int r) { return x[r] * y[r]; }, bm, lane_v);
+    const double sx = band_sum([&](int r) { return x[r]; }, bm, lane_v, flux_a);
+    const double sxx = band_sum([&](int r) { return xx[r]; }, bm, lane_v, flux_aa);
+    const double sxy = band_sum([&](int r) { return xy[r]; }, bm, lane_v, flux_ab);
     // geometric mean: sum of log(|x| + 1e-20) (Statistics.cpp:417-455 keeps a running product and
     // takes logs only when it leaves [1e-64, 1e64]; same value up to rounding)
     double lg[kRows];
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) lg[r] = band_log(fabs(x[r]) + 1e-20);
+    for (int r = 0; r < kRows; ++r) lg[r] = band_log(fabs(x[r]) + 1e-20, logt);
     const double slog = band_sum([&](int r) { return lg[r]; }, bm, lane_v);
     const double bmax = band_max([&](int r) { return x[r]; }, bm, lane_v);
 
@@ -616,43 +665,62 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       psum = (((lane_v >> 2) & 15) == bb) ? sp : psum;
     }
 
-    // ---- per-band results: every lane_v finishes the band (lane_v >> 2) & 15 ----
-    const int b = (lane_v >> 2) & 15;
-    const bool valid = b < kNumSub;
-    // 1 / n and 1 / neighbours of this lane's band: from the wave's LDS table (a select chain per frame was 60 instructions)
-    const double nb = cn[2 * 16 + b], inv_nb = cn[b], inv_nn = cn[16 + b];
-    const double cplx = (double)cnt;
-    // quotients by the band's bin count as products with its reciprocal, the others through fast_div (exact when the
-    // quotient is representable, one ulp otherwise), roots through mag_sqrt: the generic expansions of this stage were
-    // 17 divisions and 2 roots of ~25 instructions each
-    const double mean = sx * inv_nb;                                   // TStatistics::Mean (n >= 2 for every band)
-    const double rms = mag_sqrt(sxx * inv_nb);                         // SA:2154-2159
-    const double gm = fast_exp(slog * inv_nb);                         // Statistics.cpp:442
-    const double fl = (mean == 0.0) ? 0.0 : fast_div(gm, mean);        // Statistics.cpp:565-574
-    double fdb = lin_to_db(fl) * (-1.0 / 60.0);                        // SFlatnessDb, SA:129-133
-    fdb = fdb < 1.0 ? fdb : 1.0;
-    const double ma = mean, mb = sy * inv_nb;                          // Statistics.cpp:604-638
-    const double denom2 = (sxx - ma * ma * nb) * (syy - mb * mb * nb);
-    const double num = sxy - (ma * mb * nb);
-    const double flux = (fabs(denom2) > (double)1e-12f) ? fast_div(num, pearson_root(denom2)) : 0.0;
-    const double valley = vsum * inv_nn + 1e-30, peakv = psum * inv_nn + 1e-30;  // SA:2216, 2228
-    // pow(a, b) = exp(b log a), a > 0 (SA:2231-2232)
-    // (the exponent's quotient stays the generic one: a band mean of exactly 1.0 makes its denominator 0)
-    const double contrast = -1.0 * fast_exp(fast_log(fast_div(peakv, valley)) / fast_log(mean + 1e-30));
+    // ---- park the frame's sums in its slot of the group (LDS): the per-band sums of up to four frames wait for their
+    //      closed forms, and the quotients, roots, logarithms and exponentials of a group are evaluated once, in all 64
+    //      lanes (lane L: band L >> 2 of frame L & 3 of the group), when it is full or the chunk ends -- instead of once per
+    //      frame in the 14 lanes that matter ----
+    {
+      const int slot = fi & 3;
+      if ((lane_v & 3) == 0) {
+        double* const mine = park + slot * (kParked * 16) + (lane_v >> 2);
+        mine[0 * 16] = sx;   mine[1 * 16] = sxx;  mine[2 * 16] = sxy;  mine[3 * 16] = slog; mine[4 * 16] = sy;
+        mine[5 * 16] = syy;  mine[6 * 16] = vsum; mine[7 * 16] = psum; mine[8 * 16] = (double)cnt;
+      }
+      if (slot == 3 || fi == ch.nframes - 1) {
+        wave_lds_fence();
+        const double* const mine = park + (lane_v & 3) * (kParked * 16) + (lane_v >> 2);
+        const double p_sx = mine[0 * 16], p_sxx = mine[1 * 16], p_sxy = mine[2 * 16], p_slog = mine[3 * 16], p_sy = mine[4 * 16];
+        const double p_syy = mine[5 * 16], p_vsum = mine[6 * 16], p_psum = mine[7 * 16], p_cnt = mine[8 * 16];
+        // ---- per-band results: lane L finishes band L >> 2 of frame (f - slot) + (L & 3) ----
+        const int b = lane_v >> 2, j = lane_v & 3;
+        const bool live = j <= slot;
+        // 1 / n and 1 / neighbours of this lane's band: from the wave's LDS table (a select chain per frame was 60 instructions)
+        const double nb = cn[2 * 16 + b], inv_nb = cn[b], inv_nn = cn[16 + b];
+        // quotients by the band's bin count as products with its reciprocal, the others through fast_div (exact when the
+        // quotient is representable, one ulp otherwise), roots through mag_sqrt: the generic expansions of this stage were
+        // 17 divisions and 2 roots of ~25 instructions each
+        const double mean = p_sx * inv_nb;                                 // TStatistics::Mean (n >= 2 for every band)
+        const double rms = mag_sqrt(p_sxx * inv_nb);                       // SA:2154-2159
+        const double gm = fast_exp(p_slog * inv_nb);                       // Statistics.cpp:442
+        const double fl = (mean == 0.0) ? 0.0 : fast_div(gm, mean);        // Statistics.cpp:565-574
+        double fdb = lin_to_db(fl) * (-1.0 / 60.0);                        // SFlatnessDb, SA:129-133
+        fdb = fdb < 1.0 ? fdb : 1.0;
+        const double ma = mean, mb = p_sy * inv_nb;                        // Statistics.cpp:604-638
+        const double denom2 = (p_sxx - ma * ma * nb) * (p_syy - mb * mb * nb);
+        const double num = p_sxy - (ma * mb * nb);
+        const double flux = (fabs(denom2) > (double)1e-12f) ? fast_div(num, pearson_root(denom2)) : 0.0;
+        const double valley = p_vsum * inv_nn + 1e-30, peakv = p_psum * inv_nn + 1e-30;  // SA:2216, 2228
+        // pow(a, b) = exp(b log a), a > 0 (SA:2231-2232)
+        // (the exponent's quotient stays the generic one: a band mean of exactly 1.0 makes its denominator 0)
+        const double contrast = -1.0 * fast_exp(fast_log(fast_div(peakv, valley)) / fast_log(mean + 1e-30));
 
-    double* const rec = a.rec + f * a.lay.stride;
-    if (valid && (lane_v & 3) == 0) {
-      rec[a.lay.sub_rms + b] = rms;
-      rec[a.lay.sub_flat + b] = fdb;
-      rec[a.lay.sub_flux + b] = flux;
-      rec[a.lay.sub_cplx + b] = cplx;
-      rec[a.lay.sub_contrast + b] = contrast;
-    }
-    // spectral_contrast = mean of the 14 band contrasts, summed in band order (SA:2252-2260)
-    double csum = 0.0;
+        double* const rec = a.rec + (f - slot + j) * a.lay.stride;
+        if (live && b < kNumSub) {
+          rec[a.lay.sub_rms + b] = rms;
+          rec[a.lay.sub_flat + b] = fdb;
+          rec[a.lay.sub_flux + b] = flux;
+          rec[a.lay.sub_cplx + b] = p_cnt;
+          rec[a.lay.sub_contrast + b] = contrast;
+        }
+        // spectral_flux (SA:1919-1933, Statistics.cpp:604-638): the same expression over the whole analysis range
+        if (live && b == kWholeBand && (flags & kBandsFlux)) rec[a.lay.flux] = flux;
+        // spectral_contrast = mean of the 14 band contrasts, summed in band order (SA:2252-2260)
+        double csum = 0.0;
 #pragma unroll
-    for (int i = 0; i < kNumSub; ++i) csum += __shfl(contrast, 4 * i);
-    if (lane_v == 0) rec[a.lay.contrast] = csum / (double)kNumSub;
+        for (int i = 0; i < kNumSub; ++i) csum += __shfl(contrast, 4 * i + j);
+        if (live && b == 0) rec[a.lay.contrast] = csum / (double)kNumSub;
+      }
+    }
 
     // this frame is the next one's predecessor
     sy = sx; syy = sxx;
@@ -668,7 +736,12 @@ hipError_t launch_bands(const BandArgs& a, hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
   const int want = (a.n_chunks + 3) / 4;
   const int grid = want < 256 * 16 ? want : 256 * 16;
-  hipLaunchKernelGGL(bands_kernel, dim3(grid), dim3(256), 0, stream, a);
+  constexpr int kAll = kBandsFeatures | kBandsFlux;
+  if (a.flags == kAll) hipLaunchKernelGGL(bands_kernel<kAll>, dim3(grid), dim3(256), 0, stream, a);
+  else if (a.flags == (kAll | kBandsSpectrum)) hipLaunchKernelGGL(bands_kernel<kAll | kBandsSpectrum>, dim3(grid), dim3(256), 0, stream, a);
+  else if (a.flags == (kAll | kBandsSpectrum | kBandsStats))
+    hipLaunchKernelGGL(bands_kernel<kAll | kBandsSpectrum | kBandsStats>, dim3(grid), dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(bands_kernel<-1>, dim3(grid), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -144,6 +144,14 @@ __device__ __forceinline__ double wave_uniform(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// a * b rounded to a double of its own: never fused into the addition that consumes it.  For values that two code paths
+// must compute alike (a sum carried from frame to frame and the same sum recomputed where a chunk starts): whether the
+// compiler contracts a product into an fma depends on the code around it.
+__device__ __forceinline__ double mul_rn(double a, double b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+
 // A PCM sample as the double the reference's loop sees.  SCALED (kPcmScaledF32, afx_internal.h): the arena holds the
 // float mono signal LoadSample worked on and `scale` is the buffer's FinalScaling -- the product, rounded once, is the
 // reference's TSampleData::mData[n] bit for bit (SampleAnalyser.cpp:710-718).

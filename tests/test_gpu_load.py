@@ -247,3 +247,41 @@ def test_large_batches_behind_loadsample_take_the_half_wave_frame_kernel():
             continue          # discrete / ill-conditioned on noise: compared with the oracle's tolerances in their own tests
         assert np.max(np.abs(a - b) / scale) < 1e-6, field
     big.close(); small.close(); plan.close()
+
+
+@pytest.mark.parametrize("kernel", ["wave64", "halfwave"])
+def test_a_files_rows_do_not_depend_on_the_batch_it_was_analysed_in(kernel):
+    """SampleAnalyser.cpp:368-408 analyses a file on its own; here a file's frames are cut into chunks whose length the
+    planner picks for the whole batch, and the kernels carry state from frame to frame inside a chunk (the previous
+    spectrum and its band sums, groups of frames finished together).  Every per-frame value and statistic of a file must
+    be the same bit pattern whatever the batch size, the file's position in it and the chunk length were."""
+    rng = np.random.default_rng(77)
+    t = np.arange(66150)
+    pool = [np.round(9000 * rng.uniform(-1, 1, 66150)).astype(np.int16),
+            np.round(12000 * np.sin(2 * np.pi * 220 * t / 44100) * np.exp(-t / 20000.0)).astype(np.int16),
+            np.round(3000 * rng.standard_normal(66150) * (t % 11025 < 2000)).astype(np.int16),
+            np.concatenate([np.zeros(20000), np.round(15000 * rng.uniform(-1, 1, 46150))]).astype(np.int16)]
+    plan = afx.Plan(frame_kernel=afx.FRAME_KERNEL_WAVE64 if kernel == "wave64" else afx.FRAME_KERNEL_HALFWAVE)
+    mask = afx.D_ALL_PER_FRAME | afx.D_STATISTICS
+    results, chunk_frames = [], set()
+    for n_files in (4, 9, 150, 601):
+        b, _ = plan.batch_from_raw([(pool[i % 4], 1) for i in range(n_files)], mask)
+        chunk_frames.add(b.info()["chunk_frames"])
+        b.run()
+        res, st = b.fetch(), b.fetch_statistics()
+        off = res["frame_offset"]
+        rows = {}
+        for i in (0, 1, 2, 3, n_files - 4, n_files - 3, n_files - 2, n_files - 1, n_files // 2):
+            rows[i] = ({k: v[off[i]:off[i + 1]] for k, v in res.items() if k not in ("frame_offset", "buf_status")},
+                       {k: v[i] for k, v in st.items()})
+        results.append(rows)
+        b.close()
+    assert len(chunk_frames) >= 2, chunk_frames       # the planner did cut the files differently
+    want = {c: results[0][c] for c in range(4)}
+    for rows in results:
+        for i, (frames, stats) in rows.items():
+            for k, v in frames.items():
+                np.testing.assert_array_equal(v, want[i % 4][0][k], err_msg=f"{k} of file {i}")
+            for k, v in stats.items():
+                np.testing.assert_array_equal(v, want[i % 4][1][k], err_msg=f"statistics {k} of file {i}")
+    plan.close()

@@ -87,6 +87,8 @@ def main():
     passes = [("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]),
               ("sq", ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY",
                       "SQ_ACTIVE_INST_LDS", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"])]
+    if os.environ.get("AFX_PROF_TRACE_ONLY"):     # A/B timing of builds: the kernel trace alone
+        passes = []
     for name, counters in passes:
         d, _, r = run_pass(tag, name, ["--pmc"] + counters, bench_args)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):

@@ -527,6 +527,17 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     const double sxy = band_sum([&](int r) { return xy[r]; }, bm, lane_v, flux_ab);
     // geometric mean: sum of log(|x| + 1e-20) (Statistics.cpp:417-455 keeps a running product and
     // takes logs only when it leaves [1e-64, 1e64]; same value up to rounding)
+    // the neighbours of this lane's bins in the unsorted spectrum, for the local maxima below (they may reach into the
+    // adjacent band; bin 0 and 1023 never count): asked for here, all at once, and used behind the logarithms -- loaded
+    // where they are compared, each was a cache round trip of its own in a branch
+    double left[kRows], right[kRows];
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const int k = 64 * r + lane_v;
+      left[r] = cur[(r == 0) ? k - (k > 0 ? 1 : 0) : k - 1];
+      right[r] = cur[k + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     double lg[kRows];
 #pragma unroll
     for (int r = 0; r < kRows; ++r) lg[r] = band_log(fabs(x[r]) + 1e-20, logt);
@@ -545,12 +556,9 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     for (int r = 0; r < kRows; ++r) {
       const int k = 64 * r + lane_v;
       const double t = thr[bid[r]];
-      // neighbours in the unsorted spectrum, may reach into the adjacent band; bin 0 and 1023 never count
-      const double left = (k > 0) ? cur[k - 1] : 0.0;
-      const double right = cur[k + 1];
       // bins outside every band: bin 0 (row 0) and 752..767 (last row)
       const bool inside = (r == 0) ? (lane_v >= kSubStart[0]) : ((r == kRows - 1) ? (k < kSubStart[kNumSub]) : true);
-      const mask64 pk = __ballot(inside && t > 0.0 && x[r] > t && x[r] > left && x[r] > right);
+      const mask64 pk = __ballot(inside & (t > 0.0) & (x[r] > t) & (x[r] > left[r]) & (x[r] > right[r]));
 #pragma unroll
       for (int b = 0; b < kNumSub; ++b)
         if (sub_touches(b, r)) peaks[b] += __popcll(pk & bm[sub_pair_index(b, r)]);
@@ -591,27 +599,41 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     // largest key of the block: position 255), the first 35 bins of band 11 at [220, 255).  Block 1 = bins 256..511: the
     // other 61 bins of band 11 at [256, 317), band 12 at [317, 465), the first 47 bins of band 13 at [465, 512).  Block 2:
     // the other 240 bins of band 13 at [512, 752).
-    // lanes 16..23: the four cut keys (ranks nn - 1, nn, n - nn - 1, n - nn) of band 11 (lanes 16..19) and band 13 (20..23)
-    // by bisection over the two runs [a0, a0 + na), [b0, b0 + nb)
-    if (lane_v >= 16 && lane_v < 24) {
-      const bool b13 = lane_v >= 20;
-      const int a0 = b13 ? 465 : 220, na = b13 ? 47 : 35, b0 = b13 ? 512 : 256, nb = b13 ? 240 : 61;
-      const int n = na + nb, nn = b13 ? kSubNeigh[13] : kSubNeigh[11];
-      const int which = lane_v & 3;
-      const int t = (which == 0) ? nn - 1 : (which == 1 ? nn : (which == 2 ? n - nn - 1 : n - nn));
-      // i = elements of run A among the t + 1 smallest: the smallest i with B[t - i] <= A[i]
-      int lo = max(0, t + 1 - nb), hi = min(t + 1, na);
-      auto A = [&](int i) -> u32 { return (i < 0) ? 0u : ((i >= na) ? 0xFFFFFFFFu : sorted[a0 + (i < na ? i : 0)]); };
-      auto B = [&](int j) -> u32 { return (j < 0) ? 0u : ((j >= nb) ? 0xFFFFFFFFu : sorted[b0 + (j < nb ? j : 0)]); };
-#pragma unroll 1
-      for (int it = 0; it < 6; ++it) {          // 2^6 > 48 candidates
-        const int i = (lo + hi) >> 1;
-        const bool more = lo < hi && B(t - i) > A(i);
-        lo = more ? i + 1 : lo;
-        hi = more ? hi : i;
+    // The four cut keys (ranks nn - 1, nn, n - nn - 1, n - nn) of band 11 (sel[0..3]) and band 13 (sel[4..7]): the key of
+    // rank t of two sorted runs A = [a0, a0 + na), B = [b0, b0 + nb) is max(A[i - 1], B[t - i]) where i, the number of
+    // elements of A among the t + 1 smallest, is the smallest i with B[t - i] <= A[i].  The predicate B[t - i] > A[i] is
+    // true below that i and false from it on, so i = lo + (number of candidates in [lo, hi) for which it holds): every
+    // candidate is tested by a lane of its own, one ballot per rank -- a bisection by eight lanes was six dependent LDS
+    // round trips.
+    {
+      int at[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bool b13 = c >= 4;
+        const int a0 = b13 ? 465 : 220, na = b13 ? 47 : 35, b0 = b13 ? 512 : 256, nb = b13 ? 240 : 61;
+        const int n = na + nb, nn = b13 ? kSubNeigh[13] : kSubNeigh[11], which = c & 3;
+        const int t = (which == 0) ? nn - 1 : (which == 1 ? nn : (which == 2 ? n - nn - 1 : n - nn));
+        const int lo = (t + 1 - nb > 0) ? t + 1 - nb : 0, hi = (t + 1 < na) ? t + 1 : na;   // hi - lo <= 48 candidates
+        // (the positions read stay inside the array for every lane: no guard on the reads)
+        const bool more = sorted[b0 + t - lo - lane_v] > sorted[a0 + lo + lane_v];
+        at[c] = lo + __popcll(__ballot(more) & ((1ull << (hi - lo)) - 1ull));
       }
-      const u32 ka = A(lo - 1), kb = B(t - lo);
-      sel[lane_v - 16] = ka > kb ? ka : kb;
+      u32 found[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c) {
+        const bool b13 = c >= 4;
+        const int a0 = b13 ? 465 : 220, na = b13 ? 47 : 35, b0 = b13 ? 512 : 256, nb = b13 ? 240 : 61;
+        const int n = na + nb, nn = b13 ? kSubNeigh[13] : kSubNeigh[11], which = c & 3;
+        const int t = (which == 0) ? nn - 1 : (which == 1 ? nn : (which == 2 ? n - nn - 1 : n - nn));
+        const int i = at[c];                           // wave-uniform, lo <= i <= hi: i - 1 < na, t - i < nb
+        const u32 ka = sorted[a0 + (i >= 1 ? i - 1 : 0)], kb = sorted[b0 + (t - i >= 0 ? t - i : 0)];
+        const u32 ka0 = (i >= 1) ? ka : 0u, kb0 = (t - i >= 0) ? kb : 0u;
+        found[c] = ka0 > kb0 ? ka0 : kb0;
+      }
+      if (lane_v == 0) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) sel[c] = found[c];
+      }
     }
     wave_lds_fence();
     mask64 ties_v, ties_p;   // bands whose cut goes through a class of equal keys

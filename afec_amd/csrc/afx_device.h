@@ -121,18 +121,83 @@ __device__ __forceinline__ double wave_min(double v) {
   v = fmin(v, dpp_mov<kDppMirror>(v));
   return fmin(fmin(read_lane<0>(v), read_lane<16>(v)), fmin(read_lane<32>(v), read_lane<48>(v)));
 }
+// Cross-lane sums, minima, maxima and prefix sums below move data with DPP and v_readlane only: a ds_bpermute step is an
+// LDS round trip (~100 cycles), and six dependent ones per reduction were exposed latency at two waves per SIMD.
+// v of the lane the control names, 0 where it names none (or the row is not in ROW_MASK)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_or_zero(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_or_zero(double v) {
+  return __hiloint2double(dpp_or_zero<CTRL, ROW_MASK>(__double2hiint(v)), dpp_or_zero<CTRL, ROW_MASK>(__double2loint(v)));
+}
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118;
+constexpr int kDppRowBcast15 = 0x142, kDppRowBcast31 = 0x143;   // lane 15 of a row to the next row; lane 31 to rows 2, 3
+
+// v of lane + 1 (wave_shl:1: lane i reads lane i + 1); lane 63 gets `last`
+__device__ __forceinline__ int next_lane(int v, int last) { return __builtin_amdgcn_update_dpp(last, v, 0x130, 0xF, 0xF, false); }
+__device__ __forceinline__ float next_lane(float v, float last) { return __int_as_float(next_lane(__float_as_int(v), __float_as_int(last))); }
+__device__ __forceinline__ double next_lane(double v, double last) {
+  return __hiloint2double(next_lane(__double2hiint(v), __double2hiint(last)), next_lane(__double2loint(v), __double2loint(last)));
+}
+// v of lane - 1 (wave_shr:1); lane 0 gets `first`
+__device__ __forceinline__ int prev_lane(int v, int first) { return __builtin_amdgcn_update_dpp(first, v, 0x138, 0xF, 0xF, false); }
+__device__ __forceinline__ double prev_lane(double v, double first) {
+  return __hiloint2double(prev_lane(__double2hiint(v), __double2hiint(first)), prev_lane(__double2loint(v), __double2loint(first)));
+}
+
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  v += dpp_or_zero<kDppXor1>(v);
+  v += dpp_or_zero<kDppXor2>(v);
+  v += dpp_or_zero<kDppHalfMirror>(v);
+  v += dpp_or_zero<kDppMirror>(v);
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) + (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, kDppXor1, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, kDppXor2, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, kDppHalfMirror, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(v, v, kDppMirror, 0xF, 0xF, false));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+__device__ __forceinline__ int wave_max_i(int v) {
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, kDppXor1, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, kDppXor2, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, kDppHalfMirror, 0xF, 0xF, false));
+  v = max(v, __builtin_amdgcn_update_dpp(v, v, kDppMirror, 0xF, 0xF, false));
+  return max(max(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)), max(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
+}
+// inclusive prefix maximum across the 64 lanes (a lane without a source keeps its own value)
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ int dpp_or_self(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_scan_max_i(int v) {
+  v = max(v, dpp_or_self<kDppRowShr1>(v));
+  v = max(v, dpp_or_self<kDppRowShr2>(v));
+  v = max(v, dpp_or_self<kDppRowShr4>(v));
+  v = max(v, dpp_or_self<kDppRowShr8>(v));
+  v = max(v, dpp_or_self<kDppRowBcast15, 0xA>(v));
+  v = max(v, dpp_or_self<kDppRowBcast31, 0xC>(v));
   return v;
 }
-// inclusive prefix sum across the 64 lanes
-__device__ __forceinline__ double wave_scan_incl(double v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double t = __shfl_up(v, o);
-    if (lane >= o) v += t;
-  }
+// inclusive prefix sum across the 64 lanes: inside the rows of 16 (row_shr 1, 2, 4, 8), then row 0's total into row 1 and
+// row 2's into row 3 (row_bcast:15), then the total of rows 0..1 into rows 2 and 3 (row_bcast:31)
+template <typename T>
+__device__ __forceinline__ T wave_scan_incl(T v, int /*lane*/ = 0) {
+  v += dpp_or_zero<kDppRowShr1>(v);
+  v += dpp_or_zero<kDppRowShr2>(v);
+  v += dpp_or_zero<kDppRowShr4>(v);
+  v += dpp_or_zero<kDppRowShr8>(v);
+  v += dpp_or_zero<kDppRowBcast15, 0xA>(v);
+  v += dpp_or_zero<kDppRowBcast31, 0xC>(v);
+  return v;
+}
+// the same inside each half of the wave (lanes 0..31 and 32..63 on their own)
+template <typename T>
+__device__ __forceinline__ T halfwave_scan_incl(T v) {
+  v += dpp_or_zero<kDppRowShr1>(v);
+  v += dpp_or_zero<kDppRowShr2>(v);
+  v += dpp_or_zero<kDppRowShr4>(v);
+  v += dpp_or_zero<kDppRowShr8>(v);
+  v += dpp_or_zero<kDppRowBcast15, 0xA>(v);
   return v;
 }
 

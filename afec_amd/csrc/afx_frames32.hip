@@ -778,11 +778,11 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           }
           double pb = half_sum16(rb, ln);            // lane L: slot (L & 31) >> 1
           // inclusive prefix over the row slots of a half (both lanes of a slot hold the same value)
-#pragma unroll
-          for (int o = 2; o < 32; o <<= 1) {
-            const double ua = __shfl_up(pa, o, 32), ub = __shfl_up(pb, o, 32);
-            if (hq >= o) { pa += ua; pb += ub; }
-          }
+          // (DPP row shifts, then the last lane of a half's first row into its second row: no LDS round trips)
+          pa += dpp_or_zero<kDppRowShr2>(pa);  pb += dpp_or_zero<kDppRowShr2>(pb);
+          pa += dpp_or_zero<kDppRowShr4>(pa);  pb += dpp_or_zero<kDppRowShr4>(pb);
+          pa += dpp_or_zero<kDppRowShr8>(pa);  pb += dpp_or_zero<kDppRowShr8>(pb);
+          pa += dpp_or_zero<kDppRowBcast15, 0xA>(pa);  pb += dpp_or_zero<kDppRowBcast15, 0xA>(pb);
           const int last_idx = base_idx + (22 << 2);   // slot 11
           const double tot_a = __hiloint2double(__builtin_amdgcn_ds_bpermute(last_idx, __double2hiint(pa)),
                                                 __builtin_amdgcn_ds_bpermute(last_idx, __double2loint(pa)));
@@ -825,12 +825,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
             bins_before = (rstar < 16) ? 32 * rstar - (rstar > 0 ? 1 : 0) : ((rstar == 16) ? 511 : 512 + 32 * (rstar - 17));
           }
           xs = okq ? xs : 0.0;
-          double run = xs;
-#pragma unroll
-          for (int o = 1; o < 32; o <<= 1) {
-            const double u = __shfl_up(run, o, 32);
-            if (hq >= o) run += u;
-          }
+          const double run = halfwave_scan_incl(xs);
           const unsigned long long mrow = __ballot(okq && (before + run) < pivot);
           const int in_row = __popc((unsigned)(mrow >> halfmask_shift));
           const int below = bins_before + in_row;

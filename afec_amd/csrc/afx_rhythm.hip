@@ -242,6 +242,20 @@ __device__ __forceinline__ float onset_follow(float mg, double& psp, float relax
   return (float)((fl > psp) ? fl : psp);
 }
 
+// sqrtf, correctly rounded, for arguments that are neither tiny, huge, negative nor NaN: v_sqrt_f32 (1 ulp) and the choice
+// among its neighbours by the sign of the residuals -- the compiler's own expansion without its rescaling of denormal
+// arguments and its special cases (18 -> 9 instructions).  The one caller's argument is a^2 + b^2 - a b c with
+// 0.01 < b <= 1, 0 <= a <= 1 (whitened magnitudes: the follower is never below the magnitude it divides), |c| <= 1:
+// between 7e-5 and 3.
+__device__ __forceinline__ float sqrtf_midrange(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float below = __int_as_float(__float_as_int(s) - 1), above = __int_as_float(__float_as_int(s) + 1);
+  const float r_below = __builtin_fmaf(-below, s, x), r_above = __builtin_fmaf(-above, s, x);
+  float r = (r_below <= 0.f) ? below : s;
+  r = (r_above > 0.f) ? above : r;
+  return r;
+}
+
 // The terms of both onset functions for one bin of one frame (OD.cpp:380-458) from the whitened magnitude m and the
 // phase ph of the frame and what the frame before left: pred_mag = its |m|, yester_phase = its phase, yester_diff =
 // its rewrapped phase step.  Returns the rectified complex-domain deviation, pw the power term.
@@ -254,7 +268,7 @@ __device__ __forceinline__ float onset_terms(float m, float ph, float pred_mag, 
       float d = pred_phase - ph;
       d = phase_rewrap(d);
       const float cs = cosf_glibc(d);
-      dev = sqrtf(pred_mag * pred_mag + cur * cur - pred_mag * cur * cs);
+      dev = sqrtf_midrange(pred_mag * pred_mag + cur * cur - pred_mag * cur * cs);
     }
   }
   pw = m * m;
@@ -322,8 +336,13 @@ __global__ __launch_bounds__(256, kOnsetWavesPerSimd) void onset_function_kernel
     __syncthreads();
     // ---- thread = bin: Whiten (OD.cpp:186-240) + the terms of both onset functions (OD.cpp:380-458), frame by frame ----
     if (tid < kRtBins) {
+      // (the next frame's pair is asked for before this frame's terms are computed: its row is not written until then)
+      float mg_next = plane_p[tid], ph_next = plane_c[tid];
       for (int fr = 0; fr < nf; ++fr) {
-        const float mg = plane_p[fr * kRow + tid], ph = plane_c[fr * kRow + tid];
+        const float mg = mg_next, ph = ph_next;
+        const int nx = (fr + 1 < nf) ? fr + 1 : fr;
+        mg_next = plane_p[nx * kRow + tid];
+        ph_next = plane_c[nx * kRow + tid];
         const float m = mg / onset_follow(mg, psp, a.relax_coef);
         float pw;
         const float dev = onset_terms(m, ph, pred_mag, yester_phase, yester_diff, pw);
@@ -811,12 +830,7 @@ __global__ __launch_bounds__(256, kPostWavesPerSimd) void rhythm_post_kernel(Rhy
         {
           // the digit whose bin holds the k-th element: exclusive prefix sum of the 256 bins, one bin per thread
           const int h = (int)s_hist[tid];
-          int incl = h;
-#pragma unroll
-          for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(incl, o);
-            if ((tid & 63) >= o) incl += t;
-          }
+          const int incl = wave_scan_incl(h);
           if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
           __syncthreads();
           int before = 0;

@@ -232,12 +232,7 @@ __device__ void series_stats_long(const double* col, int64_t cstride, int n, int
       c[i] = hist[4 * lane + i];
       local += c[i];
     }
-    unsigned incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned t = __shfl_up(incl, o);
-      if (lane >= o) incl += t;
-    }
+    const unsigned incl = (unsigned)wave_scan_incl((int)local);
     const unsigned base = incl - local;
     const bool mine = (unsigned)rank >= base && (unsigned)rank < incl;
     int digit = 0, below = 0;
@@ -337,10 +332,7 @@ __global__ __launch_bounds__(64) void stats_small_kernel(const StatsArgs a) {
     const int64_t nn = a.frame_offset[buf + 1] - f0;
     const bool active = s < series && nn >= 2 && nn <= kSmallMax;     // other lengths: stats_kernel
     const int n = active ? (int)nn : 0;
-    int nmax = n;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
-    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    const int nmax = wave_max_i(n);
     if (nmax == 0) continue;
     const double* const base = a.rec + f0 * a.stride + (active ? col : 0);
     // the tile in LDS: frame p of this lane's series at tile[64 p], zeros behind the lane's own n.  Rows are asked for

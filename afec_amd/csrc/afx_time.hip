@@ -30,7 +30,8 @@ constexpr int kPadSlots = 1344;                 // >= 1024 + 64 pads (blocked la
 constexpr int kTimePlaneBytes = kPadSlots * 8;
 // shared tables (t2, post: 16 KiB each; t1: 1 KiB -- from global memory its reads were three exposed cache round trips
 // per transform, the vector-memory path being what the frame's own loads wait on), then one plane per wave
-constexpr int kLdsT2 = 0, kLdsPost = 16384, kLdsT1 = 32768, kLdsCpow = 32768 + 1024, kLdsPlanes = 32768 + 1024 + 256;
+constexpr int kLdsT2 = 0, kLdsPost = 16384, kLdsT1 = 32768, kLdsCpow = 32768 + 1024, kLdsEnvScan = 32768 + 1024 + 256,
+              kLdsPlanes = 32768 + 1024 + 256 + 1024;
 constexpr int kTimeLdsBytes = kLdsPlanes + kTimeWaves * kTimePlaneBytes;
 
 __device__ __forceinline__ int pad_slot(int e) { return e + (e >> 4); }
@@ -98,30 +99,11 @@ struct Block16<double> {
   }
 };
 
-// v of lane + 1 (wave_shl:1: lane i reads lane i + 1); lane 63 gets `last`
-__device__ __forceinline__ float next_lane(float v, float last) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(last), __float_as_int(v), 0x130, 0xF, 0xF, false));
-}
-__device__ __forceinline__ double next_lane(double v, double last) {
-  const int lo = __builtin_amdgcn_update_dpp(__double2loint(last), __double2loint(v), 0x130, 0xF, 0xF, false);
-  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(last), __double2hiint(v), 0x130, 0xF, 0xF, false);
-  return __hiloint2double(hi, lo);
-}
 // lane 0's value, in every lane
 __device__ __forceinline__ float first_lane(float v) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)); }
 __device__ __forceinline__ double first_lane(double v) { return read_lane<0>(v); }
 
 using mask64 = unsigned long long;
-__device__ __forceinline__ int wave_min_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = min(v, __shfl_xor(v, o));
-  return v;
-}
-__device__ __forceinline__ int wave_max_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
-  return v;
-}
 
 // aubio_silence_detection: 10 log10(mean x^2) < -48 dB (mathutils.c:605-615, MSilenceThresholdDb).  log10 is
 // monotonic, so the test is mean x^2 < 10^-4.8 (they can only disagree for a level within an ulp of the
@@ -141,9 +123,19 @@ __device__ __forceinline__ double hop_energy(const double (&x)[16]) {
   for (int i = 0; i < 16; ++i) e += x[i] * x[i];
   return wave_sum(e);
 }
+// lane constants of the envelope's prefix scan (hop_descriptors): coef^(16 (j + 1)) takes the end value of the last lane
+// of the row before to lane j of a row; from lane 31 to lane j of row 2 it is the same power, of row 3 sixteen lanes more
+struct EnvelopeScan { double from_row_before, from_lane31; };
+__device__ __forceinline__ EnvelopeScan envelope_scan(double coef, int lane) {
+  const int j = lane & 15;
+  EnvelopeScan e;
+  e.from_row_before = pow(coef, (double)(16 * (j + 1)));
+  e.from_lane31 = (lane >= 48) ? pow(coef, (double)(16 * (j + 17))) : e.from_row_before;
+  return e;
+}
 // cpow[i] = coef^i, i <= 16 (registers in hop_kernel, an LDS table in pitch_kernel)
 template <typename Pow>
-__device__ __forceinline__ void hop_descriptors(const double (&x)[16], double e, double coef, const Pow& cpow,
+__device__ __forceinline__ void hop_descriptors(const double (&x)[16], double e, double coef, const Pow& cpow, const EnvelopeScan& scan,
                                                 uint32_t amplitude, const RecordLayout& lay, double* rec, int lane) {
   if (amplitude) {
     double peak = 0.0;
@@ -163,15 +155,19 @@ __device__ __forceinline__ void hop_descriptors(const double (&x)[16], double e,
     env = in + coef * (env - in);        // TEnvelopeDetector::Run, Envelopes.inl:14-18
     loc[i] = env;
   }
-  double carry = env, slope = cpow[16];
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const double t = __shfl_up(carry, o);
-    if (lane >= o) carry = fma(slope, t, carry);
-    slope *= slope;
-  }
-  double in_carry = __shfl_up(carry, 1);
-  if (lane == 0) in_carry = 0.0;
+  // The envelope at the end of lane l's sixteen samples is C_l = env_l + s C_(l-1), s = coef^16: a prefix "sum" with a
+  // factor per step.  Inside the rows of 16 lanes with DPP row shifts (factors s, s^2, s^4, s^8), then the last lane of
+  // row 0 into row 1 and of row 2 into row 3, then lane 31 into rows 2 and 3, each times the power of s that separates the
+  // two lanes (EnvelopeScan) -- no LDS round trips (six ds_bpermute steps before).
+  double carry = env;
+  const double s1 = cpow[16], s2 = s1 * s1, s4 = s2 * s2, s8 = s4 * s4;
+  carry = fma(s1, dpp_or_zero<kDppRowShr1>(carry), carry);
+  carry = fma(s2, dpp_or_zero<kDppRowShr2>(carry), carry);
+  carry = fma(s4, dpp_or_zero<kDppRowShr4>(carry), carry);
+  carry = fma(s8, dpp_or_zero<kDppRowShr8>(carry), carry);
+  carry = fma(scan.from_row_before, dpp_or_zero<kDppRowBcast15, 0xA>(carry), carry);
+  carry = fma(scan.from_lane31, dpp_or_zero<kDppRowBcast31, 0xC>(carry), carry);
+  const double in_carry = dpp_or_zero<0x138>(carry);      // wave_shr:1: lane l reads lane l - 1, lane 0 gets 0
   double top = 0.0;
 #pragma unroll
   for (int i = 0; i < 16; ++i) top = fmax(top, fma(cpow[i + 1], in_carry, loc[i]));
@@ -200,6 +196,7 @@ __global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
   cpow[0] = 1.0;
 #pragma unroll
   for (int i = 1; i <= 16; ++i) cpow[i] = cpow[i - 1] * coef;
+  const EnvelopeScan env_scan = envelope_scan(coef, lane);
 
   for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
     const Chunk ch = a.chunks[ci];
@@ -210,7 +207,7 @@ __global__ __launch_bounds__(256) void hop_kernel(const TimeArgs a) {
       scale16<SCALED>(x, sc);
       double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
 
-      hop_descriptors(x, hop_energy(x), coef, cpow, a.amplitude, a.lay, rec, lane);
+      hop_descriptors(x, hop_energy(x), coef, cpow, env_scan, a.amplitude, a.lay, rec, lane);
     }
   }
 }
@@ -495,10 +492,12 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
   // powers in LDS (hop_descriptors)
   const double env_coef = pow(0.01, 1000.0 / (8.0 * (double)kSampleRate));
   double* const env_pow = reinterpret_cast<double*>(lds_raw + kLdsCpow);
+  EnvelopeScan* const env_scan_of_lane = reinterpret_cast<EnvelopeScan*>(lds_raw + kLdsEnvScan);
   if (a.hop_here && threadIdx.x == 0) {
     double pw = 1.0;
     for (int i = 0; i <= 16; ++i) { env_pow[i] = pw; pw *= env_coef; }
   }
+  if (a.hop_here && threadIdx.x < 64) env_scan_of_lane[threadIdx.x] = envelope_scan(env_coef, threadIdx.x);
   __syncthreads();
   constexpr int kBig = 1 << 30;
 
@@ -664,7 +663,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       }
 
       // ---- first dip below the tolerance, else the (last) global minimum (pitchyinfast.c:154-163) ----
-      double nxt = __shfl_down(yin[0], 1);
+      const double nxt = next_lane(yin[0], yin[0]);
       int first = kBig;
 #pragma unroll
       for (int i = 15; i >= 0; --i) {
@@ -720,7 +719,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
         double xh[16];
         load16(x + 16 * lane, xh);
         scale16<SCALED>(xh, sc);
-        hop_descriptors(xh, hop_energy(xh), env_coef, env_pow, a.amplitude, a.lay, rec, lane);
+        hop_descriptors(xh, hop_energy(xh), env_coef, env_pow, env_scan_of_lane[lane], a.amplitude, a.lay, rec, lane);
       }
     }
   }

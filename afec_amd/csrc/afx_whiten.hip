@@ -27,15 +27,6 @@
 namespace afx {
 namespace {
 
-__device__ __forceinline__ int wave_scan_max_i(int v, int lane) {
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int t = __shfl_up(v, o);
-    if (lane >= o) v = max(v, t);
-  }
-  return v;
-}
-
 __device__ __forceinline__ void load_bins(const double* p, double (&m)[16]) {
   const double2* q = reinterpret_cast<const double2*>(p);
 #pragma unroll
@@ -115,12 +106,16 @@ __global__ __launch_bounds__(256) void whiten_kernel(const WhitenArgs a) {
           double t = a.decay * follow[i];
           t = (t > a.floor_value) ? t : a.floor_value;           // MAX(r_decay * peak, floor)
           follow[i] = (cur[i] > t) ? cur[i] : t;                 // MAX(norm, tmp)
-          w[i] = cur[i] / follow[i];
+          // (fast_div: exact when the quotient is representable -- 1.0 where the follower sits on the magnitude, 0 for a
+          // zero magnitude, the cases that make runs of equal values --, within an ulp otherwise; the magnitudes themselves
+          // differ from the reference's in their last bits, so a correctly rounded quotient of them is no closer to its;
+          // the generic division is 35 instructions against 8, sixteen times per lane and frame)
+          w[i] = fast_div(cur[i], follow[i]);
           top = fmax(top, w[i]);
         }
         top = wave_max(top);
         const double thr = 0.25 * top;                           // MPeakThreshold, SA:47, 105-106
-        double before = __shfl_up(w[15], 1), after = __shfl_down(w[0], 1);
+        const double before = prev_lane(w[15], w[15]), after = next_lane(w[0], w[0]);
         // Statistics.cpp:140-232 as a run analysis: a peak is a maximal run of equal values [s..e] entered by a
         // strict rise (w[s-1] < w[s], s >= 1) and left by a strict fall (w[e+1] < w[e], e + 1 < N - 1), above
         // the threshold; it is reported at bin (s + e) / 2.  The two boundary bins and bin N-2 have their own
@@ -135,9 +130,8 @@ __global__ __launch_bounds__(256) void whiten_kernel(const WhitenArgs a) {
           if (begins) open = (k << 1) | (rises ? 1 : 0);
           start[i] = open;
         }
-        const int incl = wave_scan_max_i(open, lane);
-        int carried = __shfl_up(incl, 1);
-        if (lane == 0) carried = -1;
+        const int incl = wave_scan_max_i(open);
+        const int carried = prev_lane(incl, -1);
         int count = 0;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {

@@ -165,6 +165,7 @@ struct Workspace {
   // leave most of the chip idle during any one kernel, so the two kernel chains run side by side
   hipStream_t side_stream = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_time_join = nullptr;   // the time-domain kernels (autocorrelation, f0, hop) run on the side stream too
   hipEvent_t ev_copy = nullptr;   // the host's waits for the plan's upload / download streams (and, when blocking, for this batch's stream)
   bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_plan_set_blocking_wait)
   unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
@@ -423,6 +424,7 @@ void ws_free(Workspace* w) {
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->ev_fork) hipEventDestroy(w->ev_fork);
   if (w->ev_join) hipEventDestroy(w->ev_join);
+  if (w->ev_time_join) hipEventDestroy(w->ev_time_join);
   if (w->ev_copy) hipEventDestroy(w->ev_copy);
   if (w->side_stream) hipStreamDestroy(w->side_stream);
   if (w->stream) hipStreamDestroy(w->stream);
@@ -453,6 +455,7 @@ Workspace* ws_acquire(afx_plan* plan, hipError_t* err) {
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&w->side_stream, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_time_join, hipEventDisableTiming);
   w->blocking = plan->blocking_wait.load();
   if (e == hipSuccess) e = hipEventCreateWithFlags(&w->ev_copy, hipEventDisableTiming);
   if (e != hipSuccess) { *err = e; ws_free(w); return nullptr; }
@@ -928,7 +931,7 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     // the 8 KiB of magnitudes per frame) is not needed; long files, and batches too small to fill the chip with one
     // wave per file, keep chunks of K frames whose start states follow_kernel provides.
     constexpr int64_t kWholeFileFrames = 128;
-    const bool whole_files = n_bufs >= 1024;
+    const bool whole_files = n_bufs >= 768;     // one wave per file on at least three quarters of the chip's 1 024 SIMDs
     std::vector<afx::Chunk>& wchunks = b->h_wchunks;
     chunk_first.assign((size_t)n_bufs + 1, 0);
     for (int i = 0; i < n_bufs; ++i) {
@@ -1256,12 +1259,15 @@ int run_rhythm(afx_batch* b, hipStream_t stream) {
 }
 
 // the rhythm chain on the workspace's side stream, forked here and joined by rhythm_join at the end of the run
-int rhythm_fork(afx_batch* b) {
+// (already_forked: the side stream waits for the batch's stream already -- the time-domain kernels went there first)
+int rhythm_fork(afx_batch* b, bool already_forked) {
   if (!(b->mask & AFX_D_RHYTHM) || b->n_bufs == 0) return AFX_OK;
   Workspace& w = *b->ws;
   if (!b->plan->side_stream) return run_rhythm(b, b->stream);
-  HIP_TRY(hipEventRecord(w.ev_fork, b->stream));
-  HIP_TRY(hipStreamWaitEvent(w.side_stream, w.ev_fork, 0));
+  if (!already_forked) {
+    HIP_TRY(hipEventRecord(w.ev_fork, b->stream));
+    HIP_TRY(hipStreamWaitEvent(w.side_stream, w.ev_fork, 0));
+  }
   const int st = run_rhythm(b, w.side_stream);
   if (st != AFX_OK) return st;
   HIP_TRY(hipEventRecord(w.ev_join, w.side_stream));
@@ -1556,8 +1562,39 @@ int afx_batch_run(afx_batch* b) {
   if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
   HIP_TRY(hipSetDevice(b->plan->desc.device));
   b->ran = true;
+  // The time-domain kernels (autocorrelation, f0, the hop's descriptors) read the PCM only and the spectral chain
+  // (STFT, bands) does not need them: they go to the side stream, ahead of the rhythm tracker's, and are joined where
+  // the whitening kernel reads what the pitch kernel left (f0, its confidence, the hop's silence flag).  One kernel at a
+  // time leaves the tail of every launch to a partly idle chip (a crawl's batch is 10-40 waves per SIMD per kernel).
+  const DeviceTables& t = b->plan->dev;
+  const uint32_t post_amplitude = (b->total_frames > 0 && b->halfwave && afx::frames32_class(frames_mask(b->mask)) >= 2)
+                                      ? (b->mask & (AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS)) : 0u;
+  const bool time_work = b->total_frames > 0 && ((b->mask & kTimeBits) || post_amplitude);
+  // (not with the rhythm tracker selected: its chain, the longer one, has the side stream then -- 21.7 against 21.2 M frames/s
+  // on the C4 share with everything selected; without it 34.4 against 33.9 M on C3)
+  const bool time_side = time_work && b->plan->side_stream && frames_mask(b->mask) != 0 && !(b->mask & AFX_D_RHYTHM);
+  if (time_work) {
+    hipStream_t ts = b->stream;
+    if (time_side) {
+      HIP_TRY(hipEventRecord(b->ws->ev_fork, b->stream));
+      HIP_TRY(hipStreamWaitEvent(b->ws->side_stream, b->ws->ev_fork, 0));
+      ts = b->ws->side_stream;
+    }
+    afx::TimeArgs ta{};
+    ta.pcm = b->d_pcm; ta.chunks = b->d_chunks; ta.remaining = b->d_rem; ta.n_chunks = b->n_chunks;
+    ta.pcm_dtype = b->pcm_dtype; ta.rec = b->d_rec; ta.lay = b->lay;
+    ta.t1 = t.t1_f64; ta.t2 = t.t2_f64; ta.post = t.post_f64;
+    ta.amplitude = post_amplitude;
+    // with f0 selected the pitch kernel has the hop's samples in registers anyway and writes its descriptors too
+    const bool want_hop = (b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) || post_amplitude;
+    ta.hop_here = (want_hop && (b->mask & AFX_D_F0)) ? 1u : 0u;
+    if (want_hop && !ta.hop_here) HIP_TRY(afx::launch_hop(ta, ts));
+    if (b->mask & AFX_D_F0) HIP_TRY(afx::launch_pitch(ta, ts));
+    if (b->mask & AFX_D_AUTO_CORRELATION) HIP_TRY(afx::launch_acorr(ta, ts));
+    if (time_side) HIP_TRY(hipEventRecord(b->ws->ev_time_join, ts));
+  }
   {
-    const int st = rhythm_fork(b);
+    const int st = rhythm_fork(b, time_side);
     if (st != AFX_OK) return st;
   }
   if (b->d_efflen) {
@@ -1577,7 +1614,6 @@ int afx_batch_run(afx_batch* b) {
     }
     return rhythm_join(b);
   }
-  const DeviceTables& t = b->plan->dev;
   if (frames_mask(b->mask)) {
     afx::FrameArgs a{};
     a.pcm = b->d_pcm;
@@ -1622,21 +1658,7 @@ int afx_batch_run(afx_batch* b) {
       HIP_TRY(afx::launch_stats32_finish(fa, b->stream, b->total_frames));
     }
   }
-  // the half-wave full classes leave the amplitude of the hop to hop_kernel
-  const uint32_t post_amplitude = (b->halfwave && afx::frames32_class(frames_mask(b->mask)) >= 2) ? (b->mask & (AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS)) : 0u;
-  if ((b->mask & kTimeBits) || post_amplitude) {
-    afx::TimeArgs ta{};
-    ta.pcm = b->d_pcm; ta.chunks = b->d_chunks; ta.remaining = b->d_rem; ta.n_chunks = b->n_chunks;
-    ta.pcm_dtype = b->pcm_dtype; ta.rec = b->d_rec; ta.lay = b->lay;
-    ta.t1 = t.t1_f64; ta.t2 = t.t2_f64; ta.post = t.post_f64;
-    ta.amplitude = post_amplitude;
-    // with f0 selected the pitch kernel has the hop's samples in registers anyway and writes its descriptors too
-    const bool want_hop = (b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) || post_amplitude;
-    ta.hop_here = (want_hop && (b->mask & AFX_D_F0)) ? 1u : 0u;
-    if (want_hop && !ta.hop_here) HIP_TRY(afx::launch_hop(ta, b->stream));
-    if (b->mask & AFX_D_AUTO_CORRELATION) HIP_TRY(afx::launch_acorr(ta, b->stream));
-    if (b->mask & AFX_D_F0) HIP_TRY(afx::launch_pitch(ta, b->stream));
-  }
+  if (time_side) HIP_TRY(hipStreamWaitEvent(b->stream, b->ws->ev_time_join, 0));
   if (b->mask & kWhitenBits) {
     afx::WhitenArgs wa{};
     wa.mag = b->d_mag; wa.frame_offset = b->d_frame_offset; wa.n_bufs = b->n_bufs; wa.mask = b->mask;
@@ -1856,7 +1878,7 @@ void afx_batch_destroy(afx_batch* b) {
   if (b->stream) hipStreamSynchronize(b->stream);
   // a run that failed between the rhythm chain's fork and its join leaves kernels on the side stream: they must be
   // done before the workspace goes back to the pool
-  if (b->ws && b->ws->side_stream && (b->mask & AFX_D_RHYTHM)) hipStreamSynchronize(b->ws->side_stream);
+  if (b->ws && b->ws->side_stream) hipStreamSynchronize(b->ws->side_stream);
 #if defined(AFX_STAMPS) && AFX_STAMPS
   if (g_stamp_buf) {
     unsigned long long h[16];

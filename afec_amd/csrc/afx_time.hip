@@ -563,14 +563,18 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       // C = conj(U) X at k and at 1024-k, then the packed spectrum of the inverse: Zc = Ec + i Oc,
       // Ec = (C + conj(C'))/2, Oc = (C - conj(C'))/2 conj(w^k).  The factors 1/2 are carried along instead of
       // applied (2E, 2O, 2U, 2X, 4C, 8 Zc: exact) and undone with the 1/1024 of the inverse.
-      cx<double> g[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const cx<double> pu = partner_of(zu, r, c), pn = partner_of(zn, r, c);
-        const cx<double> w = c.post[64 * r];
+      // Bins k and 1024 - k share every intermediate (U[k'] = Up, X[k'] = Xp, the roles of C and Cp swap, w[k'] = -conj(w)):
+      // the output at k' is {ec.re + oc.im, ec.im - oc.re} where the output at k is {ec.re - oc.im, -(ec.im + oc.re)}.  A lane
+      // therefore works on half of its bins (registers 0..7) and hands the partner lane the other output of each pair --
+      // lane l's register r pairs with lane 64 - l's register 15 - r --, instead of both lanes computing both.  Lane 0's
+      // bins pair among themselves (64 r with 64 (16 - r)): its fetched and delivered registers are shifted by one and its
+      // bin 512 is its own partner.
+      cx<double> g[16], gp[8];
+      auto pair_product = [&](const cx<double>& zu_k, const cx<double>& pu, const cx<double>& zn_k, const cx<double>& pn,
+                              const cx<double>& w, cx<double>& at_k, cx<double>& at_partner) {
         cx<double> e, o, en, on;
-        even_odd(zu[r], pu, e, o);
-        even_odd(zn[r], pn, en, on);
+        even_odd(zu_k, pu, e, o);
+        even_odd(zn_k, pn, en, on);
         const cx<double> wo = cmul(w, o), won = cmul(w, on);
         const cx<double> U{e.re + wo.re, e.im + wo.im};
         const cx<double> Up{e.re - wo.re, -(e.im - wo.im)};                  // U[1024-k] = conj(E - w O)
@@ -581,7 +585,20 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
         const cx<double> ec{C.re + Cp.re, C.im - Cp.im};
         const cx<double> d{C.re - Cp.re, C.im + Cp.im};
         const cx<double> oc{d.re * w.re + d.im * w.im, d.im * w.re - d.re * w.im};
-        g[r] = {ec.re - oc.im, -(ec.im + oc.re)};      // conj(8 Zc)
+        at_k = {ec.re - oc.im, -(ec.im + oc.re)};      // conj(8 Zc)
+        at_partner = {ec.re + oc.im, ec.im - oc.re};
+      };
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const cx<double> pu = partner_of(zu, r, c), pn = partner_of(zn, r, c);
+        pair_product(zu[r], pu, zn[r], pn, c.post[64 * r], g[r], gp[r]);
+      }
+      cx<double> g512, unused;
+      pair_product(zu[8], zu[8], zn[8], zn[8], c.post[64 * 8], g512, unused);     // lane 0's bin 512 (the other lanes' result is dropped)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        g[15 - j] = {__shfl(gp[j].re, c.partner), __shfl(gp[j].im, c.partner)};
+        if (lane == 0) g[15 - j] = (j < 7) ? gp[j + 1] : g512;
       }
       // the second half's transform is the next frame's first-half transform
 #pragma unroll

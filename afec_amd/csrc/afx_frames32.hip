@@ -236,6 +236,19 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
   // hop hop_kernel's.  The statistics of the full classes cost this kernel 250-300 bytes of scratch per lane and more
   // than half of its time.
   constexpr bool MAGS = (FEAT == 4);
+  // The overlap half of a frame (rows 0..15 = the hop of the frame before) either stays in 32 registers from frame to
+  // frame (MFCC class: it has them) or comes back from the cache by a second LDS-DMA into the upper half of the wave's
+  // plane, asked for at the bottom of the loop with the window pairs: the classes that keep sums or stored rows next to
+  // the FFT registers spilled those 32 registers (128 B of scratch per lane and frame pair, written and read back: 4 KiB
+  // per frame each way -- which the counters showed as HBM traffic, the scratch lines do not survive in L2 next to the
+  // streaming stores).
+#ifndef AFX_X_LO_LDS
+#define AFX_X_LO_LDS 0
+#endif
+  // (measured: magnitude class 2.35 -> 1.99 ms on the C4 share, full classes 23.1 -> 20.7 ms on 5.12 M frames; the
+  // statistics class, which spilled 44 bytes, 16.1 -> 17.7 ms and the MFCC class 493 -> 422 M frames/s: they keep the
+  // registers)
+  constexpr bool LO_LDS = (FEAT >= 2) || AFX_X_LO_LDS;
   constexpr bool STATS = (FEAT >= 1 && FEAT <= 3);
   constexpr bool PAIRS = STATS;
   // FEAT 2, 3 ("full" classes, for masks with flux / spectrum bands / sub-band descriptors / amplitude): the statistics
@@ -325,9 +338,16 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
     const int last_d = max((have_d ? (int)chd.nframes : 0) - 1, 0);
     const float* const dsrc = pcm + chd.sample_off + 64 * (16 + drow) + 2 * dq;   // row 16 + drow, sample 2 dq
 
-    float2 lo[16];
+    // (pairs of floats as the 8-byte words they are loaded as: an array of float2 was left in scratch memory by the
+    // compiler in the larger classes -- 128 bytes per lane stored and reloaded every frame pair)
+    double lo[16];
+    if constexpr (!LO_LDS) {
+      const double* const src8 = reinterpret_cast<const double*>(src);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) lo[r] = src[32 * r];
+      for (int r = 0; r < 16; ++r) lo[r] = src8[32 * r];
+    } else {
+      dma_hop(dsrc - kHop, plane_lds + 8192);   // rows 0..15 of frame 0
+    }
     // frame 0's new hop (every DS operation of the previous chunk has been waited for)
     dma_hop(dsrc, plane_lds);
 
@@ -350,20 +370,27 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       // ---- window (table carries the 1/2048 of kDivFwdByN and the 1/2 of the untangle) ----
       cx<double> v[32];
       {
-        float2 nx[16];
+        double nx[16];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the hop's LDS-DMA has landed (and the window pairs)
         AFX_STAMP(0);   // wait for DMA + window
 #pragma unroll
-        for (int r = 0; r < 16; ++r) nx[r] = __builtin_bit_cast(float2, (double)hop[64 * r]);
+        for (int r = 0; r < 16; ++r) nx[r] = hop[64 * r];
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (LO_LDS) {
+          const double* const lo_rows = reinterpret_cast<const double*>(plane_bytes + 8192 + 256 * h) + q;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) lo[r] = lo_rows[64 * r];
+        }
         // window products fused into the first radix-4 stage of P1 (rows j, j + 8 from the overlap half, rows
         // j + 16, j + 24 from the new hop): a w_a +- c w_c as one product and two fused multiply-adds
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const double ar = pcm_double<SCALED>(lo[j].x, sc), ai = pcm_double<SCALED>(lo[j].y, sc);
-          const double br = pcm_double<SCALED>(lo[j + 8].x, sc), bi = pcm_double<SCALED>(lo[j + 8].y, sc);
-          const double cr = pcm_double<SCALED>(nx[j].x, sc), ci = pcm_double<SCALED>(nx[j].y, sc);
-          const double dr = pcm_double<SCALED>(nx[j + 8].x, sc), di = pcm_double<SCALED>(nx[j + 8].y, sc);
+          auto first = [](double pair) { return __int_as_float(__double2loint(pair)); };
+          auto second = [](double pair) { return __int_as_float(__double2hiint(pair)); };
+          const double ar = pcm_double<SCALED>(first(lo[j]), sc), ai = pcm_double<SCALED>(second(lo[j]), sc);
+          const double br = pcm_double<SCALED>(first(lo[j + 8]), sc), bi = pcm_double<SCALED>(second(lo[j + 8]), sc);
+          const double cr = pcm_double<SCALED>(first(nx[j]), sc), ci = pcm_double<SCALED>(second(nx[j]), sc);
+          const double dr = pcm_double<SCALED>(first(nx[j + 8]), sc), di = pcm_double<SCALED>(second(nx[j + 8]), sc);
           const double par = ar * w[j].x, pai = ai * w[j].y, pbr = br * w[j + 8].x, pbi = bi * w[j + 8].y;
           const double t0r = fma(cr, w[j + 16].x, par), t0i = fma(ci, w[j + 16].y, pai);
           const double t1r = fma(-cr, w[j + 16].x, par), t1i = fma(-ci, w[j + 16].y, pai);
@@ -374,8 +401,10 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           v[j + 8] = {t1r + t3i, t1i - t3r};
           v[j + 24] = {t1r - t3i, t1i + t3r};
         }
+        if constexpr (!LO_LDS) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lo[r] = nx[r];
+          for (int r = 0; r < 16; ++r) lo[r] = nx[r];
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
       AFX_STAMP(1);   // hop reads + conversion + window + first radix-4 stage
@@ -719,6 +748,8 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         if (FEAT == 0 || MAGS) {
 #pragma unroll
           for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
+          // (the parked rows have been read: the upper half of the plane is free for the next frame's overlap rows)
+          if constexpr (LO_LDS) dma_hop(dsrc + (size_t)min(fi + 1, last_d) * kHop - kHop, plane_lds + 8192);
         }
         if (FEAT == 0 || MAGS) {
           if (MAGS) {   // the two free slots of the reduction: spectrum bands 26, 27 (x 4: the window carries an extra 1/2)
@@ -836,6 +867,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 
 #pragma unroll
           for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
+          if constexpr (LO_LDS) dma_hop(dsrc + (size_t)min(fi + 1, last_d) * kHop - kHop, plane_lds + 8192);
         }
         if (fi & 1) finish_mfcc32(mel_acc, recp, left, stride2, dct, logc, lane);
         AFX_STAMP(9);   // log + DCT + store (every second iteration)

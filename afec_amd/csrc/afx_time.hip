@@ -148,12 +148,11 @@ __device__ __forceinline__ void hop_descriptors(const double (&x)[16], double e,
     }
   }
   if (lay.silence < 0 && lay.envelope < 0) return;
-  double loc[16], env = 0.0;
+  double env = 0.0;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const double in = fabs(x[i]);
     env = in + coef * (env - in);        // TEnvelopeDetector::Run, Envelopes.inl:14-18
-    loc[i] = env;
   }
   // The envelope at the end of lane l's sixteen samples is C_l = env_l + s C_(l-1), s = coef^16: a prefix "sum" with a
   // factor per step.  Inside the rows of 16 lanes with DPP row shifts (factors s, s^2, s^4, s^8), then the last lane of
@@ -168,9 +167,17 @@ __device__ __forceinline__ void hop_descriptors(const double (&x)[16], double e,
   carry = fma(scan.from_row_before, dpp_or_zero<kDppRowBcast15, 0xA>(carry), carry);
   carry = fma(scan.from_lane31, dpp_or_zero<kDppRowBcast31, 0xC>(carry), carry);
   const double in_carry = dpp_or_zero<0x138>(carry);      // wave_shr:1: lane l reads lane l - 1, lane 0 gets 0
+  // the lane's sixteen values once more, now from the state the lanes before it leave: the reference's recurrence itself
+  // (the first pass, from 0, only gave the scan its per-lane term; its sixteen values are not kept -- 32 registers that
+  // the pitch kernel, which calls this with its transforms' registers live, does not have)
   double top = 0.0;
+  env = in_carry;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) top = fmax(top, fma(cpow[i + 1], in_carry, loc[i]));
+  for (int i = 0; i < 16; ++i) {
+    const double in = fabs(x[i]);
+    env = in + coef * (env - in);
+    top = fmax(top, env);
+  }
   top = wave_max(top);
   if (lane == 0) {
     if (lay.silence >= 0) rec[lay.silence] = au_silent(e, kHop) ? 1.0 : 0.0;   // SA:865-868
@@ -639,6 +646,10 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
       qb.get(xb);
       scale16<SCALED>(xa, sc);
       scale16<SCALED>(xb, sc);
+      // the hop's own descriptors (silence flag, envelope, amplitude: hop_kernel's, SA:865-872, 1760-1804): a batch that
+      // computes f0 does not launch a kernel and read the PCM from HBM once more for them; here, where the hop is in
+      // registers in the blocked layout anyway
+      if (a.hop_here) hop_descriptors(xa, hop_energy(xa), env_coef, env_pow, env_scan_of_lane[lane], a.amplitude, a.lay, rec, lane);
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
@@ -728,15 +739,6 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
         rec[a.lay.f0_conf] = conf;
         // hop silence (SA:865-868) parked in the fail-safe slot for afx_whiten.hip, which replaces it
         rec[a.lay.f0_safe] = au_silent(s0, kHop) ? 1.0 : 0.0;
-      }
-      // the hop's own descriptors (silence flag, envelope, amplitude: hop_kernel's, SA:865-872, 1760-1804): a batch that
-      // computes f0 does not launch a kernel and read the PCM from HBM once more for them; at the end of the frame, where
-      // few registers are live -- the samples are read again, from the cache this frame's loads left them in
-      if (a.hop_here) {
-        double xh[16];
-        load16(x + 16 * lane, xh);
-        scale16<SCALED>(xh, sc);
-        hop_descriptors(xh, hop_energy(xh), env_coef, env_pow, env_scan_of_lane[lane], a.amplitude, a.lay, rec, lane);
       }
     }
   }

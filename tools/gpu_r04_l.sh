@@ -1,6 +1,7 @@
 #!/bin/bash
+# round 4: full GPU tests + fuzz on the product build, then per-kernel A/B of builds on the C4 share
 set -u
 O=gpurun_out/r04x; mkdir -p $O
 timeout 900 python -m pytest tests -q -m gpu -x > $O/pytest_full.log 2>&1; tail -3 $O/pytest_full.log; grep -E "^FAILED|^E  " $O/pytest_full.log | head
-timeout 300 python tests/fuzz_gpu.py 60 61 > $O/fuzz_seed61.log 2>&1; tail -2 $O/fuzz_seed61.log
+timeout 300 python tests/fuzz_gpu.py 60 71 > $O/fuzz_seed71.log 2>&1; tail -2 $O/fuzz_seed71.log
 bash tools/x_kernel_ab.sh "--workload c4 --mask frame" "$@" 2>&1 | tee $O/ab_c4.txt

@@ -326,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   __shared__ u32 s_cut[4][32];
   __shared__ double s_cn[4][48];   // per band: 1 / bins, 1 / neighbours, bins
   __shared__ u32 s_sel[4][8];      // the cut keys of the two bands that lie across a block boundary of the sort
+  __shared__ int s_cutpos[4][32];  // per band: position of the valley's cut key, of the peak's
   __shared__ double s_nat[4][64 * kRows];   // kBandsStats: the frame's bins in natural order for the rolloff walk
   __shared__ LogEntry s_log[4][64];
   __shared__ double s_park[4][4 * kParked * 16];   // [frame of the group][quantity][band]
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   u32* const cut = s_cut[threadIdx.x >> 6];      // [0..15] valley cut key per band, [16..31] peak cut key
   double* const cn = s_cn[threadIdx.x >> 6];
   u32* const sel = s_sel[threadIdx.x >> 6];
+  int* const cutpos = s_cutpos[threadIdx.x >> 6];
   double* const nat = s_nat[threadIdx.x >> 6];
   LogEntry* const logt = s_log[threadIdx.x >> 6];
   double* const park = s_park[threadIdx.x >> 6];
@@ -347,6 +349,14 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     }
     nb = (lane == kWholeBand) ? (double)kBinCount : nb;   // the whole analysis range as one more band (spectral_flux)
     cn[lane] = 1.0 / nb; cn[16 + lane] = 1.0 / nn; cn[32 + lane] = nb;
+    int pv = 0, pp = 1;
+#pragma unroll
+    for (int i = 0; i < kNumSub; ++i) {
+      const int pos0 = (i == 12) ? kSubStart[12] : sub_pos0(i);
+      pv = (lane == i) ? pos0 + kSubNeigh[i] - 1 : pv;
+      pp = (lane == i) ? pos0 + kSubN[i] - kSubNeigh[i] : pp;
+    }
+    cutpos[lane] = pv; cutpos[16 + lane] = pp;
   }
   wave_lds_fence();
 
@@ -564,9 +574,10 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
         if (sub_touches(b, r)) peaks[b] += __popcll(pk & bm[sub_pair_index(b, r)]);
     }
     // hand every lane_v the count of its band ((lane_v >> 2) & 15) now: the scalar counters die before the sort
+    // (v_writelane: the lane that parks band b's sums, 4 b, gets its count -- a select chain over the bands was 43 instructions)
     int cnt = 0;
 #pragma unroll
-    for (int i = 0; i < kNumSub; ++i) cnt = (((lane_v >> 2) & 15) == i) ? peaks[i] : cnt;
+    for (int i = 0; i < kNumSub; ++i) asm("v_writelane_b32 %0, %1, %2" : "+v"(cnt) : "s"(peaks[i]), "n"(4 * i));
 
     // ---- contrast: sort (band, value) keys to find the key at each band's two cuts, then exact sums ----
     // The keys go into bin order (position p = bin: lane p / 16, register p % 16) and each block of 256 positions is
@@ -639,13 +650,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     mask64 ties_v, ties_p;   // bands whose cut goes through a class of equal keys
     {
       const int bl = lane_v & 15;
-      int pv = 0, pp = 1;
-#pragma unroll
-      for (int i = 0; i < kNumSub; ++i) {
-        const int pos0 = (i == 12) ? kSubStart[12] : sub_pos0(i);
-        pv = (bl == i) ? pos0 + kSubNeigh[i] - 1 : pv;
-        pp = (bl == i) ? pos0 + kSubN[i] - kSubNeigh[i] : pp;
-      }
+      const int pv = cutpos[bl], pp = cutpos[16 + bl];   // positions of the two cut keys in the sorted blocks (LDS table)
       const bool band_lane = lane_v < kNumSub;
       u32 kv = sorted[pv], kv_next = sorted[pv + 1], kp = sorted[pp], kp_prev = sorted[pp - 1];
       const bool two_runs = bl == 11 || bl == 13;

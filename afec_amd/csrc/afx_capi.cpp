@@ -168,7 +168,7 @@ struct Workspace {
   hipEvent_t ev_time_join = nullptr;   // the time-domain kernels (autocorrelation, f0, hop) run on the side stream too
   hipEvent_t ev_copy = nullptr;   // the host's waits for the plan's upload / download streams (and, when blocking, for this batch's stream)
   bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_plan_set_blocking_wait)
-  unsigned queue_count = 0;   // value of the device work-queue counter after the launches enqueued so far
+  unsigned queue_count[afx::kQueueSlots] = {};   // values of the device work-queue counters after the launches enqueued so far
   Buf pcm, chunks, wchunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff, rt_long, rt_polar;   // rhythm tracker
   Buf stat_tmp;                                                                 // half-wave statistics class
@@ -906,14 +906,16 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
     b->d_chunks = (afx::Chunk*)w.chunks.p;
     if ((e = hipMemcpyAsync(b->d_chunks, chunks.data(), chunks.size() * sizeof(afx::Chunk), hipMemcpyHostToDevice, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemcpy(chunks)"));
   }
-  if (b->n_chunks > 0 && b->halfwave) {
+  if (b->n_chunks > 0) {
     if (!w.queue.p) {
-      // zeroed once: every launch advances the counter by its number of chunk pairs (afx_frames32.hip)
-      if ((e = ws_reserve(w.queue, 64)) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(queue)"));
-      if ((e = hipMemsetAsync(w.queue.p, 0, 64, b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemset(queue)"));
-      w.queue_count = 0;
+      // zeroed once: every launch advances its counter by its number of items (afx_internal.h: WorkQueue)
+      if ((e = ws_reserve(w.queue, afx::kQueueSlots * sizeof(unsigned))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(queue)"));
+      if ((e = hipMemsetAsync(w.queue.p, 0, afx::kQueueSlots * sizeof(unsigned), b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipMemset(queue)"));
+      for (unsigned& c : w.queue_count) c = 0;
     }
     b->d_queue = (unsigned*)w.queue.p;
+  }
+  if (b->n_chunks > 0 && b->halfwave) {
     if (fmask != 1u) {   // statistics class: raw sums per frame for its closed-form kernel
       if ((e = ws_reserve(w.stat_tmp, (size_t)frames * afx::frames32_stat_tmp_doubles() * sizeof(double))) != hipSuccess) return cleanup(hip_fail(e, "hipMalloc(stat_tmp)"));
       b->d_stat_tmp = (double*)w.stat_tmp.p;
@@ -1589,8 +1591,19 @@ int afx_batch_run(afx_batch* b) {
     const bool want_hop = (b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) || post_amplitude;
     ta.hop_here = (want_hop && (b->mask & AFX_D_F0)) ? 1u : 0u;
     if (want_hop && !ta.hop_here) HIP_TRY(afx::launch_hop(ta, ts));
-    if (b->mask & AFX_D_F0) HIP_TRY(afx::launch_pitch(ta, ts));
-    if (b->mask & AFX_D_AUTO_CORRELATION) HIP_TRY(afx::launch_acorr(ta, ts));
+    auto queue_for = [&](int slot) {
+      afx::WorkQueue q{b->d_queue ? b->d_queue + slot : nullptr, b->ws->queue_count[slot]};
+      if (q.counter) b->ws->queue_count[slot] += (unsigned)b->n_chunks;
+      return q;
+    };
+    if (b->mask & AFX_D_F0) {
+      ta.queue = queue_for(afx::kQueuePitch);
+      HIP_TRY(afx::launch_pitch(ta, ts));
+    }
+    if (b->mask & AFX_D_AUTO_CORRELATION) {
+      ta.queue = queue_for(afx::kQueueAcorr);
+      HIP_TRY(afx::launch_acorr(ta, ts));
+    }
     if (time_side) HIP_TRY(hipEventRecord(b->ws->ev_time_join, ts));
   }
   {
@@ -1634,8 +1647,8 @@ int afx_batch_run(afx_batch* b) {
 #endif
     if (b->halfwave) {
       a.queue = b->d_queue;
-      a.queue_base = b->ws->queue_count;
-      b->ws->queue_count += (unsigned)((b->n_chunks + 1) / 2);
+      a.queue_base = b->ws->queue_count[afx::kQueueFrames32];
+      b->ws->queue_count[afx::kQueueFrames32] += (unsigned)((b->n_chunks + 1) / 2);
       a.stat_tmp = b->d_stat_tmp;
       a.mag_spare_row = b->total_frames;
       HIP_TRY(afx::launch_frames32(a, b->grid_blocks, b->stream, b->total_frames, b->pcm_dtype == afx::kPcmScaledF32));

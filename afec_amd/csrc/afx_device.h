@@ -209,6 +209,14 @@ __device__ __forceinline__ double wave_uniform(double v) {
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
+// the wave's next item of a WorkQueue launch (afx_internal.h): n_static = min(waves of the grid, items)
+__device__ __forceinline__ int next_item(const WorkQueue& q, int current, int n_static, int stride, int lane) {
+  if (!q.counter) return current + stride;
+  unsigned drawn = 0;
+  if (lane == 0) drawn = atomicAdd(q.counter, 1u);
+  return n_static + (int)((unsigned)__builtin_amdgcn_readfirstlane((int)drawn) - q.base);
+}
+
 // a * b rounded to a double of its own: never fused into the addition that consumes it.  For values that two code paths
 // must compute alike (a sum carried from frame to frame and the same sum recomputed where a chunk starts): whether the
 // compiler contracts a product into an fma depends on the code around it.

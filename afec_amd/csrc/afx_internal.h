@@ -175,7 +175,19 @@ hipError_t launch_bands(const BandArgs& a, hipStream_t stream);
 
 // ---- neighbours of the spectral set ----
 // time-domain descriptors of every frame, one wave per chunk (afx_time.hip)
+// Work queue of a persistent-grid launch: a wave starts with the item of its own index and draws every further one from
+// a device counter (one atomic per item), instead of a static stride -- of the two waves that share a SIMD the older one
+// wins the issue arbitration and CUs differ, so equal shares do not finish together.  The counter is never reset: a
+// launch advances it by exactly its number of items (a draw follows every processed item), and the host passes its value
+// at launch.  counter == nullptr: static stride.
+struct WorkQueue {
+  unsigned* counter;
+  unsigned base;
+};
+enum { kQueueFrames32 = 0, kQueuePitch = 1, kQueueAcorr = 2, kQueueSlots = 16 };
+
 struct TimeArgs {
+  WorkQueue queue;        // pitch_kernel, acorr_kernel (set per launch)
   const void* pcm;
   const Chunk* chunks;
   const ChunkRemaining* remaining;

@@ -293,7 +293,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void acorr_kernel(const TimeArgs a
   constexpr int kSeg = 640;           // staged samples per frame: rows start/64 .. start/64 + 9
   constexpr double kScale = 1.0 / 4096.0;   // the transforms return 4 N r
 
-  for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
+  for (int ci = wave_global; ci < a.n_chunks; ci = next_item(a.queue, ci, min(wave_stride, a.n_chunks), wave_stride, lane)) {
     const Chunk ch = a.chunks[ci];
     const double sc = SCALED ? wave_uniform(ch.scale) : 1.0;
     const int remaining0 = a.remaining[ci];
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(kTimeWaves * 64) void pitch_kernel(const TimeArgs a
   __syncthreads();
   constexpr int kBig = 1 << 30;
 
-  for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
+  for (int ci = wave_global; ci < a.n_chunks; ci = next_item(a.queue, ci, min(wave_stride, a.n_chunks), wave_stride, lane)) {
     const Chunk ch = a.chunks[ci];
     const double sc = SCALED ? wave_uniform(ch.scale) : 1.0;
     // transform of the zero-padded first half of the chunk's first frame (packed z[m] = x[2m] + i x[2m+1])

@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   const mask64 first_row_ok = __ballot(lane >= kFirstBin);                        // bins 1..63
   const mask64 last_row_ok = __ballot(64 * (kRows - 1) + lane <= kLastBin);       // bins 704..738
 
-  for (int ci = wave0; ci < a.n_chunks; ci += stride) {
+  for (int ci = wave0; ci < a.n_chunks; ci = next_item(a.queue, ci, min(stride, a.n_chunks), stride, lane)) {
     const Chunk ch = a.chunks[ci];
     double x[kRows], y[kRows];
     // the frame before the chunk; the first frame of a buffer is compared with itself (SA:937-940)
@@ -762,13 +762,17 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
 hipError_t launch_bands(const BandArgs& a, hipStream_t stream) {
   if (a.n_chunks <= 0) return hipSuccess;
   const int want = (a.n_chunks + 3) / 4;
-  const int grid = want < 256 * 16 ? want : 256 * 16;
   constexpr int kAll = kBandsFeatures | kBandsFlux;
-  if (a.flags == kAll) hipLaunchKernelGGL(bands_kernel<kAll>, dim3(grid), dim3(256), 0, stream, a);
-  else if (a.flags == (kAll | kBandsSpectrum)) hipLaunchKernelGGL(bands_kernel<kAll | kBandsSpectrum>, dim3(grid), dim3(256), 0, stream, a);
-  else if (a.flags == (kAll | kBandsSpectrum | kBandsStats))
-    hipLaunchKernelGGL(bands_kernel<kAll | kBandsSpectrum | kBandsStats>, dim3(grid), dim3(256), 0, stream, a);
-  else hipLaunchKernelGGL(bands_kernel<-1>, dim3(grid), dim3(256), 0, stream, a);
+  auto launch = [&](auto kernel) {
+    // with a work queue: the workgroups that are resident at once, each wave drawing chunks until there are none
+    static const int resident = resident_blocks(kernel, 256, 0);
+    const int cap = a.queue.counter ? resident : 256 * 16;
+    hipLaunchKernelGGL(kernel, dim3(want < cap ? want : cap), dim3(256), 0, stream, a);
+  };
+  if (a.flags == kAll) launch(bands_kernel<kAll>);
+  else if (a.flags == (kAll | kBandsSpectrum)) launch(bands_kernel<kAll | kBandsSpectrum>);
+  else if (a.flags == (kAll | kBandsSpectrum | kBandsStats)) launch(bands_kernel<kAll | kBandsSpectrum | kBandsStats>);
+  else launch(bands_kernel<-1>);
   return hipGetLastError();
 }
 

@@ -1572,6 +1572,12 @@ int afx_batch_run(afx_batch* b) {
   const uint32_t post_amplitude = (b->total_frames > 0 && b->halfwave && afx::frames32_class(frames_mask(b->mask)) >= 2)
                                       ? (b->mask & (AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS)) : 0u;
   const bool time_work = b->total_frames > 0 && ((b->mask & kTimeBits) || post_amplitude);
+  // a kernel's work queue (afx_internal.h): its counter in the workspace and the counter's value when the launch starts
+  auto queue_for = [&](int slot, int items) {
+    afx::WorkQueue q{b->d_queue ? b->d_queue + slot : nullptr, b->ws->queue_count[slot]};
+    if (q.counter) b->ws->queue_count[slot] += (unsigned)items;
+    return q;
+  };
   // (not with the rhythm tracker selected: its chain, the longer one, has the side stream then -- 21.7 against 21.2 M frames/s
   // on the C4 share with everything selected; without it 34.4 against 33.9 M on C3)
   const bool time_side = time_work && b->plan->side_stream && frames_mask(b->mask) != 0 && !(b->mask & AFX_D_RHYTHM);
@@ -1591,17 +1597,12 @@ int afx_batch_run(afx_batch* b) {
     const bool want_hop = (b->mask & (AFX_D_AMPLITUDE_SILENCE | AFX_D_AMPLITUDE_ENVELOPE)) || post_amplitude;
     ta.hop_here = (want_hop && (b->mask & AFX_D_F0)) ? 1u : 0u;
     if (want_hop && !ta.hop_here) HIP_TRY(afx::launch_hop(ta, ts));
-    auto queue_for = [&](int slot) {
-      afx::WorkQueue q{b->d_queue ? b->d_queue + slot : nullptr, b->ws->queue_count[slot]};
-      if (q.counter) b->ws->queue_count[slot] += (unsigned)b->n_chunks;
-      return q;
-    };
     if (b->mask & AFX_D_F0) {
-      ta.queue = queue_for(afx::kQueuePitch);
+      ta.queue = queue_for(afx::kQueuePitch, b->n_chunks);
       HIP_TRY(afx::launch_pitch(ta, ts));
     }
     if (b->mask & AFX_D_AUTO_CORRELATION) {
-      ta.queue = queue_for(afx::kQueueAcorr);
+      ta.queue = queue_for(afx::kQueueAcorr, b->n_chunks);
       HIP_TRY(afx::launch_acorr(ta, ts));
     }
     if (time_side) HIP_TRY(hipEventRecord(b->ws->ev_time_join, ts));
@@ -1664,6 +1665,7 @@ int afx_batch_run(afx_batch* b) {
     ba.flags = ((b->mask & AFX_D_BAND_FEATURES) ? afx::kBandsFeatures : 0) | ((b->mask & AFX_D_SPECTRAL_FLUX) ? afx::kBandsFlux : 0) |
                (bands28_later ? afx::kBandsSpectrum : 0) | (stats_later ? afx::kBandsStats : 0);
     ba.stat_tmp = b->d_stat_tmp;
+    ba.queue = queue_for(afx::kQueueBands, b->n_chunks);
     HIP_TRY(afx::launch_bands(ba, b->stream));
     if (stats_later) {
       afx::FrameArgs fa{};
@@ -1682,6 +1684,7 @@ int afx_batch_run(afx_batch* b) {
     // SampleAnalyser.cpp:44, 805-809
     wa.decay = std::pow(0.001, (double)((float)b->plan->desc.hop_size / (float)b->plan->desc.sample_rate) / 22.0);
     wa.floor_value = 1.e-4;
+    wa.queue = queue_for(afx::kQueueWhiten, b->n_wchunks);
     HIP_TRY(afx::launch_whiten(wa, b->stream));
   }
   if (b->d_stats) {

@@ -158,8 +158,32 @@ int frames32_class(uint32_t frames_mask);   // 0 = MFCC only, 1 = + spectral sta
 // and the fail-safe f0 of afx_whiten.hip, the magnitude output) -- the half-wave full class then produces them
 int frames_feature_class(uint32_t mask);     // 0 = MFCC only, 1 = + statistics, 2 = everything
 
+// Work queue of a persistent-grid launch: a wave starts with the item of its own index and draws every further one from
+// a device counter (one atomic per item), instead of a static stride -- of the two waves that share a SIMD the older one
+// wins the issue arbitration and CUs differ, so equal shares do not finish together.  The counter is never reset: a
+// launch advances it by exactly its number of items (a draw follows every processed item), and the host passes its value
+// at launch.  counter == nullptr: static stride.
+struct WorkQueue {
+  unsigned* counter;
+  unsigned base;
+};
+enum { kQueueFrames32 = 0, kQueuePitch = 1, kQueueAcorr = 2, kQueueBands = 3, kQueueWhiten = 4, kQueueSlots = 16 };
+// workgroups of `kernel` that are resident on the device at once (a WorkQueue launch must not be larger: the static first
+// items of workgroups that start late would be processed last, by few waves)
+template <typename K>
+int resident_blocks(K kernel, int threads, size_t dynamic_lds) {
+  int per_cu = 0, cus = 256, dev = 0;
+  if (hipGetDevice(&dev) == hipSuccess) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+  }
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, dynamic_lds) != hipSuccess || per_cu < 1) per_cu = 1;
+  return per_cu * cus;
+}
+
 // band-feature kernel (SampleAnalyser.cpp:2067-2308) working from stored magnitudes
 struct BandArgs {
+  WorkQueue queue;
   const double* mag;    // [F][1024]
   const Chunk* chunks;  // runs of consecutive frames of one buffer (kChunkFirstOfBuffer marks frame 0)
   int32_t n_chunks;
@@ -175,17 +199,6 @@ hipError_t launch_bands(const BandArgs& a, hipStream_t stream);
 
 // ---- neighbours of the spectral set ----
 // time-domain descriptors of every frame, one wave per chunk (afx_time.hip)
-// Work queue of a persistent-grid launch: a wave starts with the item of its own index and draws every further one from
-// a device counter (one atomic per item), instead of a static stride -- of the two waves that share a SIMD the older one
-// wins the issue arbitration and CUs differ, so equal shares do not finish together.  The counter is never reset: a
-// launch advances it by exactly its number of items (a draw follows every processed item), and the host passes its value
-// at launch.  counter == nullptr: static stride.
-struct WorkQueue {
-  unsigned* counter;
-  unsigned base;
-};
-enum { kQueueFrames32 = 0, kQueuePitch = 1, kQueueAcorr = 2, kQueueSlots = 16 };
-
 struct TimeArgs {
   WorkQueue queue;        // pitch_kernel, acorr_kernel (set per launch)
   const void* pcm;
@@ -209,6 +222,7 @@ hipError_t launch_pitch(const TimeArgs& a, hipStream_t stream);    // f0, f0 con
 // the stored magnitudes; runs after launch_pitch.  Two kernels: the follower recurrence alone, one wave per
 // (buffer, 64 bins), leaves its state at every chunk start; then one wave per chunk does the per-frame work.
 struct WhitenArgs {
+  WorkQueue queue;              // whiten_kernel
   const double* mag;            // [F][1024]
   const int64_t* frame_offset;  // [n_bufs + 1], device
   const int32_t* chunk_first;   // [n_bufs + 1]: index of the buffer's first chunk in `chunks`

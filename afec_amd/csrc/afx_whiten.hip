@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void whiten_kernel(const WhitenArgs a) {
   const bool want_cplx = (a.mask & AFX_D_SPECTRAL_COMPLEXITY) != 0;
   const bool want_f0 = (a.mask & AFX_D_F0) != 0;
 
-  for (int ci = wave_global; ci < a.n_chunks; ci += wave_stride) {
+  for (int ci = wave_global; ci < a.n_chunks; ci = next_item(a.queue, ci, min(wave_stride, a.n_chunks), wave_stride, lane)) {
     const Chunk ch = a.chunks[ci];
     const int64_t f_begin = ch.frame0, f_end = f_begin + ch.nframes;
     double follow[16];
@@ -186,7 +186,9 @@ hipError_t launch_whiten(const WhitenArgs& a, hipStream_t stream) {
     if (e != hipSuccess) return e;
   }
   const int want = (a.n_chunks + 3) / 4;
-  hipLaunchKernelGGL(whiten_kernel, dim3(want < 8192 ? want : 8192), dim3(256), 0, stream, a);
+  static const int resident = resident_blocks(whiten_kernel, 256, 0);
+  const int cap = a.queue.counter ? resident : 8192;
+  hipLaunchKernelGGL(whiten_kernel, dim3(want < cap ? want : cap), dim3(256), 0, stream, a);
   return hipGetLastError();
 }
 

@@ -236,12 +236,30 @@ __device__ __forceinline__ void merge_tail(u32 (&key)[16], int lane) {
   else inlane_stage<J>(key);
   if constexpr (J > 1) merge_tail<K, J / 2>(key, lane);
 }
+// a lane's sixteen keys ascending: the 60-comparator network for 16 inputs (ten layers; checked on all 2^16 0-1 inputs) --
+// the levels K <= 16 of the bitonic network are 80 comparators
+__device__ __forceinline__ void sort16_inlane(u32 (&key)[16]) {
+  constexpr int kNet[60][2] = {
+      {0, 13}, {1, 12}, {2, 15}, {3, 14}, {4, 8}, {5, 6}, {7, 11}, {9, 10}, {0, 5}, {1, 7}, {2, 9}, {3, 4}, {6, 13}, {8, 14}, {10, 15},
+      {11, 12}, {0, 1}, {2, 3}, {4, 5}, {6, 8}, {7, 9}, {10, 11}, {12, 13}, {14, 15}, {0, 2}, {1, 3}, {4, 10}, {5, 11}, {6, 7}, {8, 9},
+      {12, 14}, {13, 15}, {1, 2}, {3, 12}, {4, 6}, {5, 7}, {8, 10}, {9, 11}, {13, 14}, {1, 4}, {2, 6}, {5, 8}, {7, 10}, {9, 13}, {11, 14},
+      {2, 4}, {3, 6}, {9, 12}, {11, 13}, {3, 5}, {6, 8}, {7, 9}, {10, 12}, {3, 4}, {5, 6}, {7, 8}, {9, 10}, {11, 12}, {6, 7}, {8, 9}};
+#pragma unroll
+  for (int c = 0; c < 60; ++c) {
+    const u32 a = key[kNet[c][0]], b = key[kNet[c][1]];
+    key[kNet[c][0]] = a < b ? a : b;
+    key[kNet[c][1]] = a < b ? b : a;
+  }
+}
 template <int K>
 __device__ __forceinline__ void sort_level(u32 (&key)[16], int lane) {
-  if constexpr (K > 2) sort_level<K / 2>(key, lane);
-  if constexpr (K <= 16) inlane_stage<K - 1>(key);          // flip inside the lane
-  else crosslane_stage<(K >> 4) - 1, 15>(key, lane);        // flip across lanes: lane ^ (K/16 - 1), reg ^ 15
-  if constexpr (K >= 4) merge_tail<K, K / 4>(key, lane);
+  if constexpr (K == 16) {
+    sort16_inlane(key);
+  } else {
+    sort_level<K / 2>(key, lane);
+    crosslane_stage<(K >> 4) - 1, 15>(key, lane);        // flip across lanes: lane ^ (K/16 - 1), reg ^ 15
+    merge_tail<K, K / 4>(key, lane);
+  }
 }
 
 // sort key of a magnitude inside band b: band << 27 | float bits >> 4 (rounded): 19 mantissa bits order the values

@@ -848,7 +848,17 @@ int build_batch(afx_plan* plan, int32_t n_bufs, uint32_t mask, int dtype, const 
 #else
       const double prologue = b->halfwave ? kHalfwavePrologue : 0.5;
 #endif
-      const double cost = (double)((nchunks + slots - 1) / slots) * (k + prologue);
+      // The 64-lane frame kernel gives every wave the same number of chunks: rounds of the wave slots x (frames per chunk
+      // + lead-in).  Every kernel of the half-wave batches draws its chunks from a work queue: the slots share the work
+      // (frames + lead-ins) evenly and run dry within a fraction of a chunk of each other.
+      // (the 0.4: measured -- C3, 1 000 files of 82 frames: K = 6, 39.3 M frames/s against 35.8 M with the K = 22 of the
+      // rounds model; the headline batch K = 32, 499 against 495 M with K = 25; the C4 share K = 10, 41.6 against 42.3 M
+      // with K = 8; tools/gpu_r04_k.sh)
+#ifndef AFX_X_TAIL
+#define AFX_X_TAIL 0.4
+#endif
+      const double cost = b->halfwave ? ((double)frames + (double)nchunks * prologue) / (double)slots + AFX_X_TAIL * k
+                                      : (double)((nchunks + slots - 1) / slots) * (k + prologue);
       if (cost < best - 1e-9 || (std::fabs(cost - best) <= 1e-9 && k > K)) { best = cost; K = k; }
     }
   }

@@ -347,10 +347,6 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   __shared__ int s_cutpos[4][32];  // per band: position of the valley's cut key, of the peak's
   __shared__ double s_nat[4][64 * kRows];   // kBandsStats: the frame's bins in natural order for the rolloff walk
   __shared__ LogEntry s_log[4][64];
-#if defined(AFX_X_WARM)
-  __shared__ double s_warm[4][128];
-  double* const warm = s_warm[threadIdx.x >> 6];
-#endif
   __shared__ double s_park[4][4 * kParked * 16];   // [frame of the group][quantity][band]
   double* const thr = s_thr[threadIdx.x >> 6];
   u32* const sorted = s_sorted[threadIdx.x >> 6];
@@ -448,16 +444,6 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     const double* const cur = a.mag + f * kHalf;
 #pragma unroll
     for (int r = 0; r < kRows; ++r) x[r] = cur[64 * r + lane_v];
-#if defined(AFX_X_WARM)
-    // experiment: the next frame's 6 KiB pulled towards the CU by LDS-DMA into a dump area while this frame is worked on
-    if (fi + 1 < ch.nframes) {
-      const double* const nxt = cur + kHalf + 2 * lane_v;
-      const unsigned dump = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) void*)warm);
-#pragma unroll
-      for (int j = 0; j < 6; ++j)
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(nxt + 128 * j), "s"(dump) : "memory", "m0");
-    }
-#endif
     // products rounded on their own (mul_rn): see the chunk prologue
     double xx[kRows], xy[kRows];
 #pragma unroll

@@ -98,13 +98,6 @@ __global__ __launch_bounds__(256) void whiten_kernel(const WhitenArgs a) {
 #pragma unroll
       for (int i = 0; i < 16; ++i) cur[i] = m[i];
       if ((want_cplx || want_f0) && f + 1 < f_end) load_bins(a.mag + (f + 1) * kHalf + 16 * lane, m);
-      // what the pitch kernel left for this frame (lane 0 needs it at the end of the iteration: asked for here)
-      double left_f0 = 0.0, left_conf = 0.0, left_silent = 0.0;
-      if (want_f0 && lane == 0) {
-        left_f0 = rec[a.lay.f0];
-        left_conf = rec[a.lay.f0_conf];
-        left_silent = rec[a.lay.f0_safe];                        // parked there by pitch_kernel
-      }
 
       if (want_cplx) {
         double w[16], top = 0.0;
@@ -163,8 +156,8 @@ __global__ __launch_bounds__(256) void whiten_kernel(const WhitenArgs a) {
         s = wave_sum(s);
         sk = wave_sum(sk);
         if (lane == 0) {
-          const double f0 = left_f0, conf = left_conf;
-          const bool silent = left_silent != 0.0;
+          const double f0 = rec[a.lay.f0], conf = rec[a.lay.f0_conf];
+          const bool silent = rec[a.lay.f0_safe] != 0.0;         // parked there by pitch_kernel
           double safe = 0.0;
           if (f0 > 0.0 && conf > 0.2) safe = f0;                 // MLowPitchConfidenceValue, SA:64, 897-901
           else if (!silent) {

@@ -272,3 +272,39 @@ def test_page_locked_blocks_of_every_size_class():
     np.testing.assert_array_equal(a["spectral_centroid"], b["spectral_centroid"])
     p.close()
     del pinned, owner
+
+
+def test_side_stream_and_queue_order_do_not_change_a_result():
+    """The time-domain kernels and the rhythm tracker run beside the spectral chain on the workspace's side stream, and the
+    time-domain / band / whitening kernels draw their chunks from device work queues whose order differs from run to run:
+    the same batch on a plan with AFX_PLAN_NO_SIDE_STREAM, and run again and again on one plan, gives the same bits."""
+    rng = np.random.default_rng(91)
+    t = np.arange(44100)
+    pool = [np.round(9000 * rng.uniform(-1, 1, 44100)).astype(np.int16),
+            np.round(12000 * np.sin(2 * np.pi * 330 * t / 44100) * np.exp(-t / 15000.0)).astype(np.int16),
+            np.round(4000 * rng.standard_normal(44100) * (t % 8000 < 1500)).astype(np.int16)]
+    raws = [(pool[i % 3], 1) for i in range(700)]
+    results = []
+    for flags in (0, afx.PLAN_NO_SIDE_STREAM):
+        plan = afx.Plan(flags=flags)
+        for mask in (afx.D_ALL_PER_FRAME | afx.D_STATISTICS, afx.D_ALL_PER_FRAME | afx.D_STATISTICS | afx.D_RHYTHM):
+            b, _ = plan.batch_from_raw(raws, mask)
+            runs = []
+            for _ in range(3):
+                b.run()
+                res, st = b.fetch(), b.fetch_statistics()
+                res.update({"stat_" + k: v for k, v in st.items()})
+                if mask & afx.D_RHYTHM:
+                    r = b.fetch_rhythm(onset_functions=True)
+                    res.update({"rhythm_" + k: v for k, v in r.items() if isinstance(v, np.ndarray)})
+                runs.append(res)
+            for k in runs[0]:
+                np.testing.assert_array_equal(runs[0][k], runs[1][k], err_msg=k)
+                np.testing.assert_array_equal(runs[0][k], runs[2][k], err_msg=k)
+            results.append(runs[0])
+            b.close()
+        plan.close()
+    for with_side, without in ((results[0], results[2]), (results[1], results[3])):
+        assert with_side.keys() == without.keys()
+        for k in with_side:
+            np.testing.assert_array_equal(with_side[k], without[k], err_msg=k)

@@ -1579,7 +1579,10 @@ int afx_batch_run(afx_batch* b) {
   // the whitening kernel reads what the pitch kernel left (f0, its confidence, the hop's silence flag).  One kernel at a
   // time leaves the tail of every launch to a partly idle chip (a crawl's batch is 10-40 waves per SIMD per kernel).
   const DeviceTables& t = b->plan->dev;
-  const uint32_t post_amplitude = (b->total_frames > 0 && b->halfwave && afx::frames32_class(frames_mask(b->mask)) >= 2)
+  // the half-wave full classes (2, 3) leave the amplitude of the hop to hop_kernel / pitch_kernel; the magnitude class (4)
+  // has the hop in registers at the top of a frame and writes it itself
+  const int frame_class = b->halfwave ? afx::frames32_class(frames_mask(b->mask)) : -1;
+  const uint32_t post_amplitude = (b->total_frames > 0 && (frame_class == 2 || frame_class == 3))
                                       ? (b->mask & (AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS)) : 0u;
   const bool time_work = b->total_frames > 0 && ((b->mask & kTimeBits) || post_amplitude);
   // a kernel's work queue (afx_internal.h): its counter in the workspace and the counter's value when the launch starts

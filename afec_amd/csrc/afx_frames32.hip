@@ -383,6 +383,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         }
         // window products fused into the first radix-4 stage of P1 (rows j, j + 8 from the overlap half, rows
         // j + 16, j + 24 from the new hop): a w_a +- c w_c as one product and two fused multiply-adds
+        double hop_sq = 0.0, hop_max = 0.0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           auto first = [](double pair) { return __int_as_float(__double2loint(pair)); };
@@ -391,6 +392,10 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           const double br = pcm_double<SCALED>(first(lo[j + 8]), sc), bi = pcm_double<SCALED>(second(lo[j + 8]), sc);
           const double cr = pcm_double<SCALED>(first(nx[j]), sc), ci = pcm_double<SCALED>(second(nx[j]), sc);
           const double dr = pcm_double<SCALED>(first(nx[j + 8]), sc), di = pcm_double<SCALED>(second(nx[j + 8]), sc);
+          if constexpr (MAGS) {   // the hop (rows 0..15 of the frame) is in registers here: its amplitude (SA:1760-1783)
+            hop_sq = fma(ar, ar, fma(ai, ai, fma(br, br, fma(bi, bi, hop_sq))));
+            hop_max = fmax(fmax(hop_max, fmax(fabs(ar), fabs(ai))), fmax(fabs(br), fabs(bi)));
+          }
           const double par = ar * w[j].x, pai = ai * w[j].y, pbr = br * w[j + 8].x, pbi = bi * w[j + 8].y;
           const double t0r = fma(cr, w[j + 16].x, par), t0i = fma(ci, w[j + 16].y, pai);
           const double t1r = fma(-cr, w[j + 16].x, par), t1i = fma(-ci, w[j + 16].y, pai);
@@ -404,6 +409,24 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         if constexpr (!LO_LDS) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) lo[r] = nx[r];
+        }
+        if constexpr (MAGS) {
+          // amplitude_peak / amplitude_rms of the hop, reduced over the half's 32 lanes (magnitude class: no hop_kernel
+          // launch and no second pass over the PCM for masks without f0)
+          if (a.mask & ((1u << 11) | (1u << 12))) {   // AFX_D_AMPLITUDE_PEAK | AFX_D_AMPLITUDE_RMS
+            hop_sq += dpp_or_zero<kDppXor1>(hop_sq);      hop_max = fmax(hop_max, dpp_mov<kDppXor1>(hop_max));
+            hop_sq += dpp_or_zero<kDppXor2>(hop_sq);      hop_max = fmax(hop_max, dpp_mov<kDppXor2>(hop_max));
+            hop_sq += dpp_or_zero<kDppHalfMirror>(hop_sq); hop_max = fmax(hop_max, dpp_mov<kDppHalfMirror>(hop_max));
+            hop_sq += dpp_or_zero<kDppMirror>(hop_sq);    hop_max = fmax(hop_max, dpp_mov<kDppMirror>(hop_max));
+            // the two rows of a half: lane 0 / 16 of half 0, 32 / 48 of half 1
+            const double sq_h = h ? read_lane<32>(hop_sq) + read_lane<48>(hop_sq) : read_lane<0>(hop_sq) + read_lane<16>(hop_sq);
+            const double mx_h = h ? fmax(read_lane<32>(hop_max), read_lane<48>(hop_max)) : fmax(read_lane<0>(hop_max), read_lane<16>(hop_max));
+            if (q == 0 && fi < nfr) {
+              double* const rec = a.rec + ((int64_t)ch.frame0 + fi) * a.lay.stride;
+              if ((a.mask & (1u << 11)) && a.lay.amp_peak >= 0) rec[a.lay.amp_peak] = mx_h;
+              if ((a.mask & (1u << 12)) && a.lay.amp_rms >= 0) rec[a.lay.amp_rms] = nan_to_zero(sqrt(sq_h / (double)kHop));
+            }
+          }
         }
       }
       __builtin_amdgcn_sched_barrier(0);

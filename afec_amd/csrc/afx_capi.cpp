@@ -169,6 +169,7 @@ struct Workspace {
   hipEvent_t ev_copy = nullptr;   // the host's waits for the plan's upload / download streams (and, when blocking, for this batch's stream)
   bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_plan_set_blocking_wait)
   unsigned queue_count[afx::kQueueSlots] = {};   // values of the device work-queue counters after the launches enqueued so far
+  bool queue_dirty = false;                      // a run failed between counting a launch and enqueuing it: reset both before the next
   Buf pcm, chunks, wchunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff, rt_long, rt_polar;   // rhythm tracker
   Buf stat_tmp;                                                                 // half-wave statistics class
@@ -1570,9 +1571,27 @@ int afx_batch_get_info(const afx_batch* b, afx_batch_info* info) {
   return AFX_OK;
 }
 
+static int batch_run_enqueue(afx_batch* b);
+
 int afx_batch_run(afx_batch* b) {
   if (!b) return fail(AFX_ERR_INVALID_ARG, "null batch");
   HIP_TRY(hipSetDevice(b->plan->desc.device));
+  Workspace* const ws = b->ws;
+  if (ws && ws->queue_dirty && ws->queue.p) {
+    // a run that failed part-way left the work-queue counters and the host's record of them apart (a launch that was
+    // counted and never ran): everything of that run is drained, then both start from zero again
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (ws->side_stream) HIP_TRY(hipStreamSynchronize(ws->side_stream));
+    HIP_TRY(hipMemsetAsync(ws->queue.p, 0, afx::kQueueSlots * sizeof(unsigned), b->stream));
+    for (unsigned& c : ws->queue_count) c = 0;
+    ws->queue_dirty = false;
+  }
+  const int st = batch_run_enqueue(b);
+  if (st != AFX_OK && ws) ws->queue_dirty = true;
+  return st;
+}
+
+static int batch_run_enqueue(afx_batch* b) {
   b->ran = true;
   // The time-domain kernels (autocorrelation, f0, the hop's descriptors) read the PCM only and the spectral chain
   // (STFT, bands) does not need them: they go to the side stream, ahead of the rhythm tracker's, and are joined where

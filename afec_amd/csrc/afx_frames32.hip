@@ -105,11 +105,6 @@ __device__ __forceinline__ double mag_sqrt_mel(double xr, double xi, double tiny
 // under EXEC = {0, 32} put their values in place, instead of four v_cndmask_b32 per row.  EXEC is saved and restored
 // (the kernel's control flow is wave-uniform where this is called, but nothing here depends on that).
 __device__ __forceinline__ void keep_lane0(double& re, double& im, double own_re, double own_im, unsigned long long lane0_mask) {
-#if defined(AFX_X_OLDASM)   // timing experiment only: round 3's form (EXEC restored to the constant -1, not volatile)
-  asm("s_mov_b64 exec, %4\n\tv_mov_b64 %0, %2\n\tv_mov_b64 %1, %3\n\ts_mov_b64 exec, -1"
-      : "+v"(re), "+v"(im) : "v"(own_re), "v"(own_im), "s"(lane0_mask));
-  return;
-#endif
   unsigned long long saved;
   asm volatile("s_mov_b64 %2, exec\n\ts_mov_b64 exec, %5\n\tv_mov_b64 %0, %3\n\tv_mov_b64 %1, %4\n\ts_mov_b64 exec, %2"
                : "+v"(re), "+v"(im), "=&s"(saved) : "v"(own_re), "v"(own_im), "s"(lane0_mask));

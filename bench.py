@@ -7,9 +7,12 @@ Workload (BASELINE.json configs[1], "C2"): 2048/1024 STFT + 14-coefficient MFCC 
 larger batches tile those -- every copy has its own place in HBM).  One *step* = one pass of the HIP path over that
 whole batch, PCM already resident in HBM.  The batch is sized so that a step takes ~10 ms: from an idle GPU the clocks
 need ~30 ms of load to settle (the first 25 launches of a 1.3 ms step run 5-15 % slower, profiles/r03/clock_ramp.txt),
-and a handful of warm-up steps must cover that.  N>1: one process per GPU (torchrun), every rank owns its own batch
+and a handful of warm-up steps must cover that.  N>1: one process per GPU, every rank owns its own batch
 (files are sharded, no data-path collective) -> weak scaling; value = frames all ranks processed
-/ max-over-ranks time.
+/ max-over-ranks time.  The ranks come from an outside launcher (torchrun: RANK / LOCAL_RANK / WORLD_SIZE in the
+environment) or, run plainly as `python bench.py --gpus N`, from this script itself: before anything touches the
+GPU it starts N children of itself with those variables set (launch_ranks), relays rank 0's line and fails when
+any child does -- the crawler's own fan-out of one self-contained task per file (Crawler.cpp:706-728) one level up.
 
 Prints ONE JSON line on rank 0.
 """
@@ -68,7 +71,70 @@ def parse_args():
                     help="AFX_PLAN_NO_SIDE_STREAM: the rhythm tracker's kernels on the batch's own stream (profiles: a "
                          "kernel's duration is then its own)")
     ap.add_argument("--no-spot-check", action="store_true", help="skip the parity spot check of the timed batch")
+    ap.add_argument("--no-chain-rates", action="store_true",
+                    help="skip the C3 / C4-share chain rates (BASELINE configs[2] / [3]) of the default line")
+    # test hook of the launcher (tests/test_bench_dist_cpu.py): this rank exits with status 7 before it joins the others
+    ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
     return ap.parse_args()
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_gpus, argv, poll_s=0.05):
+    """`python bench.py --gpus N` with no launcher around it: N child processes of this very script, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set -- what torchrun would export.  Called before this
+    process has touched the GPU (nothing is ever exec'ed over an initialised one: the children are new processes and
+    this one only waits).  Rank 0's stdout is relayed; when a child fails the others are ended (by the PIDs started
+    here) and the failing status is returned -- a rank waiting in a barrier for a dead peer must not hang the job.
+    Returns the exit status for this process."""
+    import tempfile
+    port = _free_port()
+    children = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), AFX_BENCH_LAUNCHED_BY=str(os.getpid()))
+        out = tempfile.TemporaryFile()
+        children.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=out), out))
+    status = 0
+    pending = set(range(n_gpus))
+    while pending and status == 0:
+        for r in sorted(pending):
+            rc = children[r][0].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0:
+                print(f"bench.py: rank {r} of {n_gpus} exited with status {rc}; ending the other ranks", file=sys.stderr)
+                status = rc if rc > 0 else 1
+                break
+        if pending and status == 0:
+            time.sleep(poll_s)
+    for r in pending:                      # only after a failure: the ranks that are still running
+        children[r][0].terminate()
+    for r in pending:
+        try:
+            children[r][0].wait(10)
+        except subprocess.TimeoutExpired:
+            children[r][0].kill()
+            children[r][0].wait()
+    for r, (_, out) in enumerate(children):
+        out.seek(0)
+        text = out.read().decode(errors="replace")
+        out.close()
+        if r == 0 and status == 0:
+            for line in text.splitlines():          # the line itself to stdout, anything a library printed to stderr
+                (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+            sys.stdout.flush()
+        elif text.strip():
+            sys.stderr.write(f"[rank {r} stdout] {text}")
+    return status
 
 
 DISTINCT_BUFFERS = 64   # MT19937 buffers generated on the host; larger batches tile them (every copy has its own place in HBM)
@@ -160,7 +226,7 @@ def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=
 
 
 def dist_setup(n_gpus):
-    """Returns (rank, world, local_rank, dist or None).  N>1 runs under torchrun."""
+    """Returns (rank, world, local_rank, dist or None).  N>1: the ranks were started by torchrun or by launch_ranks."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -168,8 +234,17 @@ def dist_setup(n_gpus):
         return 0, 1, 0, None
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    # replicas only: the collective is a barrier and a max over ranks of one float on the host
-    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    # replicas only: the collective is a barrier and a max over ranks of one float on the host.
+    # gloo announces its connections on stdout ("[Gloo] Rank 0 is connected to ..."): this script's stdout is ONE JSON
+    # line, so file descriptor 1 points at stderr while the group forms.
+    sys.stdout.flush()
+    saved = os.dup(1)
+    try:
+        os.dup2(2, 1)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    finally:
+        os.dup2(saved, 1)
+        os.close(saved)
     return rank, world, local, dist
 
 
@@ -182,6 +257,15 @@ def reduce_max_sum(dist, seconds, frames):
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(f, op=dist.ReduceOp.SUM)
     return float(t.item()), float(f.item())
+
+
+def gather_ranks(dist, info):
+    """every rank's {rank, device, ms_per_step, ...}, in rank order, on every rank"""
+    if dist is None:
+        return [info]
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, info)
+    return sorted(got, key=lambda d: d["rank"])
 
 
 def cpu_model():
@@ -293,7 +377,7 @@ def parity_spot_check(batch, spot_bufs, frames_per_buffer, n_frames=64):
     from tests._oracle import Oracle
     oracle = Oracle()
     got = batch.fetch()["mfcc"]
-    worst = 0.0
+    worst = over = 0.0
     rtol, atol = _tol.GPU_TOL["mfcc"]
     ok = True
     for i, x in spot_bufs.items():
@@ -301,9 +385,81 @@ def parity_spot_check(batch, spot_bufs, frames_per_buffer, n_frames=64):
         mine = got[i * frames_per_buffer:i * frames_per_buffer + n_frames]
         err = np.abs(mine - ref) / np.maximum(np.abs(ref), 1e-9)
         worst = max(worst, float(err.max()))
+        over = max(over, _tol.over_ceiling("mfcc", mine, ref))
         ok = ok and bool(np.all(np.abs(mine - ref) <= atol + rtol * np.abs(ref)))
     return {"frames": n_frames * len(spot_bufs), "buffers": sorted(spot_bufs), "descriptor": "mfcc", "max_rel_err": worst,
-            "rtol": rtol, "atol": atol, "passed": ok, "against": "oracle/afx_oracle.c (pinned on the reference's objects)"}
+            "rtol": rtol, "atol": atol, "worst_over_ceiling": over, "ceiling": _tol.OBSERVED_CEILING["mfcc"],
+            "passed": ok and over <= 1.0, "against": "oracle/afx_oracle.c (pinned on the reference's objects)"}
+
+
+SURVEY_C3_BYTES_PER_FRAME = 5080   # 4 096 B of PCM + 123 doubles of descriptors per frame of the full low-level set
+
+
+def chain_spot_check(batch, files, channels, picks):
+    """Every per-frame descriptor of the picked files, as the timed launches left them in HBM, against the oracle
+    pipeline (load_sample -> run / run_neighbours): the bar of tests/_tol.py and the regression ceiling."""
+    from tests import _oracle, _tol
+    from tests._oracle import FIELDS, NEIGH_FIELDS, Oracle
+    ora = Oracle()
+    res = batch.fetch()
+    off = res["frame_offset"]
+    worst, worst_field, over, ok, frames, values = 0.0, None, 0.0, True, 0, 0
+    for i in picks:
+        mono, _ = _oracle.load_sample(files[i], channels)
+        ref, nref = ora.run(mono, cap=True), ora.run_neighbours(mono, cap=True)
+        if off[i + 1] - off[i] != ref.shape[0]:
+            return {"passed": False, "error": f"file {i}: {off[i + 1] - off[i]} frames, the oracle has {ref.shape[0]}"}
+        frames += ref.shape[0]
+        pairs = [(f, res[f][off[i]:off[i + 1]].reshape(ref.shape[0], -1), ref[:, a:b]) for f, (a, b) in FIELDS.items() if f != "mag"]
+        pairs += [(f, res[f][off[i]:off[i + 1]].reshape(-1, 1), nref[:, c:c + 1]) for f, c in NEIGH_FIELDS.items()]
+        for field, got, want in pairs:
+            rtol, atol = _tol.bar(field)
+            ok = ok and bool(np.all(np.isfinite(got))) and bool(np.all(np.abs(got - want) <= atol + rtol * np.abs(want)))
+            e = float(_tol.rel_err(field, got, want).max())
+            values += got.size
+            if e > worst:
+                worst, worst_field = e, field
+            over = max(over, _tol.over_ceiling(field, got, want))
+    return {"files": [int(i) for i in picks], "frames": int(frames), "values": int(values), "max_rel_err": worst,
+            "max_rel_err_descriptor": worst_field, "worst_over_ceiling": over, "passed": bool(ok and over <= 1.0),
+            "against": "oracle/afx_oracle.c pipeline (LoadSample -> 123 + 11 per-frame descriptors), bar and 10 x-observed ceiling of tests/_tol.py"}
+
+
+def chain_rate(plan, workload, n_files, seed):
+    """BASELINE configs[2] (C3: 1 000 mono 2 s files) / configs[3] (C4: one GPU's share of 100 000 stereo 1 s files) as
+    the resident chain `--workload c3|c4 --mask frame` times it: decoded files through LoadSample (untimed: batch
+    creation), then per step every per-frame low-level descriptor + the per-file statistics (SA:814-976, 1065).  Priced
+    like the headline: frames/s x SURVEY's 5 080 algorithmic bytes against 8 TB/s; traffic and VALU figures from the
+    committed profile of THIS build (profiles/kernel_profiles.json), null when the loaded library is another one."""
+    channels = 1 if workload == "c3" else 2
+    files = make_c3_files(n_files, seed) if workload == "c3" else make_c4_files(n_files, seed)
+    mask = afx.D_ALL_PER_FRAME | afx.D_STATISTICS
+    batch, _ = plan.batch_from_raw([(f, channels) for f in files], mask)
+    frames = batch.total_frames
+    batch.run()
+    batch.sync()
+    est = batch.run_timed(2) / 2
+    batch.run_timed(max(3, int(40.0 / est) + 1))          # the clocks settle within ~30 ms of load (profiles/r03/clock_ramp.txt)
+    steps = max(10, int(100.0 / est) + 1)
+    ms = batch.run_timed(steps) / steps
+    rate = frames / (ms * 1e-3)
+    info = batch.info()
+    try:
+        spot = chain_spot_check(batch, files, channels, sorted({0, n_files // 2, n_files - 1}))
+    except Exception as e:  # noqa: BLE001
+        spot = {"passed": False, "error": str(e)}
+    batch.close()
+    out = {"frames_per_s": rate, "files": n_files, "frames": frames, "ms_per_step": ms, "steps": steps,
+           "frame_kernel": {1: "wave64", 2: "halfwave"}.get(info["frame_kernel"]), "frame_kernel_class": info["feature_class"],
+           "algorithmic_bytes_per_frame": SURVEY_C3_BYTES_PER_FRAME,
+           "frac": rate * SURVEY_C3_BYTES_PER_FRAME / (HBM_PEAK_GBS * 1e9),
+           "traffic_ratio": None, "valu_frac": None, "kernels_ms": None, "parity_spot_check": spot}
+    prof = kernel_profile("f64", "frame", workload)
+    if prof and not prof.get("stale"):
+        ceiling = 4 * 256 * prof["clock_ghz"] * 1e9 / prof["valu_cycles_per_frame"]
+        out.update(traffic_ratio=prof["bytes_per_frame"] / SURVEY_C3_BYTES_PER_FRAME, valu_frac=rate / ceiling,
+                   valu_ceiling_frames_s=ceiling, kernels_ms=prof.get("kernel_ms_per_step"), profile=prof["source"])
+    return out
 
 
 def secondary_rate(plan, mask, buffers, steps=5):
@@ -318,11 +474,27 @@ def secondary_rate(plan, mask, buffers, steps=5):
     return frames / (ms * 1e-3)
 
 
+def open_plan(device, local, world, **kw):
+    """The rank's plan, or a loud end: a rank without a GPU of its own must never be counted as one (afx_plan_create
+    checks the ordinal against hipGetDeviceCount and answers AFX_ERR_NO_DEVICE)."""
+    try:
+        return afx.Plan(device=device, **kw)
+    except afx.AfxError as e:
+        raise SystemExit(f"bench.py: rank with LOCAL_RANK={local} of {world} cannot use HIP device {device}: {e} "
+                         f"(AFX_BENCH_DEVICE=<ordinal> pins every rank to one device: plumbing tests on a 1-GPU box)")
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher around us: be the launcher.  Nothing in this process has touched the GPU (importing afec_amd loads
+        # no library), the ranks are child processes, and this process only waits for them.
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.fail_rank >= 0 and int(os.environ.get("RANK", "0")) == args.fail_rank:
+        sys.exit(7)
     rank, world, local, dist = dist_setup(args.gpus)
-    if world != max(1, args.gpus) and rank == 0:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != max(1, args.gpus):
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would report another job than the one asked for")
 
     if args.end_to_end:
         if args.workload == "c2":
@@ -335,10 +507,12 @@ def main():
                         files_per_batch=args.files_per_batch)
         seconds, frames_all = reduce_max_sum(dist, st["seconds"], st["frames"])
         _, files_all = reduce_max_sum(dist, st["seconds"], st["files"])
+        per_rank = gather_ranks(dist, {"rank": rank, "device": device, "ms_per_step": st["seconds"] * 1e3, "frames": st["frames"]})
         if rank == 0:
             print(json.dumps({
                 "metric": "audio frames/sec low-level crawl, 44.1kHz 1024-hop", "value": frames_all / seconds, "unit": "frames/s",
-                "n_gpus": world, "steps": 1, "warmup": 0, "ms_per_step": seconds * 1e3, "higher_is_better": True,
+                "n_gpus": world, "ranks_seen": [d["rank"] for d in per_rank], "ranks": per_rank,
+                "steps": 1, "warmup": 0, "ms_per_step": seconds * 1e3, "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"{args.workload.upper()} end to end: {n_files} WAV images per GPU in host memory -> streaming host "
                                        f"driver ({args.workers} workers per GPU, page-locked staging) -> LoadSample + every low-level "
@@ -364,7 +538,7 @@ def main():
     precision = afx.PRECISION_F64
     # AFX_BENCH_DEVICE pins every rank to one device (plumbing tests of the N>1 path on a 1-GPU box)
     device = int(os.environ.get("AFX_BENCH_DEVICE", local))
-    plan = afx.Plan(device=device, precision=precision, max_analysis_ms=0,
+    plan = open_plan(device, local, world, precision=precision, max_analysis_ms=0,
                     frame_kernel={"auto": afx.FRAME_KERNEL_AUTO, "wave64": afx.FRAME_KERNEL_WAVE64,
                                   "halfwave": afx.FRAME_KERNEL_HALFWAVE}[args.frame_kernel],
                     flags=afx.PLAN_NO_SIDE_STREAM if args.no_side_stream else 0)
@@ -401,6 +575,8 @@ def main():
     if dist is not None:
         dist.barrier()
     seconds, frames_all = reduce_max_sum(dist, t1 - t0, frames)
+    per_rank = gather_ranks(dist, {"rank": rank, "device": device, "ms_per_step": (t1 - t0) / args.steps * 1e3,
+                                   "kernel_ms_per_step": ev_ms / args.steps, "frames": frames})
 
     # What the timed launches left in HBM is checked, not only timed: the MFCC of 64 frames of three buffers of this
     # very batch against the oracle (the checker, after the timed region; tests/_tol.py's bar for the descriptor)
@@ -431,6 +607,16 @@ def main():
             all_rate = secondary_rate(plan, afx.D_ALL_LOW_LEVEL, args.buffers)
         except Exception as e:  # noqa: BLE001
             print(f"warning: secondary rates not measured: {e}", file=sys.stderr)
+
+    # BASELINE configs[2] / configs[3] -- the crawl's own chain on decoded files -- with their own roofline and a parity
+    # spot check, in the driver's line (round 5)
+    c3_chain = c4_chain = None
+    if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single and not args.no_chain_rates:
+        try:
+            c3_chain = chain_rate(plan, "c3", 1000, 4321)
+            c4_chain = chain_rate(plan, "c4", 12500, 4321)
+        except Exception as e:  # noqa: BLE001
+            print(f"warning: chain rates not measured: {e}", file=sys.stderr)
 
     # the streaming host driver on C4's per-GPU share, every transfer inside the timed region (secondary number)
     e2e = None
@@ -496,6 +682,8 @@ def main():
             "value": frames_all * args.steps / seconds,
             "unit": "frames/s",
             "n_gpus": world,
+            "ranks_seen": [d["rank"] for d in per_rank],
+            "ranks": per_rank,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": seconds / args.steps * 1e3,
@@ -523,6 +711,8 @@ def main():
                 "single_10k_frame_buffer_frames_per_s": single,
                 "star_descriptor_set_frames_per_s": star_rate,
                 "all_spectral_descriptors_frames_per_s": all_rate,
+                "c3_frames_per_s": c3_chain,
+                "c4_share_frames_per_s": c4_chain,
                 "end_to_end_host_driver": e2e,
                 "pcm": "f32 resident in HBM" if args.workload == "c2" else
                        "f32 mono signal + one double scale per file (LoadSample output, SampleAnalyser.cpp:710-718) resident in HBM",

@@ -66,3 +66,83 @@ NEIGH_TOL = {
     "spectral_inharmonicity": (0.0, 0.0), "tristimulus1": (0.0, 0.0), "tristimulus2": (0.0, 0.0),
     "tristimulus3": (0.0, 0.0),
 }
+
+
+# ---- regression ceiling on the OBSERVED error (round 5) ----
+# The bars above are the north star's (1e-4 relative): three to eight orders of magnitude looser than what the f64
+# kernels deliver.  A change that costs 100 x in accuracy (a shorter series for a logarithm, a reciprocal without its
+# Newton step) would pass them all.  The ceilings below are 10 x the worst error the shipped kernels have shown, per
+# descriptor, as the relative error |got - ref| / max(|ref|, atol / rtol) -- the metric of the parity report
+# (profiles/r04/parity_report.md, profiles/r05/observed_errors.json: every check_gpu() call of one run of the whole
+# GPU suite, tools/observed_errors.py); discrete descriptors stay exact.  check_gpu() asserts the bar AND the ceiling.
+OBSERVED_CEILING = {
+    "mfcc": 2.5e-6,                 # 2.3e-7 observed: logs of mel sums over leakage-floor bins (xtract_mfcc, vector.c:350-391)
+    "sub_flatness": 3.5e-7,         # 3.3e-8: geometric means of sub-bands of 2..6 bins (Statistics.cpp:417-455)
+    "spectral_rms": 2e-8, "spectral_centroid": 2e-8, "spectral_spread": 2e-8, "spectral_skewness": 2e-8,
+    "spectral_kurtosis": 2e-8, "spectral_flatness": 2e-8, "spectral_flux": 2e-8, "spectrum_bands": 2e-8,
+    "sub_rms": 2e-8, "sub_flux": 2e-8, "sub_contrast": 2e-8, "spectral_contrast": 2e-8,
+    "amplitude_rms": 1e-12, "amplitude_envelope": 2e-12,        # time-domain sums of 1 024 samples: 3e-15 / 2e-15 observed
+    "auto_correlation": 2e-8, "f0": 2e-8, "f0_confidence": 2e-8, "failsafe_f0": 2e-8,
+}
+_EXACT = {"spectral_rolloff", "sub_complexity", "amplitude_peak", "amplitude_silence", "spectral_complexity",
+          "spectral_inharmonicity", "tristimulus1", "tristimulus2", "tristimulus3"}
+
+_observed = {}      # name -> worst relative error seen by check_gpu() in this process
+
+
+def bar(name):
+    """(rtol, atol) of a descriptor: the north-star bar"""
+    return GPU_TOL[name] if name in GPU_TOL else NEIGH_TOL[name]
+
+
+def rel_err(name, got, ref):
+    """|got - ref| / max(|ref|, floor), floor = atol / rtol of the descriptor's bar (0 / 0 = 0 for the exact ones)"""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    rtol, atol = bar(name)
+    floor = atol / rtol if rtol > 0 else 0.0
+    denom = np.maximum(np.abs(ref), floor) if floor > 0 else np.where(ref != 0, np.abs(ref), 1.0)
+    return np.abs(got - ref) / denom
+
+
+def over_ceiling(name, got, ref):
+    """worst relative error in units of the descriptor's ceiling (<= 1 is inside; exact descriptors: 0 or inf)"""
+    e = rel_err(name, got, ref)
+    worst = float(e.max()) if e.size else 0.0
+    if name in _EXACT:
+        return 0.0 if worst == 0.0 else float("inf")
+    return worst / OBSERVED_CEILING[name]
+
+
+def check_gpu(name, got, ref, rtol=None, atol=None, what=""):
+    """The HIP path against the oracle / the reference's goldens: the 1e-4 bar (check) and the regression ceiling.
+    AFX_TOL_RECORD=<file>: the worst relative error per descriptor of the process is written there (json) and the
+    ceiling is not enforced -- how the ceilings were measured."""
+    import json
+    import os
+    if rtol is None:
+        rtol, atol = bar(name)
+    check(name, got, ref, rtol, atol, what=what)
+    e = rel_err(name, got, ref)
+    worst = float(e.max()) if e.size else 0.0
+    record = os.environ.get("AFX_TOL_RECORD")
+    if record:
+        if worst > _observed.get(name, -1.0):
+            _observed[name] = worst
+            try:
+                old = json.load(open(record)) if os.path.exists(record) else {}
+            except ValueError:
+                old = {}
+            old[name] = max(worst, old.get(name, 0.0))
+            with open(record, "w") as f:
+                json.dump(old, f, indent=1, sort_keys=True)
+        return
+    if name in _EXACT:
+        return                                   # (0, 0) bars: check() has already demanded equality
+    ceiling = OBSERVED_CEILING[name]
+    if worst > ceiling:
+        i = np.unravel_index(int(np.argmax(e)), e.shape)
+        raise AssertionError(
+            f"{what}{name}: relative error {worst:.3e} at {i} is inside the {rtol:g} bar but above the regression ceiling "
+            f"{ceiling:g} (10 x the worst error the shipped kernels have shown, tests/_tol.py): got "
+            f"{np.asarray(got, dtype=np.float64)[i]!r} ref {np.asarray(ref, dtype=np.float64)[i]!r}")

@@ -106,7 +106,7 @@ def main():
                 continue
             keep = ~flat_spectrum if field in discrete_spectral else np.ones(ref.shape[0], bool)
             try:
-                _tol.check(field, res[field].reshape(ref.shape[0], -1)[keep], ref[keep, a:b], *_tol.GPU_TOL[field])
+                _tol.check_gpu(field, res[field].reshape(ref.shape[0], -1)[keep], ref[keep, a:b], *_tol.GPU_TOL[field])
             except AssertionError as e:
                 bad += 1
                 dump(rounds, bufs, mask)
@@ -116,7 +116,7 @@ def main():
                 continue
             keep = ~flat_spectrum if field in discrete_spectral else (~flat_yin if field in pitch_fields else np.ones(ref.shape[0], bool))
             try:
-                _tol.check(field, res[field][keep], nref[keep, col], *_tol.NEIGH_TOL[field])
+                _tol.check_gpu(field, res[field][keep], nref[keep, col], *_tol.NEIGH_TOL[field])
             except AssertionError as e:
                 bad += 1
                 dump(rounds, bufs, mask)

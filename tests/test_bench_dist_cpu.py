@@ -58,3 +58,41 @@ def test_single_process_path_needs_no_torch():
         for k, v in old.items():
             if v is not None:
                 os.environ[k] = v
+
+
+def _run_bench(*argv, env=None, timeout=300):
+    import subprocess
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, timeout=timeout)
+
+
+def test_plain_gpus_n_starts_its_own_ranks_and_a_failed_rank_fails_the_job():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself (Crawler.cpp:706-728 one level up).
+    Rank 1 exits with status 7 before it joins; rank 0 is then waiting for it in the rendezvous: the launcher must end
+    it and return the failing status instead of hanging -- and must not print a line."""
+    r = _run_bench("--gpus", "2", "--fail-rank", "1", "--steps", "1", "--warmup", "0", "--buffers", "1", "--no-cpu-baseline", "--no-single")
+    assert r.returncode == 7, (r.returncode, r.stderr.decode()[-2000:])
+    assert b"rank 1 of 2 exited with status 7" in r.stderr
+    assert not any(line.startswith(b"{") for line in r.stdout.splitlines())
+
+
+def test_without_a_gpu_every_rank_fails_loudly_and_no_line_is_printed():
+    """This container has no GPU: the ranks' plans fail (AFX_ERR_NO_DEVICE, no CPU fallback), the job's status is
+    non-zero and nothing that looks like a result reaches stdout."""
+    import torch
+    if torch.cuda.device_count() > 0:
+        pytest.skip("a GPU is visible: the ranks would run")
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--buffers", "1", "--no-cpu-baseline", "--no-single")
+    assert r.returncode != 0
+    assert b"cannot use HIP device" in r.stderr
+    assert not any(line.startswith(b"{") for line in r.stdout.splitlines())
+
+
+def test_a_world_size_that_contradicts_gpus_is_an_error():
+    """a launcher that exported WORLD_SIZE=1 for --gpus 2 used to get a 1-GPU number labelled n_gpus 1 and a warning"""
+    r = _run_bench("--gpus", "2", "--steps", "1", "--warmup", "0", "--buffers", "1", "--no-cpu-baseline", "--no-single",
+                   env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
+    assert r.returncode != 0 and b"--gpus 2 but WORLD_SIZE=1" in r.stderr
+    assert not any(line.startswith(b"{") for line in r.stdout.splitlines())

@@ -56,9 +56,9 @@ def test_gpu_pipeline_matches_the_reference_chain():
         for field, a, b in spectral_fields():
             rtol, atol = _tol.GPU_TOL[field]
             got = res[field][off[i]:off[i + 1]].reshape(want.shape[0], -1)
-            _tol.check(field, got, want[:, a:b], rtol, atol, what=f"{name} ")
+            _tol.check_gpu(field, got, want[:, a:b], rtol, atol, what=f"{name} ")
         for field, col in NEIGH_FIELDS.items():
             rtol, atol = _tol.NEIGH_TOL[field]
-            _tol.check(field, res[field][off[i]:off[i + 1]], z["neighbours_" + name][:, col], rtol, atol, what=f"{name} ")
+            _tol.check_gpu(field, res[field][off[i]:off[i + 1]], z["neighbours_" + name][:, col], rtol, atol, what=f"{name} ")
     batch.close()
     plan.close()

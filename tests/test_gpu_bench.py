@@ -1,0 +1,71 @@
+"""bench.py on the GPU box: the launcher of `--gpus N` (no torchrun around it) and the chain rates of the driver's line."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench_line(*argv, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], env=e, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1, lines                      # ONE JSON line, nothing else on stdout
+    return json.loads(lines[0])
+
+
+def test_gpus_2_run_plainly_starts_two_ranks_and_counts_both():
+    """`python bench.py --gpus 2` the way the driver runs `--gpus 1`: no WORLD_SIZE in the environment.  Both ranks are
+    pinned to the one device of this box (AFX_BENCH_DEVICE): the line must say two ranks, name them, and count the
+    frames of both -- not measure one GPU and call it n_gpus 1."""
+    common = ("--buffers", "16", "--steps", "3", "--no-cpu-baseline", "--no-single")
+    one = _bench_line("--gpus", "1", *common)
+    two = _bench_line("--gpus", "2", *common, env={"AFX_BENCH_DEVICE": "0"})
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == [0]
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == [0, 1]
+    assert [r["device"] for r in two["ranks"]] == [0, 0]
+    per_rank = one["config"]["frames_per_gpu_per_step"]
+    assert per_rank == 16 * 10000
+    assert [r["frames"] for r in two["ranks"]] == [per_rank, per_rank]
+    # value = frames of all ranks x steps / max-over-ranks time
+    assert abs(two["value"] - 2 * per_rank * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) <= 1e-6 * two["value"]
+    assert all(r["ms_per_step"] <= two["ms_per_step"] * (1 + 1e-9) for r in two["ranks"])
+    assert two["config"]["parity_spot_check"]["passed"] and two["config"]["parity_spot_check"]["worst_over_ceiling"] <= 1.0
+
+
+def test_a_rank_without_a_device_of_its_own_fails_the_job():
+    """one GPU on this box: rank 1 of a plain --gpus 2 has no device 1 and must say so; the job fails, no line"""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two devices: rank 1 has its own")
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "AFX_BENCH_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--buffers", "4", "--steps", "2",
+                        "--no-cpu-baseline", "--no-single"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode != 0
+    assert b"LOCAL_RANK=1 of 2 cannot use HIP device 1" in r.stderr
+    assert not any(l.startswith(b"{") for l in r.stdout.splitlines())
+
+
+@pytest.mark.parametrize("workload,n_files", [("c3", 96), ("c4", 160)])
+def test_chain_rate_objects_of_the_line(workload, n_files):
+    """config.c3_frames_per_s / c4_share_frames_per_s: a small batch of the same files through bench.chain_rate --
+    rate, roofline fraction on SURVEY's 5 080 B per frame, and the three-file parity spot check inside bar and ceiling"""
+    sys.path.insert(0, ROOT)
+    import afec_amd as afx
+    import bench
+    plan = afx.Plan(max_analysis_ms=0)
+    out = bench.chain_rate(plan, workload, n_files, 4321)
+    plan.close()
+    assert out["files"] == n_files and out["frames"] > 30 * n_files and out["frames_per_s"] > 0
+    assert abs(out["frac"] - out["frames_per_s"] * 5080 / 8e12) <= 1e-12
+    spot = out["parity_spot_check"]
+    assert spot.get("passed"), spot
+    assert spot["files"] == sorted({0, n_files // 2, n_files - 1}) and spot["worst_over_ceiling"] <= 1.0

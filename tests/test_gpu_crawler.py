@@ -94,7 +94,7 @@ def test_crawl_into_the_descriptor_database(tmp_path):
             rtol, atol = _tol.GPU_TOL[field]
             col = base + ("_VR" if b - a == 1 else "_VVR")
             got = np.array(msgpack.unpackb(r[col]), dtype=np.float64).reshape(ref.shape[0], -1)
-            _tol.check(field, got, ref[:, a:b], rtol, atol, what=f"{name} {col} ")
+            _tol.check_gpu(field, got, ref[:, a:b], rtol, atol, what=f"{name} {col} ")
             # statistics columns: the mean of the series
             want_mean = ref[:, a:b].mean(axis=0)
             if b - a == 1:
@@ -124,7 +124,7 @@ def test_crawl_into_the_descriptor_database(tmp_path):
         ref = ora.run(mono, cap=True)
         got = np.array(msgpack.unpackb(r["cepstrum_bands_VVR"]))
         a, b = FIELDS["mfcc"]
-        _tol.check("mfcc", got, ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=k + " ")
+        _tol.check_gpu("mfcc", got, ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=k + " ")
     con.close()
 
 
@@ -319,7 +319,7 @@ def test_the_c4_share_at_its_full_size(tmp_path):
         ref = ora.run(mono, cap=True)
         a, b = FIELDS["mfcc"]
         got = np.array(msgpack.unpackb(r["cepstrum_bands_VVR"]), dtype=np.float64).reshape(ref.shape[0], -1)
-        _tol.check("mfcc", got, ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"content {k} ")
+        _tol.check_gpu("mfcc", got, ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"content {k} ")
         assert r["status"] == "succeeded" and r["file_channel_count_R"] == 2
     con.close()
 

@@ -91,7 +91,7 @@ def test_pipeline_matches_oracle_on_sampled_files(shape, n_files, n_sampled):
                 continue
             rtol, atol = _tol.GPU_TOL[field]
             got = res[field][off[i]:off[i + 1]].reshape(ref.shape[0], -1)
-            _tol.check(field, got, ref[:, a:b], rtol, atol, what=f"{shape} file {i} ")
+            _tol.check_gpu(field, got, ref[:, a:b], rtol, atol, what=f"{shape} file {i} ")
             # per-file statistics of the same series
             width = b - a
             gs = stats[field].reshape(n_files, width, 13)[i]

@@ -57,10 +57,10 @@ def test_golden_mfcc(forced, name):
     # float32 rounding is part of both sides only when the test converts: compare against the oracle on the
     # float32 signal instead when the cast changes the input
     if np.array_equal(x.astype(np.float32).astype(np.float64), x):
-        _tol.check("mfcc", res["mfcc"], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=name + " ")
+        _tol.check_gpu("mfcc", res["mfcc"], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=name + " ")
     else:
         o = Oracle().run(x.astype(np.float32).astype(np.float64))
-        _tol.check("mfcc", res["mfcc"], o[:, a:b], *_tol.GPU_TOL["mfcc"], what=name + " (oracle) ")
+        _tol.check_gpu("mfcc", res["mfcc"], o[:, a:b], *_tol.GPU_TOL["mfcc"], what=name + " (oracle) ")
 
 
 def test_ragged_batch_matches_oracle_and_the_64_lane_kernel(forced, lanes64, oracle):
@@ -83,7 +83,7 @@ def test_ragged_batch_matches_oracle_and_the_64_lane_kernel(forced, lanes64, ora
         if off[i + 1] == off[i]:
             continue
         o = oracle.run(x.astype(np.float64))
-        _tol.check("mfcc", got["mfcc"][off[i]:off[i + 1]], o[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"buffer {i} ")
+        _tol.check_gpu("mfcc", got["mfcc"][off[i]:off[i + 1]], o[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"buffer {i} ")
 
 
 def test_repeated_launches_and_workspace_reuse(forced):
@@ -114,7 +114,7 @@ def test_default_plan_picks_the_half_wave_kernel_for_large_batches(forced, oracl
     np.testing.assert_array_equal(got, forced.extract(bufs, afx.D_MFCC)["mfcc"])
     a, b = FIELDS["mfcc"]
     o = oracle.run(bufs[3][:2048 + 1024 * 40].astype(np.float64))
-    _tol.check("mfcc", got[3 * 3000:3 * 3000 + 41], o[:, a:b], *_tol.GPU_TOL["mfcc"], what="large batch ")
+    _tol.check_gpu("mfcc", got[3 * 3000:3 * 3000 + 41], o[:, a:b], *_tol.GPU_TOL["mfcc"], what="large batch ")
 
 
 # ---- the statistics class of the half-wave kernel: MFCC + spectral rms / centroid / spread / skewness / kurtosis /
@@ -129,7 +129,7 @@ def check_stats(got, ref_rows, what):
         if field not in got:
             continue
         a, b = FIELDS[field]
-        _tol.check(field, got[field].reshape(ref_rows.shape[0], -1), ref_rows[:, a:b], *_tol.GPU_TOL[field], what=what)
+        _tol.check_gpu(field, got[field].reshape(ref_rows.shape[0], -1), ref_rows[:, a:b], *_tol.GPU_TOL[field], what=what)
 
 
 @pytest.mark.parametrize("name", golden_names())
@@ -193,7 +193,7 @@ def check_full(got, ref_rows, what, rows=None):
             continue
         a, b = FIELDS[field]
         g = got[field] if rows is None else got[field][rows[0]:rows[1]]
-        _tol.check(field, g.reshape(ref_rows.shape[0], -1), ref_rows[:, a:b], *_tol.GPU_TOL[field], what=what)
+        _tol.check_gpu(field, g.reshape(ref_rows.shape[0], -1), ref_rows[:, a:b], *_tol.GPU_TOL[field], what=what)
 
 
 @pytest.mark.parametrize("name", golden_names())

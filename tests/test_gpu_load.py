@@ -60,7 +60,7 @@ def test_load_front_end_matches_oracle():
         ref = ora.run(want, cap=True)
         assert ref.shape[0] == nf
         a, b = FIELDS["mfcc"]
-        _tol.check("mfcc", res["mfcc"][row:row + nf], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"file {i} ")
+        _tol.check_gpu("mfcc", res["mfcc"][row:row + nf], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"file {i} ")
         a, b = FIELDS["amplitude_peak"]
         np.testing.assert_array_equal(res["amplitude_peak"][row:row + nf], ref[:, a])
         row += nf
@@ -142,7 +142,7 @@ def test_pads_are_zero_in_a_reused_workspace():
             a, b = FIELDS["amplitude_peak"]
             np.testing.assert_array_equal(res["amplitude_peak"][row:row + nf], ref[:, a])
             a, b = FIELDS["mfcc"]
-            _tol.check("mfcc", res["mfcc"][row:row + nf], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"round {round_} file {i} ")
+            _tol.check_gpu("mfcc", res["mfcc"][row:row + nf], ref[:, a:b], *_tol.GPU_TOL["mfcc"], what=f"round {round_} file {i} ")
             row += nf
         batch.close()
     plan.close()

@@ -48,7 +48,7 @@ def compare(res, ref, what, skip=()):
         if field not in res or field in skip:
             continue
         rtol, atol = _tol.NEIGH_TOL[field]
-        _tol.check(field, res[field], ref[:, col], rtol, atol, what=what)
+        _tol.check_gpu(field, res[field], ref[:, col], rtol, atol, what=what)
 
 
 @pytest.mark.parametrize("name", neighbour_names())
@@ -235,8 +235,8 @@ def test_non_finite_samples_do_not_poison_other_frames_or_buffers(plan, oracle):
         if field == "spectral_complexity":
             continue            # the follower carries the poisoned frames forward, as the reference's would
         rtol, atol = _tol.NEIGH_TOL[field]
-        _tol.check(field, res[field][off[0]:off[1]][clean], ref[clean, col], rtol, atol, what="frames without the NaN ")
-        _tol.check(field, res[field][off[1]:off[2]], ref[:, col], rtol, atol, what="second buffer ")
+        _tol.check_gpu(field, res[field][off[0]:off[1]][clean], ref[clean, col], rtol, atol, what="frames without the NaN ")
+        _tol.check_gpu(field, res[field][off[1]:off[2]], ref[:, col], rtol, atol, what="second buffer ")
     assert np.all(np.isfinite(res["spectral_complexity"]))
 
 
@@ -326,12 +326,12 @@ def test_full_size_buffer_against_oracle_samples(plan, oracle):
         if field == "auto_correlation":
             continue        # `remaining` differs between the slice and the whole buffer only in the last frame; checked below
         rtol, atol = _tol.NEIGH_TOL[field]
-        _tol.check(field, res[field][:64], head[:, col], rtol, atol, what="head ")
+        _tol.check_gpu(field, res[field][:64], head[:, col], rtol, atol, what="head ")
     local = ["amplitude_silence", "amplitude_envelope", "f0", "f0_confidence", "auto_correlation"]
     for f in rng.integers(100, 9990, 24):
         seg = x[1024 * f: 1024 * f + 2048 + 64].astype(np.float64)
         ref = oracle.run_neighbours(seg)[0]
         for field in local:
             rtol, atol = _tol.NEIGH_TOL[field]
-            _tol.check(field, res[field][f:f + 1], ref[NEIGH_FIELDS[field]:NEIGH_FIELDS[field] + 1], rtol, atol,
+            _tol.check_gpu(field, res[field][f:f + 1], ref[NEIGH_FIELDS[field]:NEIGH_FIELDS[field] + 1], rtol, atol,
                        what=f"frame {f} ")

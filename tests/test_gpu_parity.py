@@ -44,7 +44,7 @@ def compare(res, ref, mask, what, skip=()):
             continue
         rtol, atol = _tol.GPU_TOL[field]
         got = res[field].reshape(ref.shape[0], -1)
-        _tol.check(field, got, ref[:, a:b], rtol, atol, what=what)
+        _tol.check_gpu(field, got, ref[:, a:b], rtol, atol, what=what)
 
 
 def test_tables_bit_exact(plan):
@@ -100,7 +100,7 @@ def test_analysis_cap(oracle):
     assert res["mfcc"].shape == (860, 14)
     want = oracle.run(x.astype(np.float64), cap=True)
     idx = [0, 1, 31, 32, 33, 500, 858, 859]
-    _tol.check("mfcc", res["mfcc"][idx], want[idx, 1024:1038], *_tol.GPU_TOL["mfcc"])
+    _tol.check_gpu("mfcc", res["mfcc"][idx], want[idx, 1024:1038], *_tol.GPU_TOL["mfcc"])
     p.close()
 
 
@@ -117,7 +117,7 @@ def test_bad_buffer_does_not_fail_the_batch(plan, oracle):
     assert res["buf_status"].tolist() == [0, -6, 0]
     assert res["frame_offset"].tolist() == [0, 3, 3, 6]
     want = oracle.run(good.astype(np.float64))[:, 1024:1038]
-    _tol.check("mfcc", res["mfcc"], np.concatenate([want, want]), *_tol.GPU_TOL["mfcc"])
+    _tol.check_gpu("mfcc", res["mfcc"], np.concatenate([want, want]), *_tol.GPU_TOL["mfcc"])
 
 
 def test_chunking_invariance_bitwise(plan):
@@ -141,7 +141,7 @@ def test_c2_full_size_against_oracle_sample(plan, oracle):
     assert np.all(np.isfinite(res["mfcc"]))
     for f0 in (0, 4990, 9936):
         want = oracle.run_mfcc(x[f0 * 1024: f0 * 1024 + 2048 + 63 * 1024].astype(np.float64))
-        _tol.check("mfcc", res["mfcc"][f0:f0 + 64], want, *_tol.GPU_TOL["mfcc"], what=f"C2 f0={f0} ")
+        _tol.check_gpu("mfcc", res["mfcc"][f0:f0 + 64], want, *_tol.GPU_TOL["mfcc"], what=f"C2 f0={f0} ")
 
 
 def test_resident_batch_rerun_is_deterministic(plan):

@@ -92,7 +92,7 @@ def test_every_sample_type_and_a_mixed_batch():
             if field == "mag":
                 continue
             rtol, atol = _tol.GPU_TOL[field]
-            _tol.check(field, res[field][off[i]:off[i + 1]].reshape(ref.shape[0], -1), ref[:, a:b], rtol, atol, what=f"file {i} ")
+            _tol.check_gpu(field, res[field][off[i]:off[i + 1]].reshape(ref.shape[0], -1), ref[:, a:b], rtol, atol, what=f"file {i} ")
     np.testing.assert_array_equal(res["mfcc"][off[5]:off[6]], res["mfcc"][off[6]:off[7]])   # rate 0 and rate 44100: the same file
     batch.close()
     plan.close()
@@ -178,5 +178,5 @@ def test_real_audio_at_another_rate_through_the_crawler(tmp_path):
                            ("amplitude_peak", "amplitude_peak_VR")):
             a, b = FIELDS[field]
             got = np.array(msgpack.unpackb(r[col]), dtype=np.float64).reshape(ref.shape[0], -1)
-            _tol.check(field, got, ref[:, a:b], *_tol.GPU_TOL[field], what=f"{name} {col} ")
+            _tol.check_gpu(field, got, ref[:, a:b], *_tol.GPU_TOL[field], what=f"{name} {col} ")
     con.close()

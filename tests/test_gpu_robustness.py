@@ -73,13 +73,13 @@ def test_long_uncapped_buffer_head_and_tail():
     for f0 in (0, 31, 32, 33, nf - 40):
         seg = x[f0 * 1024: f0 * 1024 + 2048 + 1024 * 7].astype(np.float64)
         want = ora.run(seg)
-        _tol.check("mfcc", res["mfcc"][f0:f0 + 8], want[:, 1024:1038], *_tol.GPU_TOL["mfcc"], what=f"f0={f0} ")
+        _tol.check_gpu("mfcc", res["mfcc"][f0:f0 + 8], want[:, 1024:1038], *_tol.GPU_TOL["mfcc"], what=f"f0={f0} ")
         np.testing.assert_array_equal(res["spectral_rolloff"][f0:f0 + 8], want[:, 1043])
         # flux of a frame depends on the previous frame of the same buffer, not of the slice
         if f0 == 0:
-            _tol.check("flux", res["spectral_flux"][:8], want[:, 1045], *_tol.GPU_TOL["spectral_flux"])
+            _tol.check_gpu("flux", res["spectral_flux"][:8], want[:, 1045], *_tol.GPU_TOL["spectral_flux"])
         else:
-            _tol.check("flux", res["spectral_flux"][f0 + 1:f0 + 8], want[1:, 1045], *_tol.GPU_TOL["spectral_flux"])
+            _tol.check_gpu("flux", res["spectral_flux"][f0 + 1:f0 + 8], want[1:, 1045], *_tol.GPU_TOL["spectral_flux"])
     plan.close()
 
 
@@ -142,7 +142,7 @@ def test_vanishing_amplitudes_flush_like_the_reference():
         rtol, atol = _tol.GPU_TOL[field]
         # the transition (per-product flush there, flush of the sum here: |X| around 1e-154) is left out
         keep = np.r_[0:37, 46:51]
-        _tol.check(field, got[keep], ref[keep, a:b], rtol, atol, what="vanishing ")
+        _tol.check_gpu(field, got[keep], ref[keep, a:b], rtol, atol, what="vanishing ")
     assert res["spectral_flatness"][-1] == 1.0 and not res["sub_complexity"][-1].any()
     plan.close()
 

@@ -158,7 +158,7 @@ def test_crawl_the_reference_fixtures_into_the_database(tmp_path):
         def series_and_stats(db_base, field, got_ref, rtol, atol, width):
             col = db_base + ("_VR" if width == 1 else "_VVR")
             got = np.array(msgpack.unpackb(r[col]), dtype=np.float64).reshape(F, -1)
-            _tol.check(field, got, got_ref, rtol, atol, what=f"{base} {col} ")
+            _tol.check_gpu(field, got, got_ref, rtol, atol, what=f"{base} {col} ")
             checked.add(col)
             for w in range(width):
                 ref13 = _oracle.calc_statistics(got_ref[:, w])

@@ -20,7 +20,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("AFX_ROUND", "r04")
+ROUND = os.environ.get("AFX_ROUND", "r05")
 # steps of a few ms (C3: 3.7 ms) need more warm-up launches to get past the ~30 ms the clocks take to settle from an
 # idle GPU (profiles/r03/clock_ramp.txt): AFX_PROF_WARMUP / AFX_PROF_STEPS
 STEPS, WARMUP = int(os.environ.get("AFX_PROF_STEPS", "10")), int(os.environ.get("AFX_PROF_WARMUP", "2"))

@@ -77,9 +77,9 @@ def test_long_uncapped_buffer_head_and_tail():
         np.testing.assert_array_equal(res["spectral_rolloff"][f0:f0 + 8], want[:, 1043])
         # flux of a frame depends on the previous frame of the same buffer, not of the slice
         if f0 == 0:
-            _tol.check_gpu("flux", res["spectral_flux"][:8], want[:, 1045], *_tol.GPU_TOL["spectral_flux"])
+            _tol.check_gpu("spectral_flux", res["spectral_flux"][:8], want[:, 1045], *_tol.GPU_TOL["spectral_flux"])
         else:
-            _tol.check_gpu("flux", res["spectral_flux"][f0 + 1:f0 + 8], want[1:, 1045], *_tol.GPU_TOL["spectral_flux"])
+            _tol.check_gpu("spectral_flux", res["spectral_flux"][f0 + 1:f0 + 8], want[1:, 1045], *_tol.GPU_TOL["spectral_flux"])
     plan.close()
 
 

@@ -226,7 +226,7 @@ struct WhitenArgs {
   const double* mag;            // [F][1024]
   const int64_t* frame_offset;  // [n_bufs + 1], device
   const int32_t* chunk_first;   // [n_bufs + 1]: index of the buffer's first chunk in `chunks`
-  const Chunk* chunks;          // the whitening kernels' own chunk table (afx_capi.cpp, build_batch)
+  const Chunk* chunks;          // the whitening kernels' own chunk table (afx_batch_plan.cpp, cut_whitening_chunks)
   int32_t n_bufs, n_chunks;
   int32_t chunk_frames;         // frames per chunk of the buffers that have several (their last chunk may be shorter)
   int32_t need_follow;          // some buffer has more than one chunk: follow_kernel leaves the state at their starts

@@ -49,7 +49,7 @@ __device__ __forceinline__ float mono_sample(const unsigned char* raw, int forma
 
 // the mono mix of frames n4 .. n4 + 3 (n4 a multiple of 4; frames at or behind n_frames come back as 0).  16-bit files
 // -- the common case -- take one 8- or 16-byte load (a file's payload starts on a 16-byte boundary of the staging
-// arena, afx_capi.cpp); every other format and channel count goes sample by sample.  The arithmetic is mono_sample's.
+// arena, afx_batch_create.cpp); every other format and channel count goes sample by sample.  The arithmetic is mono_sample's.
 __device__ __forceinline__ void mono4(const unsigned char* raw, int format, int channels, int64_t n4, int64_t n_frames, float (&out)[4]) {
   if (format == 0 && channels <= 2 && n4 + 4 <= n_frames) {
     if (channels == 1) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(kLoadThreads) void load_write_kernel(const unsigned
   // only the analysed prefix is kept
   int64_t n_copy = (p.audible < p.out_n - p.start_pad) ? p.audible : (p.out_n - p.start_pad);
   if (n_copy < 0) n_copy = 0;
-  // the start pad, the end pad and the slack up to the buffer's 4-sample slot (afx_capi.cpp, build_batch) are zeros:
+  // the start pad, the end pad and the slack up to the buffer's 4-sample slot (afx_batch_plan.cpp, place_buffers) are zeros:
   // written here, by the first workgroup of the file, so that the arena needs no memset (it is written exactly once)
   if (blockIdx.y == 0) {
     const int64_t slot = (p.out_n + 3) & ~(int64_t)3, tail = p.start_pad + n_copy;

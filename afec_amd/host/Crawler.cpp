@@ -206,7 +206,8 @@ TCrawler::TCrawler(const TCrawlOptions& Options) : mpImpl(new TImpl) {
       mpImpl->mHardwareQueuesInEnvironment = q ? std::atoi(q) : 0;
     }
     for (int Device : Options.mDevices) {
-      mpImpl->mAnalysers.emplace_back(new TSampleAnalyser(Options.mSampleRate, Options.mFftFrameSize, Options.mHopFrameSize, Device));
+      mpImpl->mAnalysers.emplace_back(new TSampleAnalyser(Options.mSampleRate, Options.mFftFrameSize, Options.mHopFrameSize, Device,
+                                                          Options.mFrameKernel));
       mpImpl->mAnalysers.back()->SetSleepingWaits(Options.mSleepingWaits);
     }
   } catch (...) {
@@ -506,15 +507,22 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
     while (std::unique_ptr<TFinishedBatch> p = Queue.Pop()) {
       const double t0 = Now(), c0 = ThreadCpuSeconds();
       int64_t Failed = 0, Skipped = 0;
+      // Only whole batches reach the database.  A crawl that is ending (Abort: a lost device, an exception in a worker, an
+      // earlier failed insert) writes nothing of the batches still queued; a batch that has begun is finished and
+      // committed unless one of its OWN inserts fails -- that insert has rolled the batch's transaction back
+      // (SqlitePool.cpp: InsertColumns / InsertFailedSample), and nothing more of the batch is written behind it.
+      // (Until round 5 the loop also broke when another thread set Abort mid-batch, and the commit below then committed
+      // the partial batch.)
+      bool WriteBatch = !Abort, InsertFailed = false;
       try {
-        if (pPool) pPool->BeginTransaction();     // one commit per batch of files; the rows are those of one commit per file
+        if (pPool && WriteBatch) pPool->BeginTransaction();     // one commit per batch of files; the rows are those of one commit per file
       } catch (const std::exception& e) {
         std::lock_guard<std::mutex> Lock(StatMutex);
         if (FirstError.empty()) FirstError = e.what();
         Abort = true;
+        WriteBatch = false;
       }
-      for (size_t i = 0; i < p->mFiles.size(); ++i) {
-        if (Abort) break;     // a failed insert rolled the batch's transaction back: no partial batch is committed behind it
+      for (size_t i = 0; i < p->mFiles.size() && WriteBatch && !InsertFailed; ++i) {
         const TCrawlFile& f = *p->mFiles[i];
         try {
           if (p->mSkipped[i]) {
@@ -535,10 +543,11 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
           std::lock_guard<std::mutex> Lock(StatMutex);
           if (FirstError.empty()) FirstError = e.what();
           Abort = true;
+          InsertFailed = true;
         }
       }
       try {
-        if (pPool) pPool->CommitTransaction();
+        if (pPool && WriteBatch && !InsertFailed) pPool->CommitTransaction();
       } catch (const std::exception& e) {
         std::lock_guard<std::mutex> Lock(StatMutex);
         if (FirstError.empty()) FirstError = e.what();
@@ -602,7 +611,9 @@ std::string gDatabasePragmas;
 std::atomic<bool> gResample(true);
 std::atomic<int> gTestFailBatch(-1), gTestFailAttempts(0), gTestDeviceLost(0);
 std::atomic<int64_t> gDeviceBytesPerBatch(0);
+std::atomic<int> gFrameKernel(-1);   // afec_crawl_set_frame_kernel: -1 = TCrawlOptions' default
 }  // namespace
+extern "C" void afec_crawl_set_frame_kernel(int32_t frame_kernel) { gFrameKernel = frame_kernel; }
 extern "C" void afec_crawl_set_test_fault(int32_t batch, int32_t attempts, int32_t device_lost) {
   gTestFailBatch = batch; gTestFailAttempts = attempts; gTestDeviceLost = device_lost;
 }
@@ -634,6 +645,7 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     Options.mResample = gResample;
     Options.mTestFailBatch = gTestFailBatch; Options.mTestFailAttempts = gTestFailAttempts; Options.mTestDeviceLost = gTestDeviceLost != 0;
     if (gDeviceBytesPerBatch > 0) Options.mDeviceBytesPerBatch = gDeviceBytesPerBatch;
+    if (gFrameKernel >= 0) Options.mFrameKernel = gFrameKernel;
     {
       std::lock_guard<std::mutex> Lock(gPragmaMutex);
       Options.mDatabasePragmas = gDatabasePragmas;
@@ -646,6 +658,7 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     {
       std::string Key;
       for (int d : Options.mDevices) Key += std::to_string(d) + ",";
+      Key += "k" + std::to_string(Options.mFrameKernel);   // a crawler keeps the kernel layout its plans were built with
       for (auto& Entry : gCrawlers)
         if (Entry.first == Key) pCrawler = Entry.second;
       if (!pCrawler) {

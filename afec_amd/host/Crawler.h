@@ -40,6 +40,13 @@ struct TCrawlOptions {
   std::string mDatabasePath;        // empty: results are counted, not stored
   std::string mDatabasePragmas;     // run when the database is opened ("" = sqlite's defaults, like the reference; SqlitePool.h)
   int mSampleRate = 44100, mFftFrameSize = 2048, mHopFrameSize = 1024;
+  // Layout of the STFT kernel of the crawler's plans (afx_plan_desc.frame_kernel; TSampleAnalyser's FrameKernel).  Pinned:
+  // the library's AUTO picks the layout by batch size, the two layouts round differently (their results agree to 1e-6,
+  // the discrete descriptors may flip), and which batch a file lands in -- a crawl's tail batch, the halves of a retried
+  // batch, a batch cut by mDeviceBytesPerBatch -- must not decide its database row.  1 (AFX_FRAME_KERNEL_WAVE64): one
+  // frame per 64-lane wave, the better one up to ~30 000 frames per batch (512 one-second files are 20 000); 2
+  // (AFX_FRAME_KERNEL_HALFWAVE) for crawls of long files in large batches.  A crawler keeps the layout it was built with.
+  int mFrameKernel = 1;
   // Runtime knobs the crawler applies itself, to its own plans only (libafx_hip.so changes nothing process-wide):
   // * the HIP runtime multiplexes a process' streams onto GPU_MAX_HW_QUEUES hardware queues (4 by default) and the
   //   packets of a queue execute in order; with 2 streams per batch in flight + the plan's two copy streams the
@@ -140,6 +147,8 @@ void afec_crawl_set_database_pragmas(const char* pragmas);
 void afec_crawl_set_resample(int32_t resample);
 // TCrawlOptions::mTestFailBatch / mTestFailAttempts / mTestDeviceLost of the crawls that follow (-1, 0, 0: no fault)
 void afec_crawl_set_test_fault(int32_t batch, int32_t attempts, int32_t device_lost);
+// TCrawlOptions::mFrameKernel of the crawls that follow (-1: the default; 0 / 1 / 2 = AFX_FRAME_KERNEL_AUTO / WAVE64 / HALFWAVE)
+void afec_crawl_set_frame_kernel(int32_t frame_kernel);
 // TCrawlOptions::mDeviceBytesPerBatch of the crawls that follow (0: the default)
 void afec_crawl_set_device_bytes_per_batch(int64_t bytes);
 }

@@ -17,10 +17,10 @@ namespace {
 
 }  // namespace
 
-TSampleAnalyser::TSampleAnalyser(int SampleRate, int FftFrameSize, int HopFrameSize, int Device)
+TSampleAnalyser::TSampleAnalyser(int SampleRate, int FftFrameSize, int HopFrameSize, int Device, int FrameKernel)
     : mpPlan(nullptr), mSampleRate(SampleRate), mFftFrameSize(FftFrameSize), mHopFrameSize(HopFrameSize) {
   afx_plan_desc Desc = {SampleRate, FftFrameSize, HopFrameSize, Device, AFX_PRECISION_F64,
-                        /* MAnalyzationDurationMaxInMs, SampleAnalyser.cpp:37 */ 1000 * 20};
+                        /* MAnalyzationDurationMaxInMs, SampleAnalyser.cpp:37 */ 1000 * 20, FrameKernel};
   const int Status = afx_plan_create(&Desc, &mpPlan);
   if (Status != AFX_OK) Throw("GPU feature extraction unavailable", Status);
 }
@@ -310,7 +310,11 @@ int64_t TSampleAnalyser::ConvertedSampleFrames(const TDecodedSample& File, int R
   return (int64_t)((double)File.mNumberOfSampleFrames / ((double)File.mSampleRate / (double)Rate) + 0.5) + 1;
 }
 
-bool TSampleAnalyser::DeviceUsable() const { return afx_plan_probe_device(mpPlan) == AFX_OK; }
+bool TSampleAnalyser::DeviceUsable() const {
+  // "out of memory" is an answer: the device is alive, this batch was too large for what is free (retried in halves)
+  const int Status = afx_plan_probe_device(mpPlan);
+  return Status == AFX_OK || Status == AFX_ERR_OUT_OF_MEMORY;
+}
 
 size_t TSampleAnalyser::RhythmDoubles(const std::vector<TDecodedSample>& Files) const {
   size_t Rows = 0;

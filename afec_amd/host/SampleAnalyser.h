@@ -111,8 +111,11 @@ struct TRecordBatch {
 
 class TSampleAnalyser {
 public:
-  // Device: HIP device ordinal.  Throws TReadableException when the GPU path cannot be set up.
-  TSampleAnalyser(int SampleRate, int FftFrameSize, int HopFrameSize, int Device = 0);
+  // Device: HIP device ordinal.  FrameKernel: afx_plan_desc.frame_kernel -- the layout of the STFT kernel, PINNED by
+  // default (1 = AFX_FRAME_KERNEL_WAVE64) so that a file's descriptors do not depend on the batch it was analysed in
+  // (0 = AFX_FRAME_KERNEL_AUTO lets the library choose by batch size: fastest per batch, not batch-independent;
+  // 2 = AFX_FRAME_KERNEL_HALFWAVE).  Throws TReadableException when the GPU path cannot be set up.
+  TSampleAnalyser(int SampleRate, int FftFrameSize, int HopFrameSize, int Device = 0, int FrameKernel = 1);
   ~TSampleAnalyser();
   TSampleAnalyser(const TSampleAnalyser&) = delete;
   TSampleAnalyser& operator=(const TSampleAnalyser&) = delete;

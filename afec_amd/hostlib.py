@@ -133,3 +133,12 @@ def set_device_bytes_per_batch(n_bytes):
     L.afec_crawl_set_device_bytes_per_batch.restype = None
     L.afec_crawl_set_device_bytes_per_batch.argtypes = [ctypes.c_int64]
     L.afec_crawl_set_device_bytes_per_batch(int(n_bytes))
+
+
+def set_frame_kernel(frame_kernel):
+    """TCrawlOptions::mFrameKernel of the crawls that follow: -1 the default (pinned: one frame per 64-lane wave), 0 the
+    library's choice by batch size (not batch-independent), 1 / 2 the 64-lane / the half-wave layout."""
+    L = lib()
+    L.afec_crawl_set_frame_kernel.restype = None
+    L.afec_crawl_set_frame_kernel.argtypes = [ctypes.c_int32]
+    L.afec_crawl_set_frame_kernel(int(frame_kernel))

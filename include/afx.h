@@ -114,13 +114,16 @@ typedef struct {
   int32_t max_analysis_ms; /* MAnalyzationDurationMaxInMs = 20000 (SampleAnalyser.cpp:37);
                               0 disables the cap (synthetic benchmarks)                       */
   int32_t frame_kernel;    /* AFX_FRAME_KERNEL_*: layout of the STFT kernel for the batches the half-wave layout serves
-                              (float PCM; AFX_D_MFCC alone or with any of bits 1..7); results agree to rounding   */
+                              (float PCM); results agree to rounding (1e-6; discrete descriptors may flip), so a caller
+                              whose results must not depend on how its files were batched pins WAVE64 or HALFWAVE
+                              (the host layer's TSampleAnalyser / TCrawler do)                                    */
   int32_t flags;           /* AFX_PLAN_* bits                                                  */
 } afx_plan_desc;
 enum {
-  AFX_FRAME_KERNEL_AUTO = 0,     /* by batch size (what a zeroed field means)                                   */
-  AFX_FRAME_KERNEL_WAVE64 = 1,   /* one frame per 64-lane wave for every batch (A/B timing, tests)             */
-  AFX_FRAME_KERNEL_HALFWAVE = 2  /* one frame per 32-lane half for every batch the layout serves (tests)       */
+  AFX_FRAME_KERNEL_AUTO = 0,     /* by batch size (what a zeroed field means): fastest per batch, the layout -- and with it
+                                    the last bits of a file's descriptors -- depends on the batch                  */
+  AFX_FRAME_KERNEL_WAVE64 = 1,   /* one frame per 64-lane wave for every batch                                    */
+  AFX_FRAME_KERNEL_HALFWAVE = 2  /* one frame per 32-lane half for every batch the layout serves                  */
 };
 enum {
   AFX_PLAN_NO_SIDE_STREAM = 1u << 0 /* the rhythm tracker's kernels run on the batch's own stream instead of beside the
@@ -302,9 +305,10 @@ int afx_batch_fetch_records(afx_batch* batch, double* records, double* statistic
  * resample_open(1, f, f) + one resample_process call, f = plan rate / file rate, on the mono mix; afx_resample.hip);
  * afx_load_info and the rhythm tracker's duration heuristics then see the file's own rate and length
  * (TSampleData::mOriginalSampleRate / mOriginalNumberOfSamples).  A file above 16 x the plan's rate gets
- * AFX_ERR_UNSUPPORTED in its buf_status, and so does a file whose conversion would blow it up beyond reason (a rate
- * below the plan's / 64, or more than 2^28 converted samples: a header claiming 1 Hz must fail that file, not exhaust the
- * device for the batch).  Decoding the container stays with the caller. */
+ * AFX_ERR_UNSUPPORTED in its buf_status, and so does a file whose conversion yields 2^30 samples or more (6.8 hours at
+ * 44.1 kHz; the kernels index a file's samples with 32 bits): a header claiming 1 Hz must fail that file, not exhaust the
+ * device for the batch.  (Until round 5: a rate below the plan's / 64, or 2^28 samples -- a two-hour recording at 48 kHz
+ * failed.)  Decoding the container stays with the caller. */
 enum {
   AFX_RAW_I16 = 0, /* int16                      (S16BitSignedTo16BitFloat, SampleConverter.h:446-449) */
   AFX_RAW_I24 = 1, /* packed little-endian int24 (S24BitTo16BitFloat, SampleConverter.h:474-486)       */
@@ -389,7 +393,8 @@ int afx_plan_set_blocking_wait(afx_plan* plan, int32_t blocking);
 /* Does the plan's device still answer?  AFX_OK, or AFX_ERR_HIP when the runtime reports an error for a trivial request
  * on this device (after a fault that took the context down every call fails).  A caller whose batch failed uses this to
  * tell "this batch cannot be analysed" (retry smaller, record the file as failed, go on: SampleAnalyser.cpp:368-408)
- * from "nothing more can be analysed".  Cheap, no device-wide synchronisation. */
+ * from "nothing more can be analysed".  Cheap: allocates nothing (after an out-of-memory failure an allocation could
+ * fail on a live device) and waits for nothing but a 4-byte write on a stream of its own. */
 int afx_plan_probe_device(afx_plan* plan);
 
 /* static facts for roofline accounting (bytes the algorithm must move per frame for `mask`) */

@@ -393,8 +393,9 @@ def test_a_lost_device_ends_the_crawl():
 
 def test_a_file_whose_header_would_blow_it_up_fails_alone(tmp_path):
     """A small file whose header claims 1 Hz would be 2^31 samples once converted to 44.1 kHz: it is refused by itself
-    (AFX_ERR_UNSUPPORTED -> a failed row), its batch is analysed; a file at 1 kHz (x 44.1) is converted, and the batch
-    it is in is cut by the device budget (TCrawlOptions::mDeviceBytesPerBatch) instead of growing the workspace."""
+    (AFX_ERR_UNSUPPORTED -> a failed row), its batch is analysed; files at 1 kHz (x 44.1) and 500 Hz (x 88.2: refused
+    until round 5, when any rate below the analyser's / 64 was) are converted like the reference converts them, and the
+    batch they are in is cut by the device budget (TCrawlOptions::mDeviceBytesPerBatch) instead of growing the workspace."""
     from afec_amd import hostlib
     images, names, _ = make_crawl(20)
     rng = np.random.default_rng(4)
@@ -404,12 +405,50 @@ def test_a_file_whose_header_would_blow_it_up_fails_alone(tmp_path):
     db = str(tmp_path / "odd.db")
     st = _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=64, database=db)
     s = statuses(db)
-    assert s["Odd/one_hertz.wav"].startswith("error: Sample failed to load: ") and s["Odd/five_hundred_hertz.wav"].startswith("error: Sample failed to load: ")
-    assert s["Odd/one_kilohertz.wav"] == "succeeded"
-    assert st["files"] == len(images) and st["failed"] == 3 and st["retried_batches"] == 0
+    assert s["Odd/one_hertz.wav"].startswith("error: Sample failed to load: ")
+    assert s["Odd/one_kilohertz.wav"] == "succeeded" and s["Odd/five_hundred_hertz.wav"] == "succeeded"
+    assert st["files"] == len(images) and st["failed"] == 2 and st["retried_batches"] == 0
     try:
         hostlib.set_device_bytes_per_batch(4 << 20)          # the 1 kHz file alone is 176 400 converted samples = 2.8 MB
         cut = _host.crawl(images, names, devices=(0,), workers=2, files_per_batch=64)
     finally:
         hostlib.set_device_bytes_per_batch(0)
-    assert cut["batches"] > st["batches"] and cut["frames"] == st["frames"] and cut["failed"] == 3
+    assert cut["batches"] > st["batches"] and cut["frames"] == st["frames"] and cut["failed"] == 2
+
+
+
+def test_a_files_row_does_not_depend_on_the_batch_it_was_crawled_in(tmp_path):
+    """The library's AUTO picks the STFT kernel's layout by batch size (~32 768 frames) and the two layouts round
+    differently: with AUTO in the crawler a file's database row depended on the batch it landed in -- the tail batch of a
+    crawl, the halves of a retried batch.  The crawler pins the layout (TCrawlOptions::mFrameKernel): 600 two-second
+    files crawled in batches of 512 (43 000 frames: above the threshold, + a tail batch of 88 files below it) and in
+    batches of 64 give byte-identical rows; with AUTO forced the rows differ, which is what the pin is for."""
+    from afec_amd import hostlib
+    rng = np.random.default_rng(93)
+    pool = []
+    for _ in range(8):
+        x, ch = synth(rng, 2.0, stereo=False)
+        pool.append(wav_bytes(np.round(x * 32767).astype(np.int16), ch, 16))
+    images = [pool[i % 8] for i in range(600)]
+    names = [f"pin/file{i:04d}.wav" for i in range(600)]
+    dbs = [str(tmp_path / f"{k}.db") for k in ("big", "small", "auto_big", "auto_small")]
+    _host.crawl(images, names, workers=2, files_per_batch=512, database=dbs[0])
+    _host.crawl(images, names, workers=2, files_per_batch=64, database=dbs[1])
+    a, b = rows_by_hash(dbs[0]), rows_by_hash(dbs[1])
+    assert len(a) == 600 and a == b
+    # the same 8 contents: every copy of a content has one and the same row
+    con = sqlite3.connect(dbs[0])
+    blobs = {}
+    for name, blob in con.execute("SELECT filename, cepstrum_bands_VVR FROM assets"):
+        blobs.setdefault(int(name[-8:-4]) % 8, set()).add(blob)
+    con.close()
+    assert all(len(v) == 1 for v in blobs.values())
+    try:
+        hostlib.set_frame_kernel(0)   # AFX_FRAME_KERNEL_AUTO: what the crawler ran until round 5
+        _host.crawl(images, names, workers=2, files_per_batch=512, database=dbs[2])
+        _host.crawl(images, names, workers=2, files_per_batch=64, database=dbs[3])
+    finally:
+        hostlib.set_frame_kernel(-1)
+    c, d = rows_by_hash(dbs[2]), rows_by_hash(dbs[3])
+    assert d == b                    # small batches: the 64-lane layout either way
+    assert c != d                    # ... and AUTO's large batches took the other layout: rows that depend on the batch

@@ -115,3 +115,31 @@ def test_pipeline_matches_oracle_on_sampled_files(shape, n_files, n_sampled):
                 assert np.all(ok), (shape, int(i), field, w, gs[w], want)
     batch.close()
     plan.close()
+
+
+
+def test_whole_file_whitening_chunks_match_the_oracle():
+    """Batches of >= 768 short files: the whitening kernels walk every file as one chunk from the follower's reset state
+    and follow_kernel is not launched (afx_batch_plan.cpp: cut_whitening_chunks) -- the path bench.py's C3 / C4 chains
+    take.  900 one-second files with every per-frame descriptor; the whitened-spectrum neighbours (spectral complexity,
+    fail-safe f0, ...) and the rest of a sample of the files against the oracle."""
+    from tests._oracle import NEIGH_FIELDS
+    rng = np.random.default_rng(52)
+    files = [synth_file(rng, 1.0, False) for _ in range(900)]
+    plan = afx.Plan()
+    batch, infos = plan.batch_from_raw(files, afx.D_ALL_PER_FRAME)
+    batch.run()
+    res = batch.fetch()
+    off = res["frame_offset"]
+    ora = Oracle()
+    for i in rng.choice(900, 12, replace=False):
+        mono, _ = _oracle.load_sample(*files[i])
+        ref, nref = ora.run(mono, cap=True), ora.run_neighbours(mono, cap=True)
+        assert off[i + 1] - off[i] == ref.shape[0] <= 128
+        for field, col in NEIGH_FIELDS.items():
+            _tol.check_gpu(field, res[field][off[i]:off[i + 1]], nref[:, col], what=f"file {i} ")
+        for field, (a, b) in FIELDS.items():
+            if field != "mag":
+                _tol.check_gpu(field, res[field][off[i]:off[i + 1]].reshape(ref.shape[0], -1), ref[:, a:b], what=f"file {i} ")
+    batch.close()
+    plan.close()

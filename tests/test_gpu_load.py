@@ -264,7 +264,10 @@ def test_a_files_rows_do_not_depend_on_the_batch_it_was_analysed_in(kernel):
     plan = afx.Plan(frame_kernel=afx.FRAME_KERNEL_WAVE64 if kernel == "wave64" else afx.FRAME_KERNEL_HALFWAVE)
     mask = afx.D_ALL_PER_FRAME | afx.D_STATISTICS
     results, chunk_frames = [], set()
-    for n_files in (4, 9, 150, 601):
+    # (800: from 768 buffers on the whitening kernels take a whole file of <= 128 frames as ONE chunk and follow_kernel is
+    # not launched -- afx_batch_plan.cpp, cut_whitening_chunks -- where the smaller batches walk chunks of K frames from
+    # follower states follow_kernel left: the same bits either way)
+    for n_files in (4, 9, 150, 601, 800):
         b, _ = plan.batch_from_raw([(pool[i % 4], 1) for i in range(n_files)], mask)
         chunk_frames.add(b.info()["chunk_frames"])
         b.run()

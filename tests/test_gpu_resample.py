@@ -137,6 +137,38 @@ def test_a_long_file_and_a_lone_sample():
     plan.close()
 
 
+def test_a_file_of_more_than_2_28_converted_samples_is_analysed():
+    """A 1.7-hour recording: 136 M samples at 22.05 kHz are 272 M (> 2^28) at the analyser's rate.  Until round 5 such a file
+    got AFX_ERR_UNSUPPORTED (a failed row) where the reference converts it and analyses its first 20 s; the bound is 2^30
+    now.  LoadSample's normalisation and trim see the WHOLE converted file (the peak sits an hour in, the last audible
+    sample at the very end): offsets, peak and the analysed prefix equal the oracle's bit for bit.  The oracle needs
+    ~1 minute of CPU for it: AFX_SLOW_TESTS=1 (run by tools/gpu.sh slow; profiles/r05/slow_tests.log)."""
+    import os
+    if not os.environ.get("AFX_SLOW_TESTS"):
+        pytest.skip("AFX_SLOW_TESTS=1: one minute of oracle time")
+    rng = np.random.default_rng(21)
+    n = (1 << 27) + 2_000_000
+    d = np.zeros(n, dtype=np.int16)
+    d[3000:3000 + 66150] = burst(rng, 66150, 22050)                    # what the analysed 20 s hold
+    d[n // 2:n // 2 + 4000] = np.round(30000 * rng.uniform(-1, 1, 4000)).astype(np.int16)   # the file's peak, an hour in
+    d[-3000:-2000] = 2000                                              # the last audible samples
+    plan = afx.Plan()
+    batch, infos = plan.batch_from_raw([(d, 1, 22050)], afx.D_MFCC)
+    batch.run()
+    assert batch.fetch()["buf_status"].tolist() == [0]
+    assert infos[0]["n_samples"] > 1 << 28
+    want, winfo = _oracle.load_sample(d, 1, file_rate=22050)
+    for k in ("data_offset", "silent_leading", "silent_trailing", "n_samples"):
+        assert infos[0][k] == winfo[k], (k, infos[0][k], winfo[k])
+    assert np.float32(infos[0]["peak_value"]) == np.float32(winfo["peak_value"])
+    frames = plan.num_frames(winfo["n_samples"])                       # the 20 s cap: 860 frames
+    assert frames == 860 and batch.total_frames == frames
+    kept = (frames - 1) * 1024 + 2048
+    np.testing.assert_array_equal(batch.fetch_samples(0, kept).view(np.uint64), want[:kept].view(np.uint64))
+    batch.close()
+    plan.close()
+
+
 def test_real_audio_at_another_rate_through_the_crawler(tmp_path):
     """The reference's own fixture WAVs (tests/golden/wav/) with their headers relabelled 48 kHz and 32 kHz: crawled into
     the database, the per-frame series of the converted audio against the oracle chain (its converter is pinned on the

@@ -11,6 +11,7 @@
 #   ab=<bench args>@<lib>,<lib>  steady per-kernel durations of builds under afec_amd/lib/<lib>/ (kernel trace only)
 #   steps=<lib>,<lib>            whole-step rates of builds on the six bench configurations, two passes
 #   fuzz=<seconds>,<seed>[,stats]  tests/fuzz_gpu.py (stats: the half-wave statistics classes)
+#   slow                         the tests behind AFX_SLOW_TESTS=1                   -> $O/slow_tests.log
 #   soak=<seconds>               tools/crawl_soak.py
 #   small                        single_buffer / x_batchsize / x_classes / e2e accounting / shards8
 # Every stage prints a short tail; the full outputs stay under gpurun_out/$AFX_ROUND/.
@@ -57,6 +58,9 @@ for STAGE in "$@"; do
                  "c2 --mask all --steps 10 --warmup 3" "c2 --mask star --steps 20 --warmup 5" "c2 --steps 20 --warmup 5"; do
           echo "== $L bench $W: $(AFX_LIBRARY=$(lib_of $L) python bench.py --workload $W --no-cpu-baseline --no-single --no-spot-check 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(round(d['value']/1e6,2), 'M frames/s', round(d['ms_per_step'],3), 'K', d['config'].get('chunk_frames'))")"
         done; done; done 2>&1 | tee -a $O/ab_steps.txt ;;
+    slow)   # the tests behind AFX_SLOW_TESTS=1 (minutes of oracle time each)
+      AFX_SLOW_TESTS=1 timeout 900 python -m pytest tests/test_gpu_resample.py -m gpu -q -k "2_28" --timeout 800 --timeout-method thread > $O/slow_tests.log 2>&1
+      tail -3 $O/slow_tests.log ;;
     fuzz)
       IFS=, read -r SEC SEED KIND <<< "$ARG"
       if [ "${KIND:-}" = "stats" ]; then

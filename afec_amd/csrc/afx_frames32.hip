@@ -70,21 +70,28 @@ __device__ __forceinline__ double table_load1(__amdgpu_buffer_rsrc_t rs, int lan
 // front of it.  The kernel orders the DMA against its own DS traffic by hand: it is issued behind an explicit
 // s_waitcnt lgkmcnt(0) (the exchange reads have returned) and the hop is read behind an explicit s_waitcnt vmcnt(0).
 // M0 has no other user in this kernel (gfx9 DS instructions do not read it).
-template <int IMM>
+// NT: non-temporal (the classes that read the PCM once); the classes that fetch a hop a second time one frame later, as
+// the next frame's overlap half, leave the first read to the cache's normal policy.
+template <int IMM, bool NT>
 __device__ __forceinline__ void dma_piece(const void* gaddr, unsigned lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2 nt"
-               :: "v"(gaddr), "s"(lds_base), "n"(IMM) : "memory", "m0");
+  if constexpr (NT)
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2 nt"
+                 :: "v"(gaddr), "s"(lds_base), "n"(IMM) : "memory", "m0");
+  else
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
+                 :: "v"(gaddr), "s"(lds_base), "n"(IMM) : "memory", "m0");
 }
 // the eight pieces of a wave's hop image: global piece j at +512 j bytes, LDS piece j at +1024 j
+template <bool NT = true>
 __device__ __forceinline__ void dma_hop(const float* g, unsigned lds_plane) {
-  dma_piece<0>(g, lds_plane);
-  dma_piece<512>(g, lds_plane + 512);
-  dma_piece<1024>(g, lds_plane + 1024);
-  dma_piece<1536>(g, lds_plane + 1536);
-  dma_piece<2048>(g, lds_plane + 2048);
-  dma_piece<2560>(g, lds_plane + 2560);
-  dma_piece<3072>(g, lds_plane + 3072);
-  dma_piece<3584>(g, lds_plane + 3584);
+  dma_piece<0, NT>(g, lds_plane);
+  dma_piece<512, NT>(g, lds_plane + 512);
+  dma_piece<1024, NT>(g, lds_plane + 1024);
+  dma_piece<1536, NT>(g, lds_plane + 1536);
+  dma_piece<2048, NT>(g, lds_plane + 2048);
+  dma_piece<2560, NT>(g, lds_plane + 2560);
+  dma_piece<3072, NT>(g, lds_plane + 3072);
+  dma_piece<3584, NT>(g, lds_plane + 3584);
 }
 
 // Magnitude 2 sqrt(xr^2 + xi^2 + DBL_MIN): v_rsq_f64 seed (~2^-23) + one Newton step y (3 - r y) (~2e-14 relative)
@@ -237,6 +244,9 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
   // the FFT registers spilled those 32 registers (128 B of scratch per lane and frame pair, written and read back: 4 KiB
   // per frame each way -- which the counters showed as HBM traffic, the scratch lines do not survive in L2 next to the
   // streaming stores).
+#ifndef AFX_X_MEL_EARLY
+#define AFX_X_MEL_EARLY 4   // magnitude class: group of the untangle behind which the mel weights are asked for (-1: behind the last)
+#endif
 #ifndef AFX_X_LO_LDS
 #define AFX_X_LO_LDS 0
 #endif
@@ -244,6 +254,20 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
   // statistics class, which spilled 44 bytes, 16.1 -> 17.7 ms and the MFCC class 493 -> 422 M frames/s: they keep the
   // registers)
   constexpr bool LO_LDS = (FEAT >= 2) || AFX_X_LO_LDS;
+  // Cache policy of the classes that fetch every hop twice (round 5, A/B on the C4 share, profiles/r05/ab_cache_policy.txt):
+  // the first read without the non-temporal hint -- the line is asked for again one frame later -- and the magnitude
+  // stores with it (8 KiB per frame streaming through L2 would push those lines out): 2.14 -> 2.02 ms.
+#ifndef AFX_X_HOP_NT
+#define AFX_X_HOP_NT 0
+#endif
+#ifndef AFX_X_LO_NT
+#define AFX_X_LO_NT 1
+#endif
+#ifndef AFX_X_ST_NT
+#define AFX_X_ST_NT 1
+#endif
+  constexpr bool kHopNt = !LO_LDS || AFX_X_HOP_NT;   // first read of a hop
+  constexpr bool kLoNt = AFX_X_LO_NT;                // its second read, as the next frame's overlap half
   constexpr bool STATS = (FEAT >= 1 && FEAT <= 3);
   constexpr bool PAIRS = STATS;
   // FEAT 2, 3 ("full" classes, for masks with flux / spectrum bands / sub-band descriptors / amplitude): the statistics
@@ -341,10 +365,10 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) lo[r] = src8[32 * r];
     } else {
-      dma_hop(dsrc - kHop, plane_lds + 8192);   // rows 0..15 of frame 0
+      dma_hop<kLoNt>(dsrc - kHop, plane_lds + 8192);   // rows 0..15 of frame 0
     }
     // frame 0's new hop (every DS operation of the previous chunk has been waited for)
-    dma_hop(dsrc, plane_lds);
+    dma_hop<kHopNt>(dsrc, plane_lds);
 
     double mel_acc = 0.0;  // mel sums of up to two finished frames per half: lane 2 f + slot
     // this lane's output element: coefficient (q >> 1) of the frame in slot q & 1
@@ -471,7 +495,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       // re-reads its own hop (no branch: the loop body stays one basic block).
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       AFX_STAMP(3);   // exchange
-      dma_hop(dsrc + (size_t)min(fi + 1, last_d) * kHop, plane_lds);
+      dma_hop<kHopNt>(dsrc + (size_t)min(fi + 1, last_d) * kHop, plane_lds);
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- T + P2: v[k2] = Z[q + 32 k2]; the factors w1024^(n2 k1) are fused into the first radix-4 stage of
@@ -530,7 +554,12 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 #if defined(AFX_X_NOSTORE)   // timing experiment only (never the shipped library): what the magnitude stores cost
       auto store_mag = [&](double* p, double value) { asm volatile("" :: "v"(p), "v"(value)); };
 #else
+#if AFX_X_ST_NT
+      auto store_mag = [&](double* p, double value) { __builtin_nontemporal_store(value > logc[kCSqrtMin] ? value : 0.0, p); };
+#else
       auto store_mag = [&](double* p, double value) { *p = value > logc[kCSqrtMin] ? value : 0.0; };
+#endif
+
 #endif
       if (STATS) {
         int ql = lane;
@@ -651,6 +680,17 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           mag_rows();
           untangle(2 * g);
           untangle(2 * g + 1);
+#if AFX_X_MEL_EARLY >= 0
+          // The packed mel rows, asked for in the MIDDLE of the untangle: on gfx950 stores count in vmcnt like loads and
+          // retire in order, so weights asked for behind the frame's last store (where the last FFT registers die) made the
+          // mel stage wait for every store of the frame.  Half-way through, the rows already untangled have freed 16
+          // registers per group; the loads then wait only for the stores issued before them, which are long done when
+          // the mel stage starts, and the compiler's wait count lets the later stores stay in flight.
+          if (g == AFX_X_MEL_EARLY) {
+#pragma unroll
+            for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
+          }
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         // bin 512 = lane 0 of row 16 is its own partner: E = 2 Re Z, w O = -2i Im Z (the window carries the 1/2)
@@ -698,7 +738,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       for (int r = 8; r < 12; ++r) untangle(r);
       __builtin_amdgcn_sched_barrier(0);
       }
-      if (STATS || MAGS) {   // statistics / magnitude classes: behind the last rows (62 registers in flight that they cannot spare earlier)
+      if (STATS || (MAGS && AFX_X_MEL_EARLY < 0)) {   // statistics class: behind the last rows (62 registers in flight that it cannot spare earlier)
 #pragma unroll
         for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
       }
@@ -767,7 +807,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 #pragma unroll
           for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
           // (the parked rows have been read: the upper half of the plane is free for the next frame's overlap rows)
-          if constexpr (LO_LDS) dma_hop(dsrc + (size_t)min(fi + 1, last_d) * kHop - kHop, plane_lds + 8192);
+          if constexpr (LO_LDS) dma_hop<kLoNt>(dsrc + (size_t)min(fi + 1, last_d) * kHop - kHop, plane_lds + 8192);
         }
         if (FEAT == 0 || MAGS) {
           if (MAGS) {   // the two free slots of the reduction: spectrum bands 26, 27 (x 4: the window carries an extra 1/2)
@@ -885,7 +925,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 
 #pragma unroll
           for (int r = 0; r < 32; ++r) w[r] = table_load2(win_rs, q16, 512 * r);
-          if constexpr (LO_LDS) dma_hop(dsrc + (size_t)min(fi + 1, last_d) * kHop - kHop, plane_lds + 8192);
+          if constexpr (LO_LDS) dma_hop<kLoNt>(dsrc + (size_t)min(fi + 1, last_d) * kHop - kHop, plane_lds + 8192);
         }
         if (fi & 1) finish_mfcc32(mel_acc, recp, left, stride2, dct, logc, lane);
         AFX_STAMP(9);   // log + DCT + store (every second iteration)

@@ -84,10 +84,43 @@ __device__ __forceinline__ double keep_or_one(double v, mask64 m) {
   return __hiloint2double(hi, lo);
 }
 
+// Lane masks of the (band, row) pairs as compile-time constants: which lanes of row r (bins 64 r .. 64 r + 63) hold bins
+// [lo, hi).  They depend on nothing but the lane, so they are 64-bit literals the scalar unit materialises where they are
+// used (two s_mov_b32, off the vector pipe) -- until round 5 the sub-bands' masks were 25 ballots held in 50 SGPRs for the
+// whole kernel and the spectrum bands' were two v_cmp per pair and frame.
+__attribute__((always_inline)) constexpr mask64 row_mask(int r, int lo, int hi) {
+  const int l0 = lo - 64 * r < 0 ? 0 : (lo - 64 * r > 64 ? 64 : lo - 64 * r);   // lanes [l0, l1)
+  const int l1 = hi - 64 * r < 0 ? 0 : (hi - 64 * r > 64 ? 64 : hi - 64 * r);
+  const mask64 below_l1 = l1 >= 64 ? ~0ull : ((1ull << l1) - 1ull);
+  const mask64 below_l0 = l0 >= 64 ? ~0ull : ((1ull << l0) - 1ull);
+  return l1 > l0 ? (below_l1 & ~below_l0) : 0ull;
+}
+// (as tables: an unrolled loop's index into a constant table folds to the literal; the expression itself did not)
+struct SubMaskTable { mask64 m[kNumSub][kRows]; };
+struct SpectrumMaskTable { mask64 m[kNumBands][kRows]; };
+constexpr SubMaskTable make_sub_masks() {
+  SubMaskTable t{};
+  for (int b = 0; b < kNumSub; ++b)
+    for (int r = 0; r < kRows; ++r) t.m[b][r] = row_mask(r, kSubStart[b], kSubStart[b + 1]);
+  return t;
+}
+constexpr SpectrumMaskTable make_spectrum_masks() {
+  SpectrumMaskTable t{};
+  for (int b = 0; b < kNumBands; ++b)
+    for (int r = 0; r < kRows; ++r) t.m[b][r] = row_mask(r, kBandEdge[b], kBandEdge[b + 1]);
+  return t;
+}
+constexpr SubMaskTable kSubMasks = make_sub_masks();
+constexpr SpectrumMaskTable kSpectrumMasks = make_spectrum_masks();
+__attribute__((always_inline)) constexpr mask64 sub_mask(int b, int r) { return kSubMasks.m[b][r]; }
+__attribute__((always_inline)) constexpr mask64 spectrum_mask(int b, int r) { return kSpectrumMasks.m[b][r]; }
+constexpr mask64 kFirstRowOk = row_mask(0, kFirstBin, 64);                               // bins 1..63
+constexpr mask64 kLastRowOk = row_mask(kRows - 1, 64 * (kRows - 1), kLastBin + 1);       // bins 704..738
+
 // per-band sum of one value per row; lane L receives the total of band (L >> 2) & 15
 // whole: one more per-lane value, summed over the wave into "band" kWholeBand
 template <typename F>
-__device__ __forceinline__ double band_sum(F value_of_row, const mask64 (&bm)[kSubPairs], int lane, double whole = 0.0) {
+__device__ __forceinline__ double band_sum(F value_of_row, int lane, double whole = 0.0) {
   double acc[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
@@ -97,7 +130,7 @@ __device__ __forceinline__ double band_sum(F value_of_row, const mask64 (&bm)[kS
 #pragma unroll
       for (int r = 0; r < kRows; ++r)
         if (sub_touches(b, r)) {
-          const double v = sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), bm[sub_pair_index(b, r)]);
+          const double v = sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), sub_mask(b, r));
           acc[b] = first ? v : acc[b] + v;
           first = false;
         }
@@ -106,7 +139,7 @@ __device__ __forceinline__ double band_sum(F value_of_row, const mask64 (&bm)[kS
   return wave_sum16(acc, lane);
 }
 template <typename F>
-__device__ __forceinline__ double band_max(F value_of_row, const mask64 (&bm)[kSubPairs], int lane) {
+__device__ __forceinline__ double band_max(F value_of_row, int lane) {
   double acc[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) {
@@ -116,7 +149,7 @@ __device__ __forceinline__ double band_max(F value_of_row, const mask64 (&bm)[kS
 #pragma unroll
       for (int r = 0; r < kRows; ++r)
         if (sub_touches(b, r)) {
-          const double v = sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), bm[sub_pair_index(b, r)]);
+          const double v = sub_covers(b, r) ? value_of_row(r) : keep_where(value_of_row(r), sub_mask(b, r));
           acc[b] = first ? v : fmax(acc[b], v);
           first = false;
         }
@@ -143,9 +176,8 @@ __device__ __forceinline__ double spectrum_band_sums(const double (&xx)[12], int
 #pragma unroll
         for (int r = 0; r < 12; ++r)
           if (band_touches(b, r)) {
-            const int k = 64 * r + lane;
             const bool whole = kBandEdge[b] <= 64 * r && kBandEdge[b + 1] - 1 >= 64 * r + 63;
-            const double v = (whole || (k >= kBandEdge[b] && k < kBandEdge[b + 1])) ? xx[r] : 0.0;
+            const double v = whole ? xx[r] : keep_where(xx[r], spectrum_mask(b, r));
             acc[i] = first ? v : acc[i] + v;
             first = false;
           }
@@ -331,6 +363,30 @@ __device__ __noinline__ double exact_cut_sum(const double* cur, int b, u32 cut_k
   return strict + tsum;
 }
 
+// LDS-DMA of 16 bytes per lane (lane L's bytes land at lds_base + IMM + 16 L, read from gaddr + IMM): how a frame's
+// spectrum reaches the wave's LDS image while the wave works on the frame before.  Inline assembly for the reason
+// given in afx_frames32.hip (the builtin makes the compiler put s_waitcnt vmcnt(0) in front of every later DS read);
+// the kernel orders it against its own DS traffic by hand.  M0 has no other user here.
+template <int IMM>
+__device__ __forceinline__ void dma_16(const void* gaddr, unsigned lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off offset:%2"
+               :: "v"(gaddr), "s"(lds_base), "n"(IMM) : "memory", "m0");
+}
+// bins 0..767 of one frame (6 KiB): lane L moves bins 2 L, 2 L + 1 of every 128-bin piece
+__device__ __forceinline__ void dma_frame(const double* frame, int lane, unsigned lds_image) {
+  const unsigned char* const g = reinterpret_cast<const unsigned char*>(frame) + 16 * lane;
+  dma_16<0>(g, lds_image);
+  dma_16<1024>(g, lds_image);
+  dma_16<2048>(g, lds_image);
+  dma_16<3072>(g, lds_image);
+  dma_16<0>(g + 4096, lds_image + 4096);
+  dma_16<1024>(g + 4096, lds_image + 4096);
+}
+
+#ifndef AFX_X_BANDS_DMA
+#define AFX_X_BANDS_DMA 1
+#endif
+
 // FLAGS: the kBands* bits as a compile-time constant for the combinations the planner produces for whole descriptor
 // sets (what is not selected costs neither instructions nor registers), -1: read BandArgs::flags
 template <int FLAGS>
@@ -345,7 +401,12 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   __shared__ double s_cn[4][48];   // per band: 1 / bins, 1 / neighbours, bins
   __shared__ u32 s_sel[4][8];      // the cut keys of the two bands that lie across a block boundary of the sort
   __shared__ int s_cutpos[4][32];  // per band: position of the valley's cut key, of the peak's
-  __shared__ double s_nat[4][64 * kRows];   // kBandsStats: the frame's bins in natural order for the rolloff walk
+  // The wave's image of the frame it works on, bins 0..767 in natural order: filled by LDS-DMA while the frame before is
+  // being worked on (issued once the last read of the image is done, about a third into a frame), so a frame's spectrum
+  // is not waited for at the top of the loop; the rolloff walk (kBandsStats) and the local maxima's neighbour bins read
+  // it too (until round 5: twelve global loads at the top of every frame, waited for at once; a natural-order copy written
+  // back to LDS for the rolloff; 24 more global loads for the neighbours)
+  __shared__ __align__(16) double s_nat[4][64 * kRows];
   __shared__ LogEntry s_log[4][64];
   __shared__ double s_park[4][4 * kParked * 16];   // [frame of the group][quantity][band]
   double* const thr = s_thr[threadIdx.x >> 6];
@@ -355,6 +416,10 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
   u32* const sel = s_sel[threadIdx.x >> 6];
   int* const cutpos = s_cutpos[threadIdx.x >> 6];
   double* const nat = s_nat[threadIdx.x >> 6];
+  typedef __attribute__((address_space(3))) void lvoid;
+  const unsigned nat_lds = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(lvoid*)nat);   // its LDS byte address (M0 of the DMA)
+  using lds_vdouble = volatile __attribute__((address_space(3))) double;
+  lds_vdouble* const image = (lds_vdouble*)nat;
   LogEntry* const logt = s_log[threadIdx.x >> 6];
   double* const park = s_park[threadIdx.x >> 6];
   band_log_table(logt, lane);
@@ -380,12 +445,6 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
 
   // lane-only facts, once per wave: membership masks of the (band, row) pairs, the band of each of the
   // lane's bins, the analysis-range masks of the first and last row
-  mask64 bm[kSubPairs];
-#pragma unroll
-  for (int b = 0; b < kNumSub; ++b)
-#pragma unroll
-    for (int r = 0; r < kRows; ++r)
-      if (sub_touches(b, r)) bm[sub_pair_index(b, r)] = __ballot(in_band(b, r, lane));
   int bid[kRows];
 #pragma unroll
   for (int r = 0; r < kRows; ++r) {
@@ -394,8 +453,6 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     for (int b = 0; b < kNumSub; ++b)
       if (sub_touches(b, r)) bid[r] = in_band(b, r, lane) ? b : bid[r];
   }
-  const mask64 first_row_ok = __ballot(lane >= kFirstBin);                        // bins 1..63
-  const mask64 last_row_ok = __ballot(64 * (kRows - 1) + lane <= kLastBin);       // bins 704..738
 
   for (int ci = wave0; ci < a.n_chunks; ci = next_item(a.queue, ci, min(stride, a.n_chunks), stride, lane)) {
     const Chunk ch = a.chunks[ci];
@@ -419,21 +476,26 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
 #pragma unroll
         for (int r = 0; r < kRows; ++r) {
           const bool edge = r == 0 || r == kRows - 1;
-          const mask64 ok = (r == 0) ? first_row_ok : last_row_ok;
+          const mask64 ok = (r == 0) ? kFirstRowOk : kLastRowOk;
           fb += edge ? keep_where(y[r], ok) : y[r];
           fbb += edge ? keep_where(yy[r], ok) : yy[r];
         }
       }
       if (flags & kBandsFeatures) {
         // (with the sub-bands selected the sums of spectral_flux over the whole range are band kWholeBand of the reductions)
-        sy = band_sum([&](int r) { return y[r]; }, bm, lane, fb);
-        syy = band_sum([&](int r) { return yy[r]; }, bm, lane, fbb);
+        sy = band_sum([&](int r) { return y[r]; }, lane, fb);
+        syy = band_sum([&](int r) { return yy[r]; }, lane, fbb);
       }
     }
     if (!(flags & kBandsFeatures) && (flags & kBandsFlux)) {
       fb = wave_sum(fb); fbb = wave_sum(fbb);
     }
 
+#if AFX_X_BANDS_DMA
+    // the chunk's first frame (every DS read of the chunk before has been waited for: its results were stored)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    dma_frame(a.mag + (int64_t)ch.frame0 * kHalf, lane, nat_lds);
+#endif
   for (int fi = 0; fi < ch.nframes; ++fi) {
     // lane-only predicates other than the membership masks (reduction selects, sort directions, position
     // ranges) are recomputed per frame from a re-materialised lane id: hoisted out of the loop they would
@@ -442,8 +504,14 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     asm volatile("" : "+v"(lane_v));
     const int64_t f = (int64_t)ch.frame0 + fi;
     const double* const cur = a.mag + f * kHalf;
+#if AFX_X_BANDS_DMA
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the frame's image has landed
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) x[r] = image[64 * r + lane_v];
+#else
 #pragma unroll
     for (int r = 0; r < kRows; ++r) x[r] = cur[64 * r + lane_v];
+#endif
     // products rounded on their own (mul_rn): see the chunk prologue
     double xx[kRows], xy[kRows];
 #pragma unroll
@@ -466,7 +534,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       double mrow[kRows];
 #pragma unroll
       for (int r = 0; r < kRows; ++r) {
-        const double m = (r == 0) ? keep_where(x[r], first_row_ok) : (r == kRows - 1 ? keep_where(x[r], last_row_ok) : x[r]);
+        const double m = (r == 0) ? keep_where(x[r], kFirstRowOk) : (r == kRows - 1 ? keep_where(x[r], kLastRowOk) : x[r]);
         mrow[r] = m;
         const double m2 = m * m, jm = jq * m;
         s1 += m;
@@ -477,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
         s4 = fma(m2, m2, s4);
         // (bins outside the range: factor 1)
         const double f = m + 1e-20;
-        prod *= (r == 0) ? keep_or_one(f, first_row_ok) : (r == kRows - 1 ? keep_or_one(f, last_row_ok) : f);
+        prod *= (r == 0) ? keep_or_one(f, kFirstRowOk) : (r == kRows - 1 ? keep_or_one(f, kLastRowOk) : f);
         jq += 64.0;
       }
       double st[16];
@@ -490,15 +558,22 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       // rolloff (scalar.c:472-492): bins whose running sum stays below 85 % of the total: natural-order copy in LDS, each
       // lane walks 12 consecutive bins
       const double total = read_lane<0>(red);
+#if !AFX_X_BANDS_DMA
       wave_lds_fence();
 #pragma unroll
       for (int r = 0; r < kRows; ++r) nat[64 * r + lane_v] = mrow[r];
       wave_lds_fence();
+#endif
+      // (the image holds the stored magnitudes as they are: bin 0 is never walked, bins above the range are cut here)
       double seg[12], segsum = 0.0;
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
         const int k = kFirstBin + 12 * lane_v + i;
+#if AFX_X_BANDS_DMA
+        seg[i] = (k <= kLastBin) ? image[k < 64 * kRows ? k : 0] : 0.0;
+#else
         seg[i] = (k <= kLastBin) ? nat[k < 64 * kRows ? k : 0] : 0.0;
+#endif
         segsum += seg[i];
       }
       const double incl = wave_scan_incl(segsum, lane_v);
@@ -515,9 +590,21 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       int cnt = (pivot > 0.0) ? below + 1 : 0;
       if (cnt > kBinCount) cnt = kBinCount;
       if (lane_v == 0) tmp[7] = (double)cnt;
+#if !AFX_X_BANDS_DMA
       wave_lds_fence();
+#endif
     }
-    if (!(flags & (kBandsFeatures | kBandsFlux))) continue;
+#if AFX_X_BANDS_DMA
+    // the next frame's image, asked for once this frame's has been read for the last time (the chunk's last frame asks for
+    // its own again: no branch around the DMA)
+    auto next_image = [&]() {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      dma_frame(cur + ((fi + 1 < ch.nframes) ? kHalf : 0), lane_v, nat_lds);
+    };
+#else
+    auto next_image = [&]() {};
+#endif
+    if (!(flags & (kBandsFeatures | kBandsFlux))) { next_image(); continue; }
 
     // ---- spectral_flux: Pearson r with the previous frame over bins 1..738 (SA:1919-1933,
     //      Statistics.cpp:604-638) ----
@@ -527,7 +614,7 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
 #pragma unroll
       for (int r = 0; r < kRows; ++r) {
         const bool edge = r == 0 || r == kRows - 1;
-        const mask64 ok = (r == 0) ? first_row_ok : last_row_ok;
+        const mask64 ok = (r == 0) ? kFirstRowOk : kLastRowOk;
         fa += edge ? keep_where(x[r], ok) : x[r];
         faa += edge ? keep_where(xx[r], ok) : xx[r];
         fab += edge ? keep_where(xy[r], ok) : xy[r];
@@ -544,21 +631,23 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
         fb = fa; fbb = faa;
 #pragma unroll
         for (int r = 0; r < kRows; ++r) y[r] = x[r];
+        next_image();
         continue;
       }
       flux_a = fa; flux_aa = faa; flux_ab = fab;
     }
 
     // ---- masked per-band sums: lane L ends up with band (L >> 2) & 15 ----
-    const double sx = band_sum([&](int r) { return x[r]; }, bm, lane_v, flux_a);
-    const double sxx = band_sum([&](int r) { return xx[r]; }, bm, lane_v, flux_aa);
-    const double sxy = band_sum([&](int r) { return xy[r]; }, bm, lane_v, flux_ab);
+    const double sx = band_sum([&](int r) { return x[r]; }, lane_v, flux_a);
+    const double sxx = band_sum([&](int r) { return xx[r]; }, lane_v, flux_aa);
+    const double sxy = band_sum([&](int r) { return xy[r]; }, lane_v, flux_ab);
     // geometric mean: sum of log(|x| + 1e-20) (Statistics.cpp:417-455 keeps a running product and
     // takes logs only when it leaves [1e-64, 1e64]; same value up to rounding)
     // the neighbours of this lane's bins in the unsorted spectrum, for the local maxima below (they may reach into the
     // adjacent band; bin 0 and 1023 never count): asked for here, all at once, and used behind the logarithms -- loaded
     // where they are compared, each was a cache round trip of its own in a branch
     double left[kRows], right[kRows];
+#if !AFX_X_BANDS_DMA
 #pragma unroll
     for (int r = 0; r < kRows; ++r) {
       const int k = 64 * r + lane_v;
@@ -566,16 +655,27 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       right[r] = cur[k + 1];
     }
     __builtin_amdgcn_sched_barrier(0);
+#endif
     double lg[kRows];
 #pragma unroll
     for (int r = 0; r < kRows; ++r) lg[r] = band_log(fabs(x[r]) + 1e-20, logt);
-    const double slog = band_sum([&](int r) { return lg[r]; }, bm, lane_v);
-    const double bmax = band_max([&](int r) { return x[r]; }, bm, lane_v);
+    const double slog = band_sum([&](int r) { return lg[r]; }, lane_v);
+    const double bmax = band_max([&](int r) { return x[r]; }, lane_v);
 
     // ---- complexity: strict local maxima above 0.25 * band maximum (SA:2170-2197); counted on the scalar
     //      unit: ballot of the peak flags of a row, masked per band, popcount ----
     wave_lds_fence();
     if ((lane_v & 3) == 0) thr[lane_v >> 2] = bmax * 0.25;
+#if AFX_X_BANDS_DMA
+    // the neighbour bins from the image, where they are compared (bin 768, the right neighbour of a bin outside every
+    // band, is not in the image: any value serves)
+#pragma unroll
+    for (int r = 0; r < kRows; ++r) {
+      const int k = 64 * r + lane_v;
+      left[r] = image[(r == 0) ? k - (k > 0 ? 1 : 0) : k - 1];
+      right[r] = image[(r == kRows - 1) ? (k + 1 < 64 * kRows ? k + 1 : k) : k + 1];
+    }
+#endif
     wave_lds_fence();
     int peaks[kNumSub];
 #pragma unroll
@@ -589,13 +689,16 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       const mask64 pk = __ballot(inside & (t > 0.0) & (x[r] > t) & (x[r] > left[r]) & (x[r] > right[r]));
 #pragma unroll
       for (int b = 0; b < kNumSub; ++b)
-        if (sub_touches(b, r)) peaks[b] += __popcll(pk & bm[sub_pair_index(b, r)]);
+        if (sub_touches(b, r)) peaks[b] += __popcll(pk & sub_mask(b, r));
     }
     // hand every lane_v the count of its band ((lane_v >> 2) & 15) now: the scalar counters die before the sort
     // (v_writelane: the lane that parks band b's sums, 4 b, gets its count -- a select chain over the bands was 43 instructions)
     int cnt = 0;
 #pragma unroll
     for (int i = 0; i < kNumSub; ++i) asm("v_writelane_b32 %0, %1, %2" : "+v"(cnt) : "s"(peaks[i]), "n"(4 * i));
+    // the image has been read for the last time (the ballots above consumed the neighbours): the next frame's travels
+    // while the keys are sorted and the cuts summed
+    next_image();
 
     // ---- contrast: sort (band, value) keys to find the key at each band's two cuts, then exact sums ----
     // The keys go into bin order (position p = bin: lane p / 16, register p % 16) and each block of 256 positions is
@@ -693,10 +796,10 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       double xs[kRows];
 #pragma unroll
       for (int r = 0; r < kRows; ++r) xs[r] = (sort_key(bid[r], x[r]) <= cut[bid[r]]) ? x[r] : 0.0;
-      vsum = band_sum([&](int r) { return xs[r]; }, bm, lane_v);
+      vsum = band_sum([&](int r) { return xs[r]; }, lane_v);
 #pragma unroll
       for (int r = 0; r < kRows; ++r) xs[r] = (sort_key(bid[r], x[r]) >= cut[16 + bid[r]]) ? x[r] : 0.0;
-      psum = band_sum([&](int r) { return xs[r]; }, bm, lane_v);
+      psum = band_sum([&](int r) { return xs[r]; }, lane_v);
     }
     // cuts inside a tie class: exact resolution, band by band (wave-uniform loops; rare)
     for (mask64 m = ties_v; m; m &= m - 1) {

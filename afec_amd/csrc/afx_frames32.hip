@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
   // (measured: magnitude class 2.35 -> 1.99 ms on the C4 share, full classes 23.1 -> 20.7 ms on 5.12 M frames; the
   // statistics class, which spilled 44 bytes, 16.1 -> 17.7 ms and the MFCC class 493 -> 422 M frames/s: they keep the
   // registers)
-  constexpr bool LO_LDS = (FEAT >= 2) || AFX_X_LO_LDS;
+  constexpr bool LO_LDS = (FEAT >= 2 && FEAT <= 4) || AFX_X_LO_LDS;
   // Cache policy of the classes that fetch every hop twice (round 5, A/B on the C4 share, profiles/r05/ab_cache_policy.txt):
   // the first read without the non-temporal hint -- the line is asked for again one frame later -- and the magnitude
   // stores with it (8 KiB per frame streaming through L2 would push those lines out): 2.14 -> 2.02 ms.
@@ -268,7 +268,11 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
 #endif
   constexpr bool kHopNt = !LO_LDS || AFX_X_HOP_NT;   // first read of a hop
   constexpr bool kLoNt = AFX_X_LO_NT;                // its second read, as the next frame's overlap half
-  constexpr bool STATS = (FEAT >= 1 && FEAT <= 3);
+  // FEAT 5: the statistics class for masks without skewness / kurtosis -- the descriptor set BASELINE.json's north star
+  // names (MFCC + rms, centroid, spread, rolloff, flatness) -- keeps no third and fourth moments: four registers and two
+  // operations per magnitude less.
+  constexpr bool STATS = (FEAT >= 1 && FEAT <= 3) || FEAT == 5;
+  constexpr bool MOMENTS34 = (FEAT != 5);
   constexpr bool PAIRS = STATS;
   // FEAT 2, 3 ("full" classes, for masks with flux / spectrum bands / sub-band descriptors / amplitude): the statistics
   // class that also leaves the magnitudes in a.mag_out for bands_kernel and the whitening kernels, the amplitude peak /
@@ -585,8 +589,10 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         s2 += m2;
         sj += jm;
         sjj = fma(j, jm, sjj);
-        s3 = fma(m2, m, s3);
-        s4 = fma(m2, m2, s4);
+        if (MOMENTS34) {
+          s3 = fma(m2, m, s3);
+          s4 = fma(m2, m2, s4);
+        }
         prod_b *= ok ? (value + logc[kCEps]) : 1.0;
       };
       auto accumulate = [&](int r, double* store_at) {
@@ -600,8 +606,10 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         s2 += m2;
         sj += jm;
         sjj = fma(jq, jm, sjj);
-        s3 = fma(m2, m, s3);
-        s4 = fma(m2, m2, s4);
+        if (MOMENTS34) {
+          s3 = fma(m2, m, s3);
+          s4 = fma(m2, m2, s4);
+        }
         const double f = ok ? (mag[r] + logc[kCEps]) : 1.0;
         if (r < 12) prod_a *= f; else prod_b *= f;
         jq += logc[kC32];
@@ -1044,7 +1052,12 @@ hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stre
   if (cls == 0) return scaled ? launch_frames32_class<0, true>(a, grid_blocks, stream) : launch_frames32_class<0, false>(a, grid_blocks, stream);
   if (cls == 4) return scaled ? launch_frames32_class<4, true>(a, grid_blocks, stream) : launch_frames32_class<4, false>(a, grid_blocks, stream);
   hipError_t e;
-  if (scaled)
+#ifndef AFX_X_NO_CLASS5
+#define AFX_X_NO_CLASS5 0
+#endif
+  if (cls == 1 && !(a.mask & 0x30u) && !AFX_X_NO_CLASS5)   // neither skewness nor kurtosis: no third / fourth moments
+    e = scaled ? launch_frames32_class<5, true>(a, grid_blocks, stream) : launch_frames32_class<5, false>(a, grid_blocks, stream);
+  else if (scaled)
     e = (cls == 1) ? launch_frames32_class<1, true>(a, grid_blocks, stream)
                    : (cls == 2 ? launch_frames32_class<2, true>(a, grid_blocks, stream) : launch_frames32_class<3, true>(a, grid_blocks, stream));
   else

@@ -238,13 +238,21 @@ hipError_t stage_and_scan(RawBatch& r, const char** what) {
       r.files[(size_t)r.conv_buf[k]] = LoadFile{r.conv[k].out_off, r.conv[k].n_out, 1, kRawMonoFloat};
   }
   *what = "load_scan";
-  if ((e = hipMemcpyAsync(r.d_files, r.files.data(), r.files.size() * sizeof(LoadFile), hipMemcpyHostToDevice, s)) != hipSuccess) return e;
+  // the file table up and the scan results down through the workspace's page-locked block (pageable copies are staged
+  // by the runtime on this thread and complete through its event thread: host CPU a crawl's workers do not have to spend)
+  const size_t files_bytes = r.files.size() * sizeof(LoadFile), scan_bytes = r.scan.size() * sizeof(LoadScan);
+  const size_t scan_off = (files_bytes + 63) & ~(size_t)63;
+  if ((e = ws_pin_reserve(ws, scan_off + scan_bytes)) != hipSuccess) return e;
+  std::memcpy(ws->h_pin, r.files.data(), files_bytes);
+  if ((e = hipMemcpyAsync(r.d_files, ws->h_pin, files_bytes, hipMemcpyHostToDevice, s)) != hipSuccess) return e;
   // -48 dB of full scale (MSilenceThresholdDb, SampleAnalyser.cpp:51, 648-649)
   const double silence_floor = 32768.0 * std::exp(-48.0 * (std::log(10.0) / 20.0));
   if ((e = launch_load_scan(r.d_raw, r.d_files, n_bufs, silence_floor, ws->partial.p, d_scan, s)) != hipSuccess) return e;
-  if ((e = hipMemcpyAsync(r.scan.data(), d_scan, r.scan.size() * sizeof(LoadScan), hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
+  if ((e = hipMemcpyAsync((unsigned char*)ws->h_pin + scan_off, d_scan, scan_bytes, hipMemcpyDeviceToHost, s)) != hipSuccess) return e;
   *what = "hipStreamSynchronize";
-  return wait_for_stream(ws, s);
+  if ((e = wait_for_stream(ws, s)) != hipSuccess) return e;
+  std::memcpy(r.scan.data(), (const unsigned char*)ws->h_pin + scan_off, scan_bytes);
+  return hipSuccess;
 }
 
 // padding rules of SampleAnalyser.cpp:681-701: where the audible part of every file goes and how long its buffer is

@@ -275,19 +275,51 @@ void cut_whitening_chunks(Planner& p) {
   b->n_wchunks = (int)wchunks.size();
 }
 
-// reserve + (optionally) upload: the two lines every device table of a batch needs
+// Device memory of a batch.  Buffers the kernels only write or read (records, magnitudes, statistics ...) are reserved
+// one by one; the small tables the HOST fills (chunk tables, offsets, the rhythm tracker's file records: nine of them for
+// a crawler's batch) are collected and travel as ONE block -- one page-locked source, one hipMemcpyAsync, one device
+// buffer the batch's pointers point into.  Until round 5 each was its own copy from pageable memory: every copy is
+// staged by the runtime on the calling thread and completes through the runtime's event thread (~35 us of host CPU
+// each; that thread was 0.75 of the 2.2 CPUs a crawl kept busy, tools/thread_cpu.py).
 struct Reserver {
   afx_plan* plan;
+  Workspace* ws;
   hipStream_t stream;
   hipError_t e = hipSuccess;
   const char* what = "";
+  struct Table { void** dst; size_t off, bytes; };
+  std::vector<Table> tables;
+  std::vector<unsigned char> image;   // the tables back to back, each on a 64-byte boundary
+  // a host-filled table: into the block (the pointer is set by flush)
   template <typename T>
-  bool operator()(Workspace::Buf& buf, T** dst, size_t bytes, const void* upload, const char* name) {
+  bool table(T** dst, const void* src, size_t bytes, const char* name) {
+    what = name;
+    *dst = nullptr;
+    if (!bytes) return true;
+    const size_t off = (image.size() + 63) & ~(size_t)63;
+    image.resize(off + bytes);
+    std::memcpy(image.data() + off, src, bytes);
+    tables.push_back(Table{(void**)dst, off, bytes});
+    return true;
+  }
+  // device memory the kernels fill or read
+  template <typename T>
+  bool operator()(Workspace::Buf& buf, T** dst, size_t bytes, const char* name) {
     what = name;
     if ((e = ws_reserve(plan, buf, bytes)) != hipSuccess) return false;
     *dst = (T*)buf.p;
-    if (upload && bytes) e = hipMemcpyAsync(buf.p, upload, bytes, hipMemcpyHostToDevice, stream);
-    return e == hipSuccess;
+    return true;
+  }
+  // the collected tables: one upload, then the batch's pointers
+  bool flush() {
+    what = "tables";
+    if (tables.empty()) return true;
+    if ((e = ws_reserve(plan, ws->tables, image.size())) != hipSuccess) return false;
+    if ((e = ws_pin_reserve(ws, image.size())) != hipSuccess) return false;
+    std::memcpy(ws->h_pin, image.data(), image.size());
+    if ((e = hipMemcpyAsync(ws->tables.p, ws->h_pin, image.size(), hipMemcpyHostToDevice, stream)) != hipSuccess) return false;
+    for (const Table& t : tables) *t.dst = (unsigned char*)ws->tables.p + t.off;
+    return true;
   }
 };
 
@@ -299,41 +331,41 @@ int reserve_frame_buffers(Planner& p, Reserver& r) {
   const int64_t frames = p.frames;
   auto failed = [&]() { return hip_fail(r.e, r.what); };
   if (b->n_chunks > 0) {
-    if (!r(w.chunks, &b->d_chunks, b->h_chunks.size() * sizeof(Chunk), b->h_chunks.data(), "chunks")) return failed();
+    if (!r.table(&b->d_chunks, b->h_chunks.data(), b->h_chunks.size() * sizeof(Chunk), "chunks")) return failed();
     if (!w.queues.attached()) {
       // zeroed once: every launch advances its counter by its number of items (afx_host.h: QueueBook)
       unsigned* d = nullptr;
-      if (!r(w.queue, &d, kQueueSlots * sizeof(unsigned), nullptr, "queue")) return failed();
+      if (!r(w.queue, &d, kQueueSlots * sizeof(unsigned), "queue")) return failed();
       if ((r.e = hipMemsetAsync(d, 0, kQueueSlots * sizeof(unsigned), b->stream)) != hipSuccess) return failed();
       w.queues.attach(d);
     }
     if (b->halfwave && p.fmask != 1u)   // statistics class: raw sums per frame for its closed-form kernel
-      if (!r(w.stat_tmp, &b->d_stat_tmp, (size_t)frames * frames32_stat_tmp_doubles() * sizeof(double), nullptr, "stat_tmp")) return failed();
+      if (!r(w.stat_tmp, &b->d_stat_tmp, (size_t)frames * frames32_stat_tmp_doubles() * sizeof(double), "stat_tmp")) return failed();
     if (p.mask & kTimeBits)
-      if (!r(w.rem, &b->d_rem, b->h_remaining.size() * sizeof(ChunkRemaining), b->h_remaining.data(), "remaining")) return failed();
+      if (!r.table(&b->d_rem, b->h_remaining.data(), b->h_remaining.size() * sizeof(ChunkRemaining), "remaining")) return failed();
     if (p.mask & kWhitenBits) {
       cut_whitening_chunks(p);
-      if (!r(w.wchunks, &b->d_wchunks, b->h_wchunks.size() * sizeof(Chunk), b->h_wchunks.data(), "whitening chunks")) return failed();
-      if (!r(w.cfirst, &b->d_chunk_first, b->h_chunk_first.size() * sizeof(int32_t), b->h_chunk_first.data(), "chunk_first")) return failed();
+      if (!r.table(&b->d_wchunks, b->h_wchunks.data(), b->h_wchunks.size() * sizeof(Chunk), "whitening chunks")) return failed();
+      if (!r.table(&b->d_chunk_first, b->h_chunk_first.data(), b->h_chunk_first.size() * sizeof(int32_t), "chunk_first")) return failed();
       if ((p.mask & AFX_D_SPECTRAL_COMPLEXITY) && b->need_follow)
-        if (!r(w.follower, &b->d_follower, (size_t)b->n_wchunks * kHalf * sizeof(double), nullptr, "follower")) return failed();
+        if (!r(w.follower, &b->d_follower, (size_t)b->n_wchunks * kHalf * sizeof(double), "follower")) return failed();
     }
   }
   if (n_bufs > 0 && (p.mask & AFX_D_EFFECTIVE_LENGTH)) {
     std::vector<BufSpan>& spans = b->h_spans;
     spans.resize((size_t)n_bufs);
     for (int i = 0; i < n_bufs; ++i) spans[(size_t)i] = BufSpan{b->arena_off[i], b->used[i], p.scale_of(i)};
-    if (!r(w.spans, &b->d_spans, spans.size() * sizeof(BufSpan), spans.data(), "spans")) return failed();
-    if (!r(w.efflen, &b->d_efflen, (size_t)n_bufs * 6 * sizeof(int32_t), nullptr, "efflen")) return failed();
+    if (!r.table(&b->d_spans, spans.data(), spans.size() * sizeof(BufSpan), "spans")) return failed();
+    if (!r(w.efflen, &b->d_efflen, (size_t)n_bufs * 6 * sizeof(int32_t), "efflen")) return failed();
   }
   if (frames > 0 && b->lay.stride > 0)
-    if (!r(w.rec, &b->d_rec, (size_t)frames * b->lay.stride * sizeof(double), nullptr, "rec")) return failed();
+    if (!r(w.rec, &b->d_rec, (size_t)frames * b->lay.stride * sizeof(double), "rec")) return failed();
   if (frames > 0 && b->mag_wanted)   // (+ 1 row: the half-wave full class sends the stores of frames past a chunk's end there)
-    if (!r(w.mag, &b->d_mag, (size_t)(frames + 1) * kHalf * sizeof(double), nullptr, "mag")) return failed();
+    if (!r(w.mag, &b->d_mag, (size_t)(frames + 1) * kHalf * sizeof(double), "mag")) return failed();
   if ((p.want_stats || (p.mask & kWhitenBits)) && n_bufs > 0 && b->lay.stride > 0)
-    if (!r(w.foff, &b->d_frame_offset, b->frame_offset.size() * sizeof(int64_t), b->frame_offset.data(), "frame_offset")) return failed();
+    if (!r.table(&b->d_frame_offset, b->frame_offset.data(), b->frame_offset.size() * sizeof(int64_t), "frame_offset")) return failed();
   if (p.want_stats && n_bufs > 0 && b->lay.stride > 0)
-    if (!r(w.stats, &b->d_stats, (size_t)n_bufs * b->lay.stride * 13 * sizeof(double), nullptr, "stats")) return failed();
+    if (!r(w.stats, &b->d_stats, (size_t)n_bufs * b->lay.stride * 13 * sizeof(double), "stats")) return failed();
   return AFX_OK;
 }
 
@@ -404,27 +436,24 @@ int reserve_rhythm_buffers(Planner& p, Reserver& r) {
   int64_t lrows = 0;
   const std::vector<unsigned char> blob = plan_rhythm_files(p, &lrows);
   if (!blob.empty()) {
-    if (!r(w.rt_long, &b->d_rt_long, blob.size(), blob.data(), "rhythm long files")) return failed();
+    if (!r.table(&b->d_rt_long, blob.data(), blob.size(), "rhythm long files")) return failed();
     // (magnitude, phase) pairs, then the follower's float per bin: 12 bytes per bin and frame
-    if (!r(w.rt_polar, &b->d_rt_polar, (size_t)lrows * 256 * (sizeof(float2) + sizeof(float)), nullptr, "rhythm polar")) return failed();
+    if (!r(w.rt_polar, &b->d_rt_polar, (size_t)lrows * 256 * (sizeof(float2) + sizeof(float)), "rhythm polar")) return failed();
     b->rt_long_rows = lrows;
-    // (the blob is a local: its copy must have left before it goes)
-    if ((r.e = hipStreamSynchronize(b->stream)) != hipSuccess) { r.what = "hipStreamSynchronize"; return failed(); }
   }
   set_rhythm_context(b, nullptr);
-  // (the stream is synchronised by build_batch's caller-visible wait or, for LoadSample batches, before the pageable source can change)
-  if (!r(w.rt_files, &b->d_rt_files, b->rt_files.size() * sizeof(RhythmFile), b->rt_files.data(), "rhythm files")) return failed();
+  if (!r.table(&b->d_rt_files, b->rt_files.data(), b->rt_files.size() * sizeof(RhythmFile), "rhythm files")) return failed();
   b->rt_files_dirty = false;
-  if (!r(w.rt_scalars, &b->d_rt_scalars, (size_t)n_bufs * AFX_NUM_RHYTHM_SCALARS * sizeof(double), nullptr, "rhythm scalars")) return failed();
+  if (!r(w.rt_scalars, &b->d_rt_scalars, (size_t)n_bufs * AFX_NUM_RHYTHM_SCALARS * sizeof(double), "rhythm scalars")) return failed();
   const int64_t rows = b->rt_offset.back();
   if (rows > 0) {
-    if (!r(w.rt_odf, &b->d_rt_odf, (size_t)rows * 2 * sizeof(float), nullptr, "onset functions")) return failed();
-    if (!r(w.rt_onsets, &b->d_rt_onsets, (size_t)rows * 2 * sizeof(double), nullptr, "onsets")) return failed();
-    if (!r(w.rt_scratch, &b->d_rt_scratch, (size_t)rows * 8 * sizeof(double), nullptr, "rhythm scratch")) return failed();
+    if (!r(w.rt_odf, &b->d_rt_odf, (size_t)rows * 2 * sizeof(float), "onset functions")) return failed();
+    if (!r(w.rt_onsets, &b->d_rt_onsets, (size_t)rows * 2 * sizeof(double), "onsets")) return failed();
+    if (!r(w.rt_scratch, &b->d_rt_scratch, (size_t)rows * 8 * sizeof(double), "rhythm scratch")) return failed();
   }
   if (p.want_stats) {
-    if (!r(w.rt_foff, &b->d_rt_foff, b->rt_offset.size() * sizeof(int64_t), b->rt_offset.data(), "rhythm offsets")) return failed();
-    if (!r(w.rt_stats, &b->d_rt_stats, (size_t)n_bufs * 2 * 13 * sizeof(double), nullptr, "rhythm stats")) return failed();
+    if (!r.table(&b->d_rt_foff, b->rt_offset.data(), b->rt_offset.size() * sizeof(int64_t), "rhythm offsets")) return failed();
+    if (!r(w.rt_stats, &b->d_rt_stats, (size_t)n_bufs * 2 * 13 * sizeof(double), "rhythm stats")) return failed();
   }
   return AFX_OK;
 }
@@ -471,14 +500,15 @@ int build_batch(afx_plan* plan, const BatchSource& src, afx_batch** out_batch) {
   if (!b->ws) return cleanup(hip_fail(e, "workspace"));
   Workspace& w = *b->ws;
   b->stream = w.stream; b->ev0 = w.ev0; b->ev1 = w.ev1;
-  Reserver reserve{plan, b->stream};
+  Reserver reserve{plan, b->ws, b->stream};
   if (p.arena > 0) {
-    if (!reserve(w.pcm, &b->d_pcm, (size_t)p.arena * p.esz + 64, nullptr, "pcm")) return cleanup(hip_fail(reserve.e, reserve.what));
+    if (!reserve(w.pcm, &b->d_pcm, (size_t)p.arena * p.esz + 64, "pcm")) return cleanup(hip_fail(reserve.e, reserve.what));
     const int st = src.fill(b, src.fill_ctx);
     if (st != AFX_OK) return cleanup(st);
   }
   int st = reserve_frame_buffers(p, reserve);
   if (st == AFX_OK && (p.mask & AFX_D_RHYTHM) && src.n_bufs > 0) st = reserve_rhythm_buffers(p, reserve);
+  if (st == AFX_OK && !reserve.flush()) st = hip_fail(reserve.e, reserve.what);
   if (st != AFX_OK) return cleanup(st);
   // the caller's PCM buffers (afx_batch_create) may go away when this returns; the tables uploaded above are the batch's own
   if (src.wait_for_uploads && (e = hipStreamSynchronize(b->stream)) != hipSuccess) return cleanup(hip_fail(e, "hipStreamSynchronize"));

@@ -127,7 +127,10 @@ struct Workspace {
   hipEvent_t ev_copy = nullptr;   // the host's waits for the plan's upload / download streams (and, when blocking, for this batch's stream)
   bool blocking = false;          // the host's waits of this workspace's batches sleep (afx_plan_set_blocking_wait)
   QueueBook queues;               // the kernels' work-queue counters (their memory is `queue` below)
-  Buf pcm, chunks, wchunks, rem, rec, mag, foff, stats, cfirst, follower, spans, efflen, raw, files, scan, partial, place, queue;
+  Buf tables;                     // the host-filled tables of a batch, one block (afx_batch_plan.cpp: Reserver)
+  void* h_pin = nullptr;          // page-locked host block the tables are uploaded from (and the scan results land in)
+  size_t h_pin_cap = 0;
+  Buf pcm, rec, mag, stats, follower, efflen, raw, files, scan, partial, place, queue;
   Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff, rt_long, rt_polar;   // rhythm tracker
   Buf stat_tmp;                                                                 // half-wave statistics class
   Buf rs_files, rs_groups, rs_ngroups;                                          // sample-rate conversion (afx_resample.hip)
@@ -246,6 +249,7 @@ void ws_free(Workspace* w);
 // at least `bytes` in b.  When the device is out of memory the plan's idle pooled workspaces are freed and the
 // allocation is tried once more (they hold their capacity: a batch that failed for memory would otherwise fail again)
 hipError_t ws_reserve(afx_plan* plan, Workspace::Buf& b, size_t bytes);
+hipError_t ws_pin_reserve(Workspace* w, size_t bytes);   // at least `bytes` of page-locked host memory in w->h_pin
 size_t pool_trim(afx_plan* plan);   // frees every idle pooled workspace of the plan; returns the bytes given back
 hipError_t wait_for_event(Workspace* ws, hipEvent_t ev);
 hipError_t wait_for_stream(Workspace* ws, hipStream_t stream);

@@ -15,9 +15,8 @@ namespace afx {
 namespace host {
 
 std::vector<Workspace::Buf*> Workspace::all_bufs() {
-  return {&pcm, &chunks, &wchunks, &rem, &rec, &mag, &foff, &stats, &cfirst, &follower, &spans, &efflen, &raw, &files, &scan, &partial,
-          &place, &queue, &rt_files, &rt_long, &rt_polar, &rt_odf, &rt_onsets, &rt_scratch, &rt_scalars, &rt_stats, &rt_foff, &stat_tmp,
-          &rs_files, &rs_groups, &rs_ngroups};
+  return {&tables, &pcm, &rec, &mag, &stats, &follower, &efflen, &raw, &files, &scan, &partial, &place, &queue, &rt_polar, &rt_odf,
+          &rt_onsets, &rt_scratch, &rt_scalars, &rt_stats, &stat_tmp, &rs_files, &rs_groups, &rs_ngroups};
 }
 size_t Workspace::bytes() {
   size_t n = 0;
@@ -28,6 +27,7 @@ size_t Workspace::bytes() {
 void ws_free(Workspace* w) {
   if (!w) return;
   for (Workspace::Buf* b : w->all_bufs()) hipFree(b->p);
+  if (w->h_pin) hipHostFree(w->h_pin);
   if (w->ev0) hipEventDestroy(w->ev0);
   if (w->ev1) hipEventDestroy(w->ev1);
   if (w->ev_fork) hipEventDestroy(w->ev_fork);
@@ -81,6 +81,18 @@ void ws_release(afx_plan* plan, Workspace* w) {
   ws_free(w);
 }
 
+hipError_t ws_pin_reserve(Workspace* w, size_t bytes) {
+  if (bytes <= w->h_pin_cap) return hipSuccess;
+  if (w->h_pin) hipHostFree(w->h_pin);
+  w->h_pin = nullptr;
+  w->h_pin_cap = 0;
+  const size_t want = bytes + bytes / 2 + 4096;
+  const hipError_t e = hipHostMalloc(&w->h_pin, want, hipHostMallocDefault);
+  if (e != hipSuccess) { w->h_pin = nullptr; return e; }
+  w->h_pin_cap = want;
+  return hipSuccess;
+}
+
 size_t pool_trim(afx_plan* plan) {
   std::vector<Workspace*> idle;
   {
@@ -122,7 +134,12 @@ hipError_t ws_reserve(afx_plan* plan, Workspace::Buf& b, size_t bytes) {
 // alternatives did not serve: hipEventBlockingSync alone changes nothing here (the eight workers of a crawl still keep
 // 6.6 CPUs busy), and hipDeviceScheduleBlockingSync, set on a device that is already active, left a later
 // hipStreamSynchronize hanging.
-constexpr int kNapCeilingUs = 300;
+// (600: round 5, tools/thread_cpu.py on the C4 share -- 5 workers 1.84 -> 1.78 busy CPUs at 284 -> 287 k files/s, 8 workers
+// 1.99 -> 1.90; 1 000 us starts to cost throughput with few workers)
+#ifndef AFX_X_NAP_CEILING
+#define AFX_X_NAP_CEILING 600
+#endif
+constexpr int kNapCeilingUs = AFX_X_NAP_CEILING;
 hipError_t wait_for_event(Workspace* ws, hipEvent_t ev) {
   if (!ws->blocking) return hipEventSynchronize(ev);
   // naps grow from 20 us to kNapCeilingUs: what a crawl waits for takes milliseconds (an upload 1.6 ms, a batch's

@@ -33,7 +33,11 @@ struct TCrawlFile {
 
 struct TCrawlOptions {
   std::vector<int> mDevices = {0};  // HIP device ordinals
-  int mWorkersPerDevice = 8;        // host threads (= batches in flight) per device
+  // host threads (= batches in flight) per device.  5: the host link is full from 5 on (284 k one-second files/s; 8: 281 k)
+  // and every worker costs host CPU -- 1.78 busy CPUs per GPU with 5, 1.90-2.2 with 8 (round 5, tools/thread_cpu.py): a
+  // node with 8 GPUs and a 16-CPU quota has 2 per GPU.  Crawls that read the files themselves (pread out of the page
+  // cache is the cost there) gain from more.
+  int mWorkersPerDevice = 5;
   int mFilesPerBatch = 512;         // measured best on one MI355X for 1 s stereo files (profiles/r02/README.md)
   int64_t mBytesPerBatch = 128 << 20;  // a batch also ends before the file that takes it over this many file bytes (a
                                     // 16-bit mono file needs ~10 x its size in device memory: PCM as doubles, spectra)

@@ -62,7 +62,7 @@ def parse_args():
                     help="with --workload c3|c4: time the streaming host driver instead (WAV images in host memory -> RIFF "
                          "parse -> page-locked staging -> upload -> LoadSample + every descriptor + statistics -> results "
                          "back in host memory); value = frames/s including every transfer")
-    ap.add_argument("--workers", type=int, default=8, help="host threads (batches in flight) per GPU of --end-to-end")
+    ap.add_argument("--workers", type=int, default=5, help="host threads (batches in flight) per GPU of --end-to-end")
     ap.add_argument("--files-per-batch", type=int, default=512, help="files per GPU batch of --end-to-end")
     ap.add_argument("--cpu-frames", type=int, default=30000, help="frames per CPU worker for the baseline")
     ap.add_argument("--frame-kernel", choices=["auto", "wave64", "halfwave"], default="auto",
@@ -189,6 +189,11 @@ def wav_image(pcm_i16, channels, rate=44100):
     fmt = struct.pack("<HHIIHH", 1, channels, rate, channels * rate * 2, channels * 2, 16)
     body = b"WAVE" + b"fmt " + struct.pack("<I", len(fmt)) + fmt + b"data" + struct.pack("<I", len(payload)) + payload
     return b"RIFF" + struct.pack("<I", len(body)) + body
+
+
+def _c4_images(n_files, seed):
+    pool = [wav_image(f, 2) for f in make_c4_files(64, seed)]
+    return [pool[i % len(pool)] for i in range(n_files)]
 
 
 def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=3, files_per_batch=512, files_dir=None, rate=44100):
@@ -622,7 +627,7 @@ def main():
     e2e = None
     if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
         try:
-            st = end_to_end("c4", 12500, device, 8, 99, repeats=3, files_per_batch=512)
+            st = end_to_end("c4", 12500, device, 5, 99, repeats=5, files_per_batch=512)
             e2e = {"workload": "C4 share: 12 500 stereo 1.0 s 16-bit WAV images in host memory -> RIFF parse -> page-locked staging -> "
                                "upload -> LoadSample + every low-level descriptor (per-frame set and rhythm tracker) + statistics -> records back in host memory",
                    "files_per_s": st["files"] / st["seconds"], "frames_per_s": st["frames"] / st["seconds"],
@@ -631,7 +636,19 @@ def main():
                    # 55 GB/s: one page-locked upload stream on this host link (tools/link_rate.py, profiles/r02/README.md)
                    "upload_frac_of_host_link": st["pcm_bytes"] / st["seconds"] / 55e9,
                    "busy_host_cpus": st["cpu_seconds"] / st["seconds"],
-                   "workers": 8, "files_per_batch": 512}
+                   "workers": 5, "files_per_batch": 512}
+            # the same share as eight shards with one worker each on this one device: what one process driving the 8 GPUs
+            # of a node with a worker per GPU costs the host (Crawler.cpp:706-728; the shards share the device here)
+            try:
+                from afec_amd import hostlib
+                s8 = None
+                for _ in range(3):
+                    t8 = hostlib.crawl(_c4_images(12500, 99), devices=(device,) * 8, workers=1, files_per_batch=512)
+                    if s8 is None or t8["seconds"] < s8["seconds"]:
+                        s8 = t8
+                e2e["eight_shards_one_worker"] = {"files_per_s": s8["files"] / s8["seconds"], "busy_host_cpus": s8["cpu_seconds"] / s8["seconds"]}
+            except Exception as e8:  # noqa: BLE001
+                e2e["eight_shards_one_worker"] = {"error": str(e8)}
             # the same crawl with the single writer inserting every file into the reference's sqlite `assets` table
             # (461 columns, ~68 KB of msgpack per one-second file; one transaction per batch of 512 files), database on
             # tmpfs: the writer, not the GPU, bounds it

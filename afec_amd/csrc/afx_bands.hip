@@ -656,10 +656,42 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     }
     __builtin_amdgcn_sched_barrier(0);
 #endif
-    double lg[kRows];
+    // Eight logarithms per lane, not twelve: rows 5, 6 lie wholly inside band 12 and rows 8, 9, 10 (and 48 lanes of row 11)
+    // inside band 13, so a lane's factors of those rows belong to one band and are multiplied first -- what the reference
+    // does anyway (a running product, logarithms only when it leaves [1e-64, 1e64]).  Factors are >= 1e-20: a product of
+    // four stays above 1e-80.
+    double lg[8];
+    {
+      double fct[kRows];
 #pragma unroll
-    for (int r = 0; r < kRows; ++r) lg[r] = band_log(fabs(x[r]) + 1e-20, logt);
-    const double slog = band_sum([&](int r) { return lg[r]; }, lane_v);
+      for (int r = 0; r < kRows; ++r) fct[r] = fabs(x[r]) + 1e-20;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) lg[r] = band_log(fct[r], logt);                       // rows 0..4: several bands per row
+      lg[5] = band_log(fct[5] * fct[6], logt);                                           // band 12
+      lg[6] = band_log(fct[7], logt);                                                    // row 7: bands 12 | 13
+      lg[7] = band_log((fct[8] * fct[9]) * (fct[10] * keep_or_one(fct[11], sub_mask(13, 11))), logt);   // band 13
+    }
+    double slog;
+    {
+      // slot -> (band, row) pairs as in band_sum; the merged slots are whole-band values
+      double acc[16];
+#pragma unroll
+      for (int b = 0; b < 16; ++b) acc[b] = 0.0;
+#pragma unroll
+      for (int b = 0; b < 6; ++b) acc[b] = keep_where(lg[0], sub_mask(b, 0));
+      acc[6] = keep_where(lg[0], sub_mask(6, 0)) + keep_where(lg[1], sub_mask(6, 1));
+      acc[7] = keep_where(lg[1], sub_mask(7, 1));
+      acc[8] = keep_where(lg[1], sub_mask(8, 1));
+      acc[9] = keep_where(lg[1], sub_mask(9, 1)) + keep_where(lg[2], sub_mask(9, 2));
+      acc[10] = keep_where(lg[2], sub_mask(10, 2)) + keep_where(lg[3], sub_mask(10, 3));
+      acc[11] = keep_where(lg[3], sub_mask(11, 3)) + keep_where(lg[4], sub_mask(11, 4));
+      acc[12] = (keep_where(lg[4], sub_mask(12, 4)) + lg[5]) + keep_where(lg[6], sub_mask(12, 7));
+      acc[13] = keep_where(lg[6], sub_mask(13, 7)) + lg[7];
+      static_assert(kSubStart[12] <= 320 && kSubStart[13] >= 448 && kSubStart[13] <= 512 && kSubStart[14] >= 704 && kSubStart[14] <= 768 &&
+                    kSubStart[6] <= 63 && kSubStart[7] > 64 && kSubStart[9] <= 127 && kSubStart[10] > 128 && kSubStart[10] <= 191 &&
+                    kSubStart[11] > 192 && kSubStart[11] <= 255 && kSubStart[12] > 256, "the log slots follow the band layout");
+      slog = wave_sum16(acc, lane_v);
+    }
     const double bmax = band_max([&](int r) { return x[r]; }, lane_v);
 
     // ---- complexity: strict local maxima above 0.25 * band maximum (SA:2170-2197); counted on the scalar

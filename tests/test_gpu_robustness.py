@@ -308,3 +308,50 @@ def test_side_stream_and_queue_order_do_not_change_a_result():
         assert with_side.keys() == without.keys()
         for k in with_side:
             np.testing.assert_array_equal(with_side[k], without[k], err_msg=k)
+
+
+def test_an_allocation_that_finds_the_device_full_gets_the_idle_pool_back_and_the_probe_says_alive():
+    """Idle pooled workspaces keep their capacity (up to 16 per plan): a batch that failed for memory would fail again,
+    and the device probe -- which used to hipMalloc(256) -- could declare a live device lost.  Three batches leave ~10 GB
+    idle in the pool, a dummy allocation takes all other free device memory, and a batch that needs ~7 GB is created: the
+    first hipMalloc fails, the library gives the idle workspaces back (afx_workspace.cpp: ws_reserve -> pool_trim) and the
+    batch comes to be and computes the right thing; afx_plan_probe_device answers AFX_OK with the device that full.
+    (Workspaces above 4 GiB are not pooled: the three held here are 3.1 GB each.)"""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    plan = afx.Plan(max_analysis_ms=0)
+    L = plan.L
+    rng = np.random.default_rng(17)
+    frames = 200_000
+    x = rng.uniform(-1, 1, (frames - 1) * 1024 + 2048).astype(np.float32)      # 0.8 GB of PCM, 1.6 GB of magnitudes
+    mask = afx.D_MFCC | afx.D_SPECTRAL_FLUX        # flux is taken from stored magnitudes: 8 KiB per frame in the workspace
+    held = [plan.batch([x], mask) for _ in range(3)]                            # three workspaces at once ...
+    want = None
+    for b in held:
+        b.run()
+    want = held[0].fetch()["mfcc"][:64].copy()
+    for b in held:
+        b.close()                                                               # ... idle in the plan's pool now
+    assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+    idle_free = free.value
+    dummy = ctypes.c_void_p()
+    leave = 5 << 29                                                             # 2.5 GB: less than the ~5 GB the next batch needs
+    assert hip.hipMalloc(ctypes.byref(dummy), ctypes.c_size_t(idle_free - leave)) == 0
+    try:
+        assert L.afx_plan_probe_device(plan.h) == 0                            # no allocation in the probe
+        hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+        before = free.value
+        assert before < (3 << 30)
+        big = plan.batch([x, x], mask)                                          # 2 x: does not fit what is free, fits after the trim
+        hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total))
+        assert free.value > before + (1 << 30)                                  # more is free with the batch alive than before it: the idle pool went back
+        big.run()
+        got = big.fetch()["mfcc"]
+        np.testing.assert_array_equal(got[:64], want)
+        np.testing.assert_array_equal(got[frames:frames + 64], want)
+        assert L.afx_plan_probe_device(plan.h) == 0
+        big.close()
+    finally:
+        hip.hipFree(dummy)
+    plan.close()

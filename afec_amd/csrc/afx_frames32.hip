@@ -36,7 +36,10 @@ using f32x32::cx;
 
 constexpr int kHalfSlots = 1056;                      // 8-byte slots per half: 33 * 31 + 31 + 1, rounded to 32
 constexpr int kPlane32Bytes = 2 * kHalfSlots * 8;     // 16 896 per wave
-constexpr int kWaves32 = 8;
+#ifndef AFX_X_WAVES32
+#define AFX_X_WAVES32 8
+#endif
+constexpr int kWaves32 = AFX_X_WAVES32;
 // raw sums per frame the statistics / full classes leave for stats32_finish_kernel: sum m, m^2, j m, j^2 m, m^3, m^4,
 // sum log(m + 1e-20), rolloff count, sum x^2 of the hop, max |x| of the hop
 

@@ -76,13 +76,18 @@ NEIGH_TOL = {
 # (profiles/r04/parity_report.md, profiles/r05/observed_errors.json: every check_gpu() call of one run of the whole
 # GPU suite, tools/observed_errors.py); discrete descriptors stay exact.  check_gpu() asserts the bar AND the ceiling.
 OBSERVED_CEILING = {
-    "mfcc": 2.5e-6,                 # 2.3e-7 observed: logs of mel sums over leakage-floor bins (xtract_mfcc, vector.c:350-391)
-    "sub_flatness": 3.5e-7,         # 3.3e-8: geometric means of sub-bands of 2..6 bins (Statistics.cpp:417-455)
+    # 10 x the worst error seen over one run of the whole GPU suite (profiles/r05/observed_errors.json) AND three fuzz soaks
+    # of random material, masks and batch shapes (profiles/r05/observed_errors_fuzz.json + the soak of seed 51, which set
+    # the sub-band and f0 entries): ragged random material reaches further than the suite's signals.
+    "mfcc": 1e-5,                   # 9.8e-7 observed (fuzz; 2.6e-7 in the suite): logs of mel sums over leakage-floor bins (vector.c:350-391)
+    "sub_flatness": 2e-5,           # 1.75e-6 (fuzz; 3.6e-8 in the suite): geometric means of sub-bands of 2..6 bins (Statistics.cpp:417-455)
+    "sub_contrast": 5e-7,           # 4.9e-8 (fuzz; 1.6e-9 in the suite)
+    "f0": 5e-7, "failsafe_f0": 5e-7,   # 1.25e-7 (fuzz: a parabolic interpolation over a nearly flat minimum; 2.6e-14 in the suite); the bar is 1e-6
     "spectral_rms": 2e-8, "spectral_centroid": 2e-8, "spectral_spread": 2e-8, "spectral_skewness": 2e-8,
     "spectral_kurtosis": 2e-8, "spectral_flatness": 2e-8, "spectral_flux": 2e-8, "spectrum_bands": 2e-8,
-    "sub_rms": 2e-8, "sub_flux": 2e-8, "sub_contrast": 2e-8, "spectral_contrast": 2e-8,
-    "amplitude_rms": 1e-12, "amplitude_envelope": 2e-12,        # time-domain sums of 1 024 samples: 3e-15 / 2e-15 observed
-    "auto_correlation": 2e-8, "f0": 2e-8, "f0_confidence": 2e-8, "failsafe_f0": 2e-8,
+    "sub_rms": 2e-8, "sub_flux": 2e-8, "spectral_contrast": 2e-8,          # all <= 1.6e-9 observed
+    "amplitude_rms": 1e-12, "amplitude_envelope": 2e-12,        # time-domain sums of 1 024 samples: 1.4e-14 / 5e-15 observed
+    "auto_correlation": 2e-8, "f0_confidence": 2e-8,           # 7.8e-11 / 8.7e-14 observed
 }
 _EXACT = {"spectral_rolloff", "sub_complexity", "amplitude_peak", "amplitude_silence", "spectral_complexity",
           "spectral_inharmonicity", "tristimulus1", "tristimulus2", "tristimulus3"}

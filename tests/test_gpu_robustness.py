@@ -318,9 +318,15 @@ def test_an_allocation_that_finds_the_device_full_gets_the_idle_pool_back_and_th
     batch comes to be and computes the right thing; afx_plan_probe_device answers AFX_OK with the device that full.
     (Workspaces above 4 GiB are not pooled: the three held here are 3.1 GB each.)"""
     import ctypes
-    hip = ctypes.CDLL("libamdhip64.so")
-    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    import os
     plan = afx.Plan(max_analysis_ms=0)
+    # the HIP runtime libafx_hip.so itself runs on (a process that imported torch has torch's own copy loaded as well, and
+    # that one has no device): the one of the image's ROCm, by path
+    rocm = "/opt/rocm/lib/libamdhip64.so"
+    hip = ctypes.CDLL(rocm if os.path.exists(rocm) else "libamdhip64.so")
+    free, total = ctypes.c_size_t(0), ctypes.c_size_t(0)
+    if hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) != 0:
+        pytest.skip("no handle on the HIP runtime the library uses")
     L = plan.L
     rng = np.random.default_rng(17)
     frames = 200_000

@@ -1,3 +1,10 @@
+#!/usr/bin/env python3
+"""Per-section instruction budget of bands_kernel<15>: a copy of afec_amd/csrc/afx_bands.hip gets a scheduling barrier and
+an assembly comment at every section boundary of the frame loop, is compiled to ISA (hipcc -S --cuda-device-only), and the
+instructions between the markers are counted by kind.  (The scheduler still moves some work across the markers; the 'park'
+section holds the closed forms that run once per four frames.)   usage: tools/bands_budget.py"""
+import os
+os.chdir(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "afec_amd", "csrc"))
 import re,subprocess,sys
 src=sys.argv[1] if len(sys.argv)>1 else 'afx_bands.hip'
 s=open(src).read()

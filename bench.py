@@ -75,6 +75,7 @@ def parse_args():
                     help="skip the C3 / C4-share chain rates (BASELINE configs[2] / [3]) of the default line")
     # test hook of the launcher (tests/test_bench_dist_cpu.py): this rank exits with status 7 before it joins the others
     ap.add_argument("--fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    ap.add_argument("--stall-seconds", type=float, default=0.0, help=argparse.SUPPRESS)   # test hook: every rank sleeps first
     return ap.parse_args()
 
 
@@ -102,28 +103,39 @@ def launch_ranks(n_gpus, argv, poll_s=0.05):
                    MASTER_PORT=str(port), AFX_BENCH_LAUNCHED_BY=str(os.getpid()))
         out = tempfile.TemporaryFile()
         children.append((subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, stdout=out), out))
+    # a launcher that is told to stop (the driver's timeout: SIGTERM) must not leave its ranks behind on the GPUs
+    import signal
+
+    def stop(signum, _frame):
+        raise SystemExit(128 + signum)
+    previous = {sig: signal.signal(sig, stop) for sig in (signal.SIGTERM, signal.SIGINT)}
     status = 0
     pending = set(range(n_gpus))
-    while pending and status == 0:
-        for r in sorted(pending):
-            rc = children[r][0].poll()
-            if rc is None:
-                continue
-            pending.discard(r)
-            if rc != 0:
-                print(f"bench.py: rank {r} of {n_gpus} exited with status {rc}; ending the other ranks", file=sys.stderr)
-                status = rc if rc > 0 else 1
-                break
-        if pending and status == 0:
-            time.sleep(poll_s)
-    for r in pending:                      # only after a failure: the ranks that are still running
-        children[r][0].terminate()
-    for r in pending:
-        try:
-            children[r][0].wait(10)
-        except subprocess.TimeoutExpired:
-            children[r][0].kill()
-            children[r][0].wait()
+    try:
+        while pending and status == 0:
+            for r in sorted(pending):
+                rc = children[r][0].poll()
+                if rc is None:
+                    continue
+                pending.discard(r)
+                if rc != 0:
+                    print(f"bench.py: rank {r} of {n_gpus} exited with status {rc}; ending the other ranks", file=sys.stderr)
+                    status = rc if rc > 0 else 1
+                    break
+            if pending and status == 0:
+                time.sleep(poll_s)
+    finally:
+        for r in pending:                  # after a failure or a signal: the ranks that are still running (by their PIDs)
+            if children[r][0].poll() is None:
+                children[r][0].terminate()
+        for r in pending:
+            try:
+                children[r][0].wait(10)
+            except subprocess.TimeoutExpired:
+                children[r][0].kill()
+                children[r][0].wait()
+        for sig, handler in previous.items():
+            signal.signal(sig, handler)
     for r, (_, out) in enumerate(children):
         out.seek(0)
         text = out.read().decode(errors="replace")
@@ -497,6 +509,8 @@ def main():
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     if args.fail_rank >= 0 and int(os.environ.get("RANK", "0")) == args.fail_rank:
         sys.exit(7)
+    if args.stall_seconds > 0 and "AFX_BENCH_LAUNCHED_BY" in os.environ:
+        time.sleep(args.stall_seconds)
     rank, world, local, dist = dist_setup(args.gpus)
     if world != max(1, args.gpus):
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the line would report another job than the one asked for")

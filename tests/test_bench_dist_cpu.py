@@ -96,3 +96,31 @@ def test_a_world_size_that_contradicts_gpus_is_an_error():
                    env={"WORLD_SIZE": "1", "RANK": "0", "LOCAL_RANK": "0"})
     assert r.returncode != 0 and b"--gpus 2 but WORLD_SIZE=1" in r.stderr
     assert not any(line.startswith(b"{") for line in r.stdout.splitlines())
+
+
+def test_a_launcher_that_is_told_to_stop_takes_its_ranks_with_it():
+    """SIGTERM to `bench.py --gpus 2` (a driver's timeout) while its ranks are running: the launcher ends them (their PIDs
+    are gone afterwards) and leaves with 128 + SIGTERM -- nothing stays behind on the GPUs."""
+    import signal
+    import subprocess
+    import time
+    e = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stall-seconds", "120", "--steps", "1",
+                          "--buffers", "1", "--no-cpu-baseline", "--no-single"], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    kids = []
+    for _ in range(100):                       # the launcher imports numpy first: wait for its two ranks
+        kids = [int(k) for k in subprocess.run(["ps", "-o", "pid=", "--ppid", str(p.pid)], stdout=subprocess.PIPE).stdout.split()]
+        if len(kids) == 2:
+            break
+        time.sleep(0.1)
+    assert len(kids) == 2, kids
+    p.send_signal(signal.SIGTERM)
+    assert p.wait(30) == 128 + signal.SIGTERM
+    time.sleep(0.5)
+
+    def running(pid):
+        try:
+            return open(f"/proc/{pid}/stat").read().rsplit(")", 1)[1].split()[0] != "Z"
+        except OSError:
+            return False
+    assert [k for k in kids if running(k)] == []

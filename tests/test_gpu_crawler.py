@@ -391,6 +391,27 @@ def test_a_lost_device_ends_the_crawl():
     assert again["files"] == len(images) and again["failed"] == 1
 
 
+def test_a_crawl_that_is_ending_commits_whole_batches_only(tmp_path):
+    """A worker that loses its device sets the crawl's abort flag while the writer may be in the middle of another batch:
+    until round 5 the writer's loop then left early and the commit behind it committed the partial batch.  With batches of
+    8 files in file order (one worker): whatever reached the database before the crawl ended is whole batches -- every
+    group of 8 consecutive files is either complete or absent."""
+    from afec_amd import hostlib
+    images, names, _ = make_crawl(120)
+    db = str(tmp_path / "ending.db")
+    try:
+        hostlib.set_test_fault(batch=9, attempts=1, device_lost=True)
+        with pytest.raises(RuntimeError, match="injected fault"):
+            _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=8, database=db)
+    finally:
+        hostlib.set_test_fault()
+    have = set(statuses(db))
+    groups = [names[i:i + 8] for i in range(0, len(names), 8)]
+    counts = [sum(n in have for n in g) for g in groups]
+    assert all(c in (0, len(g)) for c, g in zip(counts, groups)), counts
+    assert 0 < sum(counts) < len(names)                     # some batches made it, the crawl did end early
+
+
 def test_a_file_whose_header_would_blow_it_up_fails_alone(tmp_path):
     """A small file whose header claims 1 Hz would be 2^31 samples once converted to 44.1 kHz: it is refused by itself
     (AFX_ERR_UNSUPPORTED -> a failed row), its batch is analysed; files at 1 kHz (x 44.1) and 500 Hz (x 88.2: refused

@@ -228,7 +228,7 @@ def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=
             with open(name, "wb") as f:
                 f.write(image)
         images = None
-    best, cold = None, None
+    best, cold, busy = None, None, []
     for rep in range(repeats):
         # every repeat writes its own database file: a crawl into the file of the one before would time INSERT OR REPLACE
         # of existing rows (delete + insert), not the inserts of a crawl
@@ -236,9 +236,14 @@ def end_to_end(workload, n_files, device, workers, seed, database=None, repeats=
         st = hostlib.crawl(images, names, devices=(device,), workers=workers, files_per_batch=files_per_batch, database=db)
         if cold is None:
             cold = st["seconds"]
+        else:
+            busy.append(st["cpu_seconds"] / st["seconds"])     # warm crawls only: the first one also sets the crawler up
         if best is None or st["seconds"] < best["seconds"]:
             best = st
-    best = dict(best, cold_seconds=cold)
+    # busy host CPUs: the median over the warm crawls (the fastest crawl's own figure is not the typical one: a crawl is
+    # fastest when its threads happened to wait least)
+    best = dict(best, cold_seconds=cold,
+                busy_cpus_median=float(np.median(busy)) if busy else best["cpu_seconds"] / best["seconds"])
     return best
 
 
@@ -641,7 +646,7 @@ def main():
     e2e = None
     if rank == 0 and args.workload == "c2" and args.mask == "c2" and not args.no_single:
         try:
-            st = end_to_end("c4", 12500, device, 5, 99, repeats=5, files_per_batch=512)
+            st = end_to_end("c4", 12500, device, 5, 99, repeats=8, files_per_batch=512)
             e2e = {"workload": "C4 share: 12 500 stereo 1.0 s 16-bit WAV images in host memory -> RIFF parse -> page-locked staging -> "
                                "upload -> LoadSample + every low-level descriptor (per-frame set and rhythm tracker) + statistics -> records back in host memory",
                    "files_per_s": st["files"] / st["seconds"], "frames_per_s": st["frames"] / st["seconds"],
@@ -649,7 +654,8 @@ def main():
                    "upload_GB_per_s": st["pcm_bytes"] / st["seconds"] / 1e9, "download_GB_per_s": st["result_bytes"] / st["seconds"] / 1e9,
                    # 55 GB/s: one page-locked upload stream on this host link (tools/link_rate.py, profiles/r02/README.md)
                    "upload_frac_of_host_link": st["pcm_bytes"] / st["seconds"] / 55e9,
-                   "busy_host_cpus": st["cpu_seconds"] / st["seconds"],
+                   "busy_host_cpus": st["busy_cpus_median"],     # median over the warm crawls of this process
+                   "busy_host_cpus_of_the_fastest_crawl": st["cpu_seconds"] / st["seconds"],
                    "workers": 5, "files_per_batch": 512}
             # the same share as eight shards with one worker each on this one device: what one process driving the 8 GPUs
             # of a node with a worker per GPU costs the host (Crawler.cpp:706-728; the shards share the device here)
@@ -686,7 +692,7 @@ def main():
             with tempfile.TemporaryDirectory(dir=shm) as td:
                 sf = end_to_end("c4", 12500, device, 8, 99, repeats=3, files_per_batch=512, files_dir=td)
                 e2e["files_per_s_from_files_on_tmpfs"] = sf["files"] / sf["seconds"]
-                e2e["busy_host_cpus_from_files_on_tmpfs"] = sf["cpu_seconds"] / sf["seconds"]
+                e2e["busy_host_cpus_from_files_on_tmpfs"] = sf["busy_cpus_median"]
             # the same 12 500 files labelled 48 kHz: every one goes through the sample-rate conversion on the GPU first
             # (libresample's arithmetic, afx_resample.hip), then the same pipeline on 0.92 x the samples
             sr = end_to_end("c4", 12500, device, 8, 99, repeats=3, files_per_batch=512, rate=48000)

@@ -5,7 +5,7 @@ Python here is test/bench plumbing over the C-ABI (ctypes); the product is
 afec_amd/lib/libafx_hip.so and the C++ host layer in afec_amd/host/.
 """
 from .capi import (  # noqa: F401
-    AfxError, Batch, Plan, build_info, build_library, library_path, load_library,
+    AfxError, Batch, Plan, build_info, build_library, device_count, library_path, load_library,
     D_MFCC, D_SPECTRAL_RMS, D_SPECTRAL_CENTROID, D_SPECTRAL_SPREAD, D_SPECTRAL_SKEWNESS,
     D_SPECTRAL_KURTOSIS, D_SPECTRAL_ROLLOFF, D_SPECTRAL_FLATNESS, D_SPECTRAL_FLUX,
     D_SPECTRUM_BANDS, D_BAND_FEATURES, D_AMPLITUDE_PEAK, D_AMPLITUDE_RMS, D_MAGNITUDE, D_STATISTICS, NUM_STATISTICS, STAT_NAMES,

@@ -63,7 +63,7 @@ EXPORTS = [
     "afx_algorithmic_bytes_per_frame", "afx_batch_create_from_raw", "afx_batch_fetch_samples",
     "afx_host_alloc", "afx_host_free", "afx_batch_record_layout", "afx_batch_fetch_records",
     "afx_batch_set_file_info", "afx_batch_rhythm_frames", "afx_batch_fetch_rhythm", "afx_batch_fetch_onset_functions",
-    "afx_plan_set_blocking_wait", "afx_batch_get_info", "afx_plan_probe_device",
+    "afx_plan_set_blocking_wait", "afx_batch_get_info", "afx_plan_probe_device", "afx_device_count",
 ]
 RAW_I16, RAW_I24, RAW_F32, RAW_I32, RAW_F64 = 0, 1, 2, 3, 4
 
@@ -146,6 +146,13 @@ def build_info():
 
 def library_path():
     return _LIB_PATH
+
+
+def device_count():
+    """afx_device_count(): HIP devices this process can use (0 without a GPU)."""
+    L = load_library()
+    L.afx_device_count.restype = ctypes.c_int
+    return int(L.afx_device_count())
 
 
 def build_library(force=False):

@@ -131,10 +131,10 @@ struct Workspace {
   void* h_pin = nullptr;          // page-locked host block the tables are uploaded from (and the scan results land in)
   size_t h_pin_cap = 0;
   Buf pcm, rec, mag, stats, follower, efflen, raw, files, scan, partial, place, queue;
-  Buf rt_files, rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_foff, rt_long, rt_polar;   // rhythm tracker
+  Buf rt_odf, rt_onsets, rt_scratch, rt_scalars, rt_stats, rt_polar;   // rhythm tracker (its host-filled tables lie in `tables`)
   Buf stat_tmp;                                                                 // half-wave statistics class
   Buf rs_files, rs_groups, rs_ngroups;                                          // sample-rate conversion (afx_resample.hip)
-  std::vector<Buf*> all_bufs();
+  std::vector<Buf*> all_bufs();   // every Buf member above, each exactly once: ws_free and bytes() walk this list
   size_t bytes();
 };
 

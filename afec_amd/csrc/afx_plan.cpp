@@ -355,7 +355,7 @@ const char* afx_build_info(void) {
 #ifndef AFX_SRC_HASH
 #define AFX_SRC_HASH "unknown"
 #endif
-  return "afx abi=" "5" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL " src=" AFX_SRC_HASH;
+  return "afx abi=" "6" " arch=gfx950 stamps=" AFX_INFO_STAMPS " ablation=" AFX_INFO_ABL " src=" AFX_SRC_HASH;
 }
 
 int afx_plan_create(const afx_plan_desc* desc, afx_plan** out_plan) {
@@ -465,6 +465,13 @@ int64_t afx_algorithmic_bytes_per_frame(const afx_plan* plan, uint32_t mask, int
   int64_t out = (int64_t)make_layout(mask).stride * 8;
   if (mask & AFX_D_MAGNITUDE) out += (int64_t)afx::kHalf * 8;
   return in + out;
+}
+
+int afx_device_count(void) {
+  int n = 0;
+  const hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
 }
 
 int afx_plan_probe_device(afx_plan* plan) {

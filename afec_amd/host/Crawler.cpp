@@ -14,6 +14,7 @@
 #include <thread>
 #include <time.h>
 
+#include <sched.h>
 #include <sys/stat.h>
 
 #include "../../include/afx.h"
@@ -33,6 +34,21 @@ double ProcessCpuSeconds() {
   ::clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &t);
   return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec;
 }
+
+// 64-bit FNV-1a over 8-byte words (row digests: equality of results, not cryptography)
+struct TDigest {
+  uint64_t mHash = 1469598103934665603ull;
+  void Add(const void* p, size_t Bytes) {
+    const unsigned char* b = (const unsigned char*)p;
+    size_t i = 0;
+    for (; i + 8 <= Bytes; i += 8) {
+      uint64_t w;
+      std::memcpy(&w, b + i, 8);
+      mHash = (mHash ^ w) * 1099511628211ull;
+    }
+    for (; i < Bytes; ++i) mHash = (mHash ^ b[i]) * 1099511628211ull;
+  }
+};
 
 double ThreadCpuSeconds() {
   timespec t;
@@ -176,6 +192,33 @@ private:
 
 }  // namespace
 
+double UsableHostCpus() {
+  double Cpus = 0;
+  cpu_set_t Set;
+  if (::sched_getaffinity(0, sizeof(Set), &Set) == 0) Cpus = (double)CPU_COUNT(&Set);
+  if (Cpus < 1) Cpus = (double)std::thread::hardware_concurrency();
+  if (Cpus < 1) Cpus = 1;
+  // the container's CPU bandwidth limit (the GPU pool shows 256 hardware threads and allows 16 CPUs)
+  double Quota = 0;
+  if (std::FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {            // cgroup v2: "<quota|max> <period>"
+    char Text[64] = {0};
+    double Period = 0;
+    if (std::fscanf(f, "%63s %lf", Text, &Period) == 2 && std::strcmp(Text, "max") != 0 && Period > 0) Quota = std::atof(Text) / Period;
+    std::fclose(f);
+  } else {
+    double Q = 0, P = 0;                                                      // cgroup v1
+    if (std::FILE* q = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (std::fscanf(q, "%lf", &Q) != 1) Q = 0; std::fclose(q); }
+    if (std::FILE* p = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(p, "%lf", &P) != 1) P = 0; std::fclose(p); }
+    if (Q > 0 && P > 0) Quota = Q / P;
+  }
+  return (Quota > 0 && Quota < Cpus) ? Quota : Cpus;
+}
+
+int WorkersPerDeviceFor(int NumberOfDevices) {
+  const int PerDevice = (int)(UsableHostCpus() / (double)(NumberOfDevices < 1 ? 1 : NumberOfDevices));
+  return PerDevice < 1 ? 1 : (PerDevice > 5 ? 5 : PerDevice);
+}
+
 // What outlives one crawl: the analysers (one plan per device, with its pooled device workspaces) and the page-locked
 // buffers.  Setting these up costs ~65 ms on an MI355X box -- as much as analysing 8 000 one-second files.
 struct TCrawler::TImpl {
@@ -228,7 +271,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
       Options.mFftFrameSize != mpImpl->mFftFrameSize || Options.mHopFrameSize != mpImpl->mHopFrameSize)
     throw TReadableException("TCrawler::Crawl: devices / geometry differ from the crawler's");
   const int G = (int)Options.mDevices.size();
-  const int W = Options.mWorkersPerDevice < 1 ? 1 : Options.mWorkersPerDevice;
+  const int W = Options.mWorkersPerDevice < 1 ? WorkersPerDeviceFor(G) : Options.mWorkersPerDevice;
   const int FilesPerBatch = Options.mFilesPerBatch < 1 ? 1 : Options.mFilesPerBatch;
   std::vector<std::unique_ptr<TSampleAnalyser>>& Analysers = mpImpl->mAnalysers;
   TPinnedPool& Pool = mpImpl->mRecordPool;
@@ -253,6 +296,12 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
 
   TCrawlStatistics Total;
   Total.mFilesPerDevice.assign((size_t)G, 0);
+  Total.mPcmBytesPerDevice.assign((size_t)G, 0);
+  Total.mSecondsPerDevice.assign((size_t)G, 0.0);
+  Total.mWorkersPerDevice = W;
+  Total.mUsableHostCpus = UsableHostCpus();
+  if (Options.mRowDigests) Total.mRowDigests.assign(Files.size(), 0);
+  const double Start = Now();
   Total.mHardwareQueuesInEnvironment = mpImpl->mHardwareQueuesInEnvironment;
   double PhaseSeconds[2] = {0, 0};   // summed over workers: parse + staging copy, GPU round trip
   double GpuSeconds[3] = {0, 0, 0};  // of the round trip: upload + LoadSample, kernels enqueue, download + wait
@@ -383,6 +432,30 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
         if (k >= 0 && Done.mResults.mStatus[(size_t)k] != AFX_OK)
           Done.mFailed[i] = std::string("Sample failed to load: ") + afx_status_str(Done.mResults.mStatus[(size_t)k]);
       }
+      // a digest of everything the device returned for a file (TCrawlOptions::mRowDigests): the file's slot is this
+      // worker's alone, no lock
+      if (Options.mRowDigests) {
+        const TRecordBatch& R = Done.mResults;
+        for (size_t i = 0; i < n; ++i) {
+          const int k = Done.mBatchIndex[i];
+          if (k < 0 || !Done.mFailed[i].empty()) continue;
+          TDigest D;
+          const int64_t f0 = R.mFrameOffset[(size_t)k], f1 = R.mFrameOffset[(size_t)k + 1];
+          D.Add(R.mpRecords + f0 * R.mStride, (size_t)((f1 - f0) * R.mStride) * sizeof(double));
+          D.Add(R.mpStatistics + (size_t)k * (size_t)R.mStride * 13, (size_t)R.mStride * 13 * sizeof(double));
+          D.Add(&R.mEffectiveLength[(size_t)k * 3], 3 * sizeof(double));
+          const TSampleDataInfo& Info = R.mInfo[(size_t)k];
+          D.Add(&Info.mPeakValue, sizeof(float)); D.Add(&Info.mRmsValue, sizeof(float));
+          D.Add(&Info.mDataOffset, sizeof(int)); D.Add(&Info.mNumberOfSamples, sizeof(int64_t));
+          if (!R.mRhythmOffset.empty() && R.mpRhythmOnsets) {
+            const int64_t t0 = R.mRhythmOffset[(size_t)k], t1 = R.mRhythmOffset[(size_t)k + 1];
+            D.Add(R.mpRhythmOnsets + t0 * 2, (size_t)(t1 - t0) * 2 * sizeof(double));
+            D.Add(R.mpRhythmScalars + (size_t)k * 14, 14 * sizeof(double));
+            D.Add(R.mpRhythmStatistics + (size_t)k * 26, 26 * sizeof(double));
+          }
+          Total.mRowDigests[(size_t)(Done.mFiles[i] - Files.data())] = D.mHash ? D.mHash : 1;
+        }
+      }
       // with a database: the rows' column values are built here, by the eight workers, not by the one writer
       if (pPool && Options.mPrepareRowsInWorkers) {
         Done.mpRows = RowPool.Acquire();
@@ -407,8 +480,13 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
       Total.mPcmBytes += Work.mDecoded.empty() ? 0 : PcmBytes;
       Total.mResultBytes += ResultBytes;
       Total.mFilesPerDevice[(size_t)d] += (int64_t)n;
+      Total.mPcmBytesPerDevice[(size_t)d] += Work.mDecoded.empty() ? 0 : PcmBytes;
     }
     Queue.Push(std::move(Work.mpDone));
+    {
+      std::lock_guard<std::mutex> Lock(StatMutex);
+      Total.mSecondsPerDevice[(size_t)d] = Now() - Start;
+    }
   };
 
   auto Worker = [&](int d) {
@@ -565,7 +643,6 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
     }
   });
 
-  const double Start = Now();
   const double CpuStart = ProcessCpuSeconds();
   std::vector<std::thread> Workers;
   for (int d = 0; d < G; ++d)
@@ -628,6 +705,15 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
                                       const int32_t* devices, int32_t n_devices, int32_t workers_per_device,
                                       int32_t files_per_batch, const char* database_path, double* stats, char* error,
                                       int32_t error_size) {
+  return afec_crawl_wave_images_ex(names, images, sizes, n_files, devices, n_devices, workers_per_device, files_per_batch,
+                                   database_path, stats, nullptr, nullptr, nullptr, error, error_size);
+}
+
+extern "C" int afec_crawl_wave_images_ex(const char* const* names, const void* const* images, const int64_t* sizes,
+                                         int32_t n_files, const int32_t* devices, int32_t n_devices, int32_t workers_per_device,
+                                         int32_t files_per_batch, const char* database_path, double* stats,
+                                         double* device_stats, uint64_t* row_digests, double* crawl_facts, char* error,
+                                         int32_t error_size) {
   try {
     std::vector<afec::TCrawlFile> Files((size_t)n_files);
     for (int32_t i = 0; i < n_files; ++i) {
@@ -646,6 +732,7 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
     Options.mTestFailBatch = gTestFailBatch; Options.mTestFailAttempts = gTestFailAttempts; Options.mTestDeviceLost = gTestDeviceLost != 0;
     if (gDeviceBytesPerBatch > 0) Options.mDeviceBytesPerBatch = gDeviceBytesPerBatch;
     if (gFrameKernel >= 0) Options.mFrameKernel = gFrameKernel;
+    Options.mRowDigests = row_digests != nullptr;
     {
       std::lock_guard<std::mutex> Lock(gPragmaMutex);
       Options.mDatabasePragmas = gDatabasePragmas;
@@ -677,6 +764,15 @@ extern "C" int afec_crawl_wave_images(const char* const* names, const void* cons
       stats[10 + n_devices] = (double)s.mRetriedBatches;
       stats[11 + n_devices] = (double)s.mDeviceFailedFiles;
     }
+    if (device_stats)
+      for (int32_t d = 0; d < n_devices; ++d) {
+        device_stats[3 * d] = (double)s.mFilesPerDevice[(size_t)d];
+        device_stats[3 * d + 1] = (double)s.mPcmBytesPerDevice[(size_t)d];
+        device_stats[3 * d + 2] = s.mSecondsPerDevice[(size_t)d];
+      }
+    if (row_digests)
+      for (int32_t i = 0; i < n_files; ++i) row_digests[i] = s.mRowDigests[(size_t)i];
+    if (crawl_facts) { crawl_facts[0] = (double)s.mWorkersPerDevice; crawl_facts[1] = s.mUsableHostCpus; }
     return 0;
   } catch (const std::exception& e) {
     if (error && error_size > 0) std::snprintf(error, (size_t)error_size, "%s", e.what());
@@ -718,5 +814,8 @@ extern "C" int afec_wave_probe_file(const char* path, int64_t* props, void* payl
     return -1;
   }
 }
+
+extern "C" double afec_usable_host_cpus(void) { return afec::UsableHostCpus(); }
+extern "C" int32_t afec_workers_per_device_for(int32_t n_devices) { return afec::WorkersPerDeviceFor(n_devices); }
 
 extern "C" int afec_shard_of_file(int64_t file_index, int32_t n_devices) { return afec::ShardOfFile(file_index, n_devices); }

@@ -33,11 +33,12 @@ struct TCrawlFile {
 
 struct TCrawlOptions {
   std::vector<int> mDevices = {0};  // HIP device ordinals
-  // host threads (= batches in flight) per device.  5: the host link is full from 5 on (284 k one-second files/s; 8: 281 k)
-  // and every worker costs host CPU -- 1.78 busy CPUs per GPU with 5, 1.90-2.2 with 8 (round 5, tools/thread_cpu.py): a
-  // node with 8 GPUs and a 16-CPU quota has 2 per GPU.  Crawls that read the files themselves (pread out of the page
-  // cache is the cost there) gain from more.
-  int mWorkersPerDevice = 5;
+  // host threads (= batches in flight) per device.  0: picked from the CPUs the process may really use (the cgroup CPU
+  // bandwidth quota, else the affinity mask) -- floor(CPUs / devices), at most 5, at least 1 (WorkersPerDeviceFor): the
+  // host link is full from 5 on (284 k one-second files/s; 8: 281 k) and every worker costs host CPU -- 1.78 busy CPUs per
+  // GPU with 5, 1.90-2.2 with 8 (round 5, tools/thread_cpu.py) -- so a node with 8 GPUs and a 16-CPU quota gets 2 per GPU,
+  // one GPU alone 5.  Crawls that read the files themselves (pread out of the page cache is the cost there) gain from more.
+  int mWorkersPerDevice = 0;
   int mFilesPerBatch = 512;         // measured best on one MI355X for 1 s stereo files (profiles/r02/README.md)
   int64_t mBytesPerBatch = 128 << 20;  // a batch also ends before the file that takes it over this many file bytes (a
                                     // 16-bit mono file needs ~10 x its size in device memory: PCM as doubles, spectra)
@@ -77,7 +78,17 @@ struct TCrawlOptions {
   // (the crawl must end with the error).
   int mTestFailBatch = -1, mTestFailAttempts = 0;
   bool mTestDeviceLost = false;
+  // TCrawlStatistics::mRowDigests is filled: one 64-bit digest per file over everything the device returned for it
+  // (per-frame records, statistics, rhythm results, LoadSample's facts), computed by the worker that analysed its batch.
+  // For checks that the same content gives the same row whichever device / batch it landed on (bench.py's sharded crawl)
+  bool mRowDigests = false;
 };
+
+// CPUs the process may use at once: the cgroup CPU bandwidth quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) where
+// one is set, else the size of the affinity mask
+double UsableHostCpus();
+// TCrawlOptions::mWorkersPerDevice == 0: floor(UsableHostCpus() / NumberOfDevices), at most 5, at least 1
+int WorkersPerDeviceFor(int NumberOfDevices);
 
 struct TCrawlStatistics {
   int64_t mFiles = 0, mFailedFiles = 0, mFrames = 0, mBatches = 0;
@@ -89,6 +100,11 @@ struct TCrawlStatistics {
   double mSeconds = 0;              // first file read .. last result delivered to the writer
   double mWriterSeconds = 0;        // time the writer spent inserting (0 without a database)
   std::vector<int64_t> mFilesPerDevice;
+  std::vector<int64_t> mPcmBytesPerDevice;   // bytes of PCM uploaded to each device
+  std::vector<double> mSecondsPerDevice;     // crawl start .. the device's last batch handed to the writer
+  int mWorkersPerDevice = 0;                 // the worker threads per device the crawl ran with
+  double mUsableHostCpus = 0;                // UsableHostCpus() when the crawl started
+  std::vector<uint64_t> mRowDigests;         // TCrawlOptions::mRowDigests: [file], 0 for files that were not analysed
   double mCpuSeconds = 0;           // CPU time the process spent during the crawl (all threads): mCpuSeconds / mSeconds = busy CPUs
   // GPU_MAX_HW_QUEUES as the environment had it when the crawler was built (0: unset).  The HIP runtime reads it at its
   // first call: when the process had used HIP before, a value set here came too late (175-205 k instead of 268 k files/s)
@@ -133,6 +149,20 @@ extern "C" {
 int afec_crawl_wave_images(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
                            const int32_t* devices, int32_t n_devices, int32_t workers_per_device, int32_t files_per_batch,
                            const char* database_path, double* stats, char* error, int32_t error_size);
+// The same with the per-device figures and the row digests of a sharded crawl: device_stats (NULL or [n_devices][3]) =
+// {files, bytes of PCM uploaded, seconds until the device's last batch was delivered} per device; row_digests (NULL or
+// [n_files]) = TCrawlStatistics::mRowDigests; crawl_facts (NULL or [2]) = {worker threads per device the crawl ran with,
+// UsableHostCpus()}.  workers_per_device <= 0: TCrawlOptions' default (picked from the usable CPUs and the device count).
+int afec_crawl_wave_images_ex(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
+                              const int32_t* devices, int32_t n_devices, int32_t workers_per_device, int32_t files_per_batch,
+                              const char* database_path, double* stats, double* device_stats, uint64_t* row_digests,
+                              double* crawl_facts, char* error, int32_t error_size);
+// BASELINE.json configs[1]'s input: n floats U(-1, 1) from std::mt19937(seed) through
+// std::uniform_real_distribution<float>(-1, 1) -- the generator the CPU-baseline driver built from the reference's own objects draws from
+// (its `time` mode), so both sides of the comparison see the same stream
+void afec_fill_uniform_mt19937(float* dst, int64_t n, uint32_t seed);
+double afec_usable_host_cpus(void);                      // afec::UsableHostCpus
+int32_t afec_workers_per_device_for(int32_t n_devices);  // afec::WorkersPerDeviceFor
 // TWaveFile::OpenForRead on a file image: props = {channels, sampling rate, bits per sample, TSampleType, sample
 // frames, AFX_RAW_* format of the decoded payload, payload bytes}; when payload is not NULL the decoded payload
 // (8-bit files widened to int16) is copied there (payload_capacity bytes).  Returns 0, or -1 with the reader's message.

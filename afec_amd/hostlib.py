@@ -25,6 +25,11 @@ def lib():
                                              ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
                                              ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p,
                                              ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int32]
+        L.afec_crawl_wave_images_ex.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_void_p),
+                                                ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p,
+                                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
+                                                ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int32]
         _lib = L
     return _lib
 
@@ -58,8 +63,11 @@ def wave_probe_file(path):
     return d, payload[:d["payload_bytes"]].tobytes()
 
 
-def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, database=None):
-    """images: list of bytes (WAV file images), or None: names are the paths of files on disk.  -> dict of statistics."""
+def crawl(images, names=None, devices=(0,), workers=None, files_per_batch=512, database=None, digests=False):
+    """images: list of bytes (WAV file images), or None: names are the paths of files on disk.  -> dict of statistics.
+    workers: host threads per device; None = the library's choice (TCrawlOptions::mWorkersPerDevice = 0: from the CPUs the
+    process may use and the number of devices, at most 5).  digests: also "row_digests", one uint64 per file over
+    everything the device returned for it (0: not analysed)."""
     L = lib()
     n = len(images) if images is not None else len(names)
     names = names or [f"file{i:06d}.wav" for i in range(n)]
@@ -70,21 +78,56 @@ def crawl(images, names=None, devices=(0,), workers=8, files_per_batch=512, data
         c_sizes = (ctypes.c_int64 * n)(*[len(b) for b in images])
     else:
         c_images = c_sizes = None
-    c_dev = (ctypes.c_int32 * len(devices))(*devices)
-    stats = (ctypes.c_double * (12 + len(devices)))()
+    G = len(devices)
+    c_dev = (ctypes.c_int32 * G)(*devices)
+    stats = (ctypes.c_double * (12 + G))()
+    device_stats = (ctypes.c_double * (3 * G))()
+    facts = (ctypes.c_double * 2)()
+    row_digests = np.zeros(n, dtype=np.uint64) if digests else None
     err = ctypes.create_string_buffer(512)
-    rc = L.afec_crawl_wave_images(c_names, c_images, c_sizes, n, c_dev, len(devices), workers, files_per_batch,
-                                  database.encode() if database else None, stats, err, 512)
+    rc = L.afec_crawl_wave_images_ex(c_names, c_images, c_sizes, n, c_dev, G, int(workers or 0), files_per_batch,
+                                     database.encode() if database else None, stats, device_stats,
+                                     row_digests.ctypes.data if digests else None, facts, err, 512)
     if rc != 0:
         raise RuntimeError(err.value.decode())
     keys = ["files", "failed", "frames", "pcm_bytes", "result_bytes", "seconds", "writer_seconds", "batches"]
     out = dict(zip(keys, list(stats)[:8]))
-    out["files_per_device"] = [int(v) for v in list(stats)[8:8 + len(devices)]]
-    out["cpu_seconds"] = stats[8 + len(devices)]   # process CPU time during the crawl: / seconds = busy CPUs
-    out["skipped_sample_rate"] = int(stats[9 + len(devices)])   # files at another rate than the analyser's (not resampled here)
-    out["retried_batches"] = int(stats[10 + len(devices)])      # GPU round trips that failed on a live device and were retried
-    out["device_failed_files"] = int(stats[11 + len(devices)])  # files recorded as failed after their own attempts failed
+    out["files_per_device"] = [int(v) for v in list(stats)[8:8 + G]]
+    out["cpu_seconds"] = stats[8 + G]   # process CPU time during the crawl: / seconds = busy CPUs
+    out["skipped_sample_rate"] = int(stats[9 + G])   # files at another rate than the analyser's (not resampled here)
+    out["retried_batches"] = int(stats[10 + G])      # GPU round trips that failed on a live device and were retried
+    out["device_failed_files"] = int(stats[11 + G])  # files recorded as failed after their own attempts failed
+    out["pcm_bytes_per_device"] = [int(device_stats[3 * d + 1]) for d in range(G)]
+    out["seconds_per_device"] = [float(device_stats[3 * d + 2]) for d in range(G)]   # crawl start .. the device's last batch delivered
+    out["workers_per_device"] = int(facts[0])
+    out["usable_host_cpus"] = float(facts[1])
+    if digests:
+        out["row_digests"] = row_digests
     return out
+
+
+def fill_uniform_mt19937(n, seed):
+    """n float32 U(-1, 1) from std::mt19937(seed) + std::uniform_real_distribution<float>(-1, 1): BASELINE configs[1]'s
+    generator, the one the CPU-baseline driver (the reference's own objects) draws from."""
+    L = lib()
+    L.afec_fill_uniform_mt19937.restype = None
+    L.afec_fill_uniform_mt19937.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32]
+    x = np.empty(int(n), dtype=np.float32)
+    L.afec_fill_uniform_mt19937(x.ctypes.data, int(n), int(seed) & 0xFFFFFFFF)
+    return x
+
+
+def usable_host_cpus():
+    L = lib()
+    L.afec_usable_host_cpus.restype = ctypes.c_double
+    return float(L.afec_usable_host_cpus())
+
+
+def workers_per_device_for(n_devices):
+    L = lib()
+    L.afec_workers_per_device_for.restype = ctypes.c_int32
+    L.afec_workers_per_device_for.argtypes = [ctypes.c_int32]
+    return int(L.afec_workers_per_device_for(int(n_devices)))
 
 
 def release():

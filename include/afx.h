@@ -19,7 +19,7 @@
 extern "C" {
 #endif
 
-#define AFX_VERSION 5
+#define AFX_VERSION 6
 
 /* ---- status codes (replace TReadableException on this path, SampleAnalyser.cpp:397-408) ---- */
 enum {
@@ -389,6 +389,11 @@ void afx_host_free(void* p);
  * 270 k files/s with about 3 instead of 7 busy CPUs (TCrawlOptions::mSleepingWaits).  Per plan; applies to the batches
  * created after the call.  (ABI 3 had a process-wide afx_set_blocking_wait instead.) */
 int afx_plan_set_blocking_wait(afx_plan* plan, int32_t blocking);
+
+/* HIP devices this process can use (0 when there is none or the runtime cannot be reached): the ordinals a host layer
+ * shards files over, file i -> device i mod G (Crawler.cpp:706-728 hands one self-contained task per file to a pool of
+ * threads; afec::TCrawlOptions::mDevices).  ABI 6. */
+int afx_device_count(void);
 
 /* Does the plan's device still answer?  AFX_OK, or AFX_ERR_HIP when the runtime reports an error for a trivial request
  * on this device (after a fault that took the context down every call fails).  A caller whose batch failed uses this to

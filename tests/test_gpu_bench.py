@@ -39,6 +39,20 @@ def test_gpus_2_run_plainly_starts_two_ranks_and_counts_both():
     assert abs(two["value"] - 2 * per_rank * two["steps"] / (two["ms_per_step"] * 1e-3 * two["steps"])) <= 1e-6 * two["value"]
     assert all(r["ms_per_step"] <= two["ms_per_step"] * (1 + 1e-9) for r in two["ranks"])
     assert two["config"]["parity_spot_check"]["passed"] and two["config"]["parity_spot_check"]["worst_over_ceiling"] <= 1.0
+    # the clock of the timed launches is sampled in the run itself (tools/clock_probe), per rank
+    assert 1.0 < two["roofline"]["clock_ghz_in_run"] < 2.6, two["roofline"]["clock_probe"]
+    assert two["roofline"]["clock_probe"]["ended_by"] == "stop"
+    assert all(1.0 < r["clock_ghz_in_run"] < 2.6 for r in two["ranks"])
+    # after the replicas ONE process drove both shards through the C++ file-sharding crawler (file i -> shard i mod 2,
+    # Crawler.cpp:706-728): BASELINE configs[3]'s 12 500 files per GPU, every content on every shard with the same digest
+    sc = two["config"]["sharded_crawl"]
+    assert "error" not in sc, sc
+    assert sc["devices"] == [0, 0] and sc["files"] == 25000 and sc["failed"] == 0
+    assert sc["files_per_device"] == [12500, 12500]
+    assert sc["row_digests"]["identical_per_content"] and sc["row_digests"]["files_per_device"] == [126, 126]
+    from afec_amd import hostlib
+    assert sc["workers_per_device"] == hostlib.workers_per_device_for(2) and sc["cpu_quota"] == hostlib.usable_host_cpus()
+    assert sc["files_per_s"] > 0 and len(sc["upload_GB_per_s_per_device"]) == 2 and sc["busy_host_cpus"] > 0
 
 
 def test_a_rank_without_a_device_of_its_own_fails_the_job():
@@ -54,18 +68,46 @@ def test_a_rank_without_a_device_of_its_own_fails_the_job():
     assert not any(l.startswith(b"{") for l in r.stdout.splitlines())
 
 
-@pytest.mark.parametrize("workload,n_files", [("c3", 96), ("c4", 160)])
-def test_chain_rate_objects_of_the_line(workload, n_files):
-    """config.c3_frames_per_s / c4_share_frames_per_s: a small batch of the same files through bench.chain_rate --
-    rate, roofline fraction on SURVEY's 5 080 B per frame, and the three-file parity spot check inside bar and ceiling"""
+@pytest.mark.parametrize("workload,n_files,mask_name,batch_files",
+                         [("c3", 96, "frame", 0), ("c4", 160, "frame", 0), ("c3", 96, "all", 0), ("c4", 160, "frame", 48)])
+def test_chain_rate_objects_of_the_line(workload, n_files, mask_name, batch_files):
+    """config.c3_frames_per_s / c4_share_frames_per_s / c3_spectral_set_frames_per_s / c4_share_at_crawler_shape: a small
+    batch of the same files through bench.chain_rate -- rate, roofline fraction on SURVEY's 5 080 B per frame, the clock
+    sampled during the timed launches, and the three-file parity spot check inside bar and ceiling"""
     sys.path.insert(0, ROOT)
     import afec_amd as afx
     import bench
-    plan = afx.Plan(max_analysis_ms=0)
-    out = bench.chain_rate(plan, workload, n_files, 4321)
+    plan = afx.Plan(max_analysis_ms=0, frame_kernel=afx.FRAME_KERNEL_WAVE64 if batch_files else afx.FRAME_KERNEL_AUTO)
+    out = bench.chain_rate(plan, workload, n_files, 4321, mask_name=mask_name, batch_files=batch_files, in_flight=3)
     plan.close()
     assert out["files"] == n_files and out["frames"] > 30 * n_files and out["frames_per_s"] > 0
     assert abs(out["frac"] - out["frames_per_s"] * 5080 / 8e12) <= 1e-12
+    assert out["clock_ghz_in_run"] is None or 1.0 < out["clock_ghz_in_run"] < 2.6
+    if batch_files:
+        assert out["batches"].startswith("4 batches of <= 48 files, 3 in flight") and out["frame_kernel"] == "wave64"
     spot = out["parity_spot_check"]
     assert spot.get("passed"), spot
     assert spot["files"] == sorted({0, n_files // 2, n_files - 1}) and spot["worst_over_ceiling"] <= 1.0
+    if mask_name == "all":
+        assert "f0" not in out["descriptors"].split("BASELINE")[0]
+
+
+def test_the_default_line_one_gpu_sharded_crawl_agrees_with_the_end_to_end_driver():
+    """The driver's own command (minus the CPU baseline): config.sharded_crawl at N = 1 is the same C++ driver over one
+    device and must agree with config.end_to_end_host_driver; the roofline carries the clock of this very run and the
+    VALU fraction at that clock and at the nominal one; the two round-6 chain objects are there with their spot checks."""
+    line = _bench_line("--no-cpu-baseline")
+    roof, cfg = line["roofline"], line["config"]
+    assert 1.0 < roof["clock_ghz_in_run"] < 2.6 and roof["clock_probe"]["ended_by"] == "stop"
+    if roof["valu"] is not None:      # counters are quoted for the build they were measured on only
+        assert roof["valu"]["clock_ghz"] == roof["clock_ghz_in_run"]
+        assert roof["valu"]["frac_at_nominal_clock"] < roof["valu"]["frac"] <= 1.0
+    sc, e2e = cfg["sharded_crawl"], cfg["end_to_end_host_driver"]
+    assert "error" not in sc and "error" not in e2e, (sc, e2e)
+    assert sc["files_per_device"] == [12500] and sc["row_digests"]["identical_per_content"]
+    assert sc["workers_per_device"] == e2e["workers"] == 5 or sc["cpu_quota"] < 5
+    assert abs(sc["files_per_s"] / e2e["files_per_s"] - 1.0) < 0.10, (sc["files_per_s"], e2e["files_per_s"])
+    for key in ("c3_frames_per_s", "c3_spectral_set_frames_per_s", "c4_share_frames_per_s", "c4_share_at_crawler_shape"):
+        assert cfg[key]["parity_spot_check"]["passed"], (key, cfg[key]["parity_spot_check"])
+    assert cfg["c4_share_at_crawler_shape"]["frame_kernel"] == "wave64"
+    assert "mt19937" in cfg["workload"]

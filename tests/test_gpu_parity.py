@@ -133,9 +133,10 @@ def test_chunking_invariance_bitwise(plan):
 
 
 def test_c2_full_size_against_oracle_sample(plan, oracle):
-    """BASELINE config C2: 10 000 frames of U(-1,1), MFCC only."""
-    rng = np.random.default_rng(1234)
-    x = rng.uniform(-1, 1, 10241024).astype(np.float32)
+    """BASELINE config C2: 10 000 frames of U(-1,1) from std::mt19937(1234) (SURVEY 8d's generator), MFCC only."""
+    from afec_amd import hostlib
+    x = hostlib.fill_uniform_mt19937(10241024, 1234)
+    assert x.dtype == np.float32 and abs(float(x[0]) + 0.6169611) < 1e-6 and -1.0 <= x.min() and x.max() < 1.0
     res = plan.extract([x], afx.D_C2)
     assert res["mfcc"].shape == (10000, 14)
     assert np.all(np.isfinite(res["mfcc"]))

@@ -8,6 +8,9 @@
 #   gpus2                        `bench.py --gpus 2` run plainly, both ranks on device 0 -> $O/bench_gpus2.json
 #   profile=<tag>[,<args>]       tools/profile_config.py <tag> <args>  (kernel trace + PMC passes)
 #   profiles                     every configuration of profiles/kernel_profiles.json
+#   lease                        ONE lease, one record: the driver's bench line, then every profile, then tools/lease_report.py
+#                                (host name, the line's rates and in-run clocks beside the profiled kernel times of c2 / c3 / c4)
+#                                                                                     -> $O/lease_report.{json,txt}
 #   ab=<bench args>@<lib>,<lib>  steady per-kernel durations of builds under afec_amd/lib/<lib>/ (kernel trace only)
 #   steps=<lib>,<lib>            whole-step rates of builds on the six bench configurations, two passes
 #   fuzz=<seconds>,<seed>[,stats]  tests/fuzz_gpu.py (stats: the half-wave statistics classes)
@@ -16,8 +19,9 @@
 #   small                        single_buffer / x_batchsize / x_classes / e2e accounting / shards8
 # Every stage prints a short tail; the full outputs stay under gpurun_out/$AFX_ROUND/.
 set -u
-export AFX_ROUND=${AFX_ROUND:-r05}
+export AFX_ROUND=${AFX_ROUND:-r06}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+export GRAFT_REPO_ROOT=$ROOT      # tools/x_kernel_ab.sh reads it (outside gpurun it is not set)
 O=$ROOT/gpurun_out/$AFX_ROUND; mkdir -p $O
 lib_of() { echo "$ROOT/afec_amd/lib/$1/libafx_hip.so"; }
 
@@ -48,7 +52,15 @@ for STAGE in "$@"; do
       python tools/profile_config.py frame_f64 --mask frame | head -12
       AFX_PROF_WARMUP=12 AFX_PROF_STEPS=20 python tools/profile_config.py c3 --workload c3 --mask frame | head -12
       python tools/profile_config.py c4 --workload c4 --mask frame | head -12
-      python tools/profile_config.py c4_everything --workload c4 --mask everything | head -16 ;;
+      python tools/profile_config.py c4_everything --workload c4 --mask everything | head -16
+      AFX_PROF_WARMUP=12 AFX_PROF_STEPS=20 python tools/profile_config.py c3_all --workload c3 --mask all | head -8
+      python tools/profile_config.py c4_crawler --workload c4 --mask frame --batch-files 512 --in-flight 5 --frame-kernel wave64 | head -12 ;;
+    lease)
+      hostname > $O/lease_host.txt; date -u +%FT%TZ >> $O/lease_host.txt
+      timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench_default.json 2> $O/bench_default.err
+      echo "bench rc=$?"; tail -2 $O/bench_default.err
+      bash $0 profiles
+      python tools/lease_report.py | tee $O/lease_report.txt ;;
     ab)
       BARGS=${ARG%%@*}; LIBS=${ARG#*@}
       AFX_ROUND=${AFX_ROUND}x bash tools/x_kernel_ab.sh "$BARGS" ${LIBS//,/ } 2>&1 | tee -a $O/ab.txt ;;

@@ -11,7 +11,7 @@ import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = sys.argv[1] if len(sys.argv) > 1 else "r04"
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC = os.path.join(ROOT, "gpurun_out", ROUND)
 DST = os.path.join(ROOT, "profiles", ROUND)
 CLOCK_GHZ = 2.0    # fallback when a profile has no GRBM_GUI_ACTIVE: in-kernel (s_memtime / s_memrealtime, stamps build) at steady
@@ -42,6 +42,7 @@ for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
         "valu_instructions_per_frame": d["per_frame"]["valu_instructions"],
         # the clock the counters themselves saw: GRBM_GUI_ACTIVE / 8 XCDs / kernel time of the profiled run
         "clock_ghz": round(d.get("clock_ghz_grbm") or CLOCK_GHZ, 3),
+        "host": d.get("host"),
         "frames_profiled": d["frames_per_step"],
         "limiter": LIMITER.get(tag, "f64 VALU issue"),
         "kernels": kernels,
@@ -52,7 +53,8 @@ for f in sorted(glob.glob(os.path.join(SRC, "profile_*.json"))):
     shutil.copy(f, DST)
 for pat in ("*_kernel_stats.csv", "*_kernel_steady.csv", "*_pmc_summary.csv", "*_pmc.csv", "rhythm_report.md", "parity_report.md", "ubench_*.txt",
             "bench_default.json", "pytest_gpu.log", "*_pmc_kernels.csv", "single_buffer.txt", "kernel_choice_by_batch_size.txt",
-            "halfwave_classes_on_c4.txt", "e2e_cpu_accounting.txt", "shards8_busy_cpus.txt", "fuzz_*.log", "crawl_soak.log"):
+            "halfwave_classes_on_c4.txt", "e2e_cpu_accounting.txt", "shards8_busy_cpus.txt", "fuzz_*.log", "crawl_soak.log",
+            "lease_report.json", "lease_report.txt", "lease_host.txt", "bench_*.json"):
     for f in glob.glob(os.path.join(SRC, pat)):
         shutil.copy(f, DST)
 json.dump(out, open(os.path.join(ROOT, "profiles", "kernel_profiles.json"), "w"), indent=1)

@@ -20,7 +20,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("AFX_ROUND", "r05")
+ROUND = os.environ.get("AFX_ROUND", "r06")
 # steps of a few ms (C3: 3.7 ms) need more warm-up launches to get past the ~30 ms the clocks take to settle from an
 # idle GPU (profiles/r03/clock_ramp.txt): AFX_PROF_WARMUP / AFX_PROF_STEPS
 STEPS, WARMUP = int(os.environ.get("AFX_PROF_STEPS", "10")), int(os.environ.get("AFX_PROF_WARMUP", "2"))
@@ -29,9 +29,13 @@ STEPS, WARMUP = int(os.environ.get("AFX_PROF_STEPS", "10")), int(os.environ.get(
 def run_pass(tag, name, prof_args, bench_args):
     d = f"/tmp/prof_{tag}_{name}"
     shutil.rmtree(d, ignore_errors=True)
+    # the counter passes serialise the dispatches: bench.py's clock probe (a kernel that runs beside the timed launches
+    # until it is told to stop) stays off there; the trace pass keeps it, so the profile records the clock of its own run
+    probe = [] if name == "trace" else ["--no-clock-probe"]
     cmd = ["rocprofv3"] + prof_args + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3",
                                        os.path.join(ROOT, "bench.py"), "--steps", str(STEPS), "--warmup", str(WARMUP),
-                                       "--no-cpu-baseline", "--no-single", "--no-spot-check", "--no-side-stream"] + bench_args
+                                       "--no-cpu-baseline", "--no-single", "--no-spot-check", "--no-side-stream",
+                                       "--no-sharded-crawl"] + probe + bench_args
     # --no-side-stream: the rhythm kernels on the batch's own stream, so that a kernel's duration is its own
     env = dict(os.environ, TMPDIR="/tmp")
     r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True)
@@ -111,6 +115,9 @@ def main():
         "build_info": afec_amd.build_info(),
         "bench_args": bench_args,
         "frames_per_step": frames,
+        "host": os.uname().nodename,
+        "traced_run": {"frames_per_s": bench["value"], "ms_per_step": bench["ms_per_step"],
+                       "clock_ghz_in_run": bench["roofline"].get("clock_ghz_in_run")},   # the bench line of the kernel-trace pass itself
         "unprofiled_value_frames_per_s": bench["value"],
         "kernels": kernels,
         "per_frame": {

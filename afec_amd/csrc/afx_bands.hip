@@ -54,7 +54,7 @@ __attribute__((always_inline)) constexpr int sub_pair_count() {
     for (int r = 0; r < kRows; ++r) n += sub_touches(b, r) ? 1 : 0;
   return n;
 }
-constexpr int kSubPairs = sub_pair_count();   // 25
+static_assert(sub_pair_count() == 25, "(band, row) pairs of the 64-lane layout");
 __attribute__((always_inline)) constexpr int sub_pair_index(int b, int r) {
   int n = 0;
   for (int bb = 0; bb < kNumSub; ++bb)
@@ -383,10 +383,6 @@ __device__ __forceinline__ void dma_frame(const double* frame, int lane, unsigne
   dma_16<1024>(g + 4096, lds_image + 4096);
 }
 
-#ifndef AFX_X_BANDS_DMA
-#define AFX_X_BANDS_DMA 1
-#endif
-
 // FLAGS: the kBands* bits as a compile-time constant for the combinations the planner produces for whole descriptor
 // sets (what is not selected costs neither instructions nor registers), -1: read BandArgs::flags
 template <int FLAGS>
@@ -491,11 +487,9 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       fb = wave_sum(fb); fbb = wave_sum(fbb);
     }
 
-#if AFX_X_BANDS_DMA
     // the chunk's first frame (every DS read of the chunk before has been waited for: its results were stored)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     dma_frame(a.mag + (int64_t)ch.frame0 * kHalf, lane, nat_lds);
-#endif
   for (int fi = 0; fi < ch.nframes; ++fi) {
     // lane-only predicates other than the membership masks (reduction selects, sort directions, position
     // ranges) are recomputed per frame from a re-materialised lane id: hoisted out of the loop they would
@@ -504,14 +498,9 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     asm volatile("" : "+v"(lane_v));
     const int64_t f = (int64_t)ch.frame0 + fi;
     const double* const cur = a.mag + f * kHalf;
-#if AFX_X_BANDS_DMA
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the frame's image has landed
 #pragma unroll
     for (int r = 0; r < kRows; ++r) x[r] = image[64 * r + lane_v];
-#else
-#pragma unroll
-    for (int r = 0; r < kRows; ++r) x[r] = cur[64 * r + lane_v];
-#endif
     // products rounded on their own (mul_rn): see the chunk prologue
     double xx[kRows], xy[kRows];
 #pragma unroll
@@ -531,11 +520,9 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     if (flags & kBandsStats) {
       double s1 = 0.0, s2 = 0.0, sj = 0.0, sjj = 0.0, s3 = 0.0, s4 = 0.0, prod = 1.0;
       double jq = (double)(lane_v - 1);
-      double mrow[kRows];
 #pragma unroll
       for (int r = 0; r < kRows; ++r) {
         const double m = (r == 0) ? keep_where(x[r], kFirstRowOk) : (r == kRows - 1 ? keep_where(x[r], kLastRowOk) : x[r]);
-        mrow[r] = m;
         const double m2 = m * m, jm = jq * m;
         s1 += m;
         s2 += m2;
@@ -558,22 +545,12 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       // rolloff (scalar.c:472-492): bins whose running sum stays below 85 % of the total: natural-order copy in LDS, each
       // lane walks 12 consecutive bins
       const double total = read_lane<0>(red);
-#if !AFX_X_BANDS_DMA
-      wave_lds_fence();
-#pragma unroll
-      for (int r = 0; r < kRows; ++r) nat[64 * r + lane_v] = mrow[r];
-      wave_lds_fence();
-#endif
       // (the image holds the stored magnitudes as they are: bin 0 is never walked, bins above the range are cut here)
       double seg[12], segsum = 0.0;
 #pragma unroll
       for (int i = 0; i < 12; ++i) {
         const int k = kFirstBin + 12 * lane_v + i;
-#if AFX_X_BANDS_DMA
         seg[i] = (k <= kLastBin) ? image[k < 64 * kRows ? k : 0] : 0.0;
-#else
-        seg[i] = (k <= kLastBin) ? nat[k < 64 * kRows ? k : 0] : 0.0;
-#endif
         segsum += seg[i];
       }
       const double incl = wave_scan_incl(segsum, lane_v);
@@ -590,20 +567,13 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       int cnt = (pivot > 0.0) ? below + 1 : 0;
       if (cnt > kBinCount) cnt = kBinCount;
       if (lane_v == 0) tmp[7] = (double)cnt;
-#if !AFX_X_BANDS_DMA
-      wave_lds_fence();
-#endif
     }
-#if AFX_X_BANDS_DMA
     // the next frame's image, asked for once this frame's has been read for the last time (the chunk's last frame asks for
     // its own again: no branch around the DMA)
     auto next_image = [&]() {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       dma_frame(cur + ((fi + 1 < ch.nframes) ? kHalf : 0), lane_v, nat_lds);
     };
-#else
-    auto next_image = [&]() {};
-#endif
     if (!(flags & (kBandsFeatures | kBandsFlux))) { next_image(); continue; }
 
     // ---- spectral_flux: Pearson r with the previous frame over bins 1..738 (SA:1919-1933,
@@ -647,15 +617,6 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     // adjacent band; bin 0 and 1023 never count): asked for here, all at once, and used behind the logarithms -- loaded
     // where they are compared, each was a cache round trip of its own in a branch
     double left[kRows], right[kRows];
-#if !AFX_X_BANDS_DMA
-#pragma unroll
-    for (int r = 0; r < kRows; ++r) {
-      const int k = 64 * r + lane_v;
-      left[r] = cur[(r == 0) ? k - (k > 0 ? 1 : 0) : k - 1];
-      right[r] = cur[k + 1];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     // Eight logarithms per lane, not twelve: rows 5, 6 lie wholly inside band 12 and rows 8, 9, 10 (and 48 lanes of row 11)
     // inside band 13, so a lane's factors of those rows belong to one band and are multiplied first -- what the reference
     // does anyway (a running product, logarithms only when it leaves [1e-64, 1e64]).  Factors are >= 1e-20: a product of
@@ -698,7 +659,6 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
     //      unit: ballot of the peak flags of a row, masked per band, popcount ----
     wave_lds_fence();
     if ((lane_v & 3) == 0) thr[lane_v >> 2] = bmax * 0.25;
-#if AFX_X_BANDS_DMA
     // the neighbour bins from the image, where they are compared (bin 768, the right neighbour of a bin outside every
     // band, is not in the image: any value serves)
 #pragma unroll
@@ -707,7 +667,6 @@ __global__ __launch_bounds__(256, 2) void bands_kernel(const BandArgs a) {
       left[r] = image[(r == 0) ? k - (k > 0 ? 1 : 0) : k - 1];
       right[r] = image[(r == kRows - 1) ? (k + 1 < 64 * kRows ? k + 1 : k) : k + 1];
     }
-#endif
     wave_lds_fence();
     int peaks[kNumSub];
 #pragma unroll

@@ -191,13 +191,18 @@ hipError_t upload_raw(RawBatch& r, const char** what) {
       contiguous = ((const char*)r.raws[i].data == base + r.files[(size_t)i].raw_off);
     }
   if (contiguous && base) {
-    // up to the last valid file's real end: raw_bytes rounds every file up to 16 bytes, and the bytes behind the
-    // caller's last buffer are not the library's to read (a buffer may end at the end of a mapping)
-    int64_t used = 0;
+    // from the first valid file's first byte up to the last valid file's real end: raw_bytes rounds every file up to 16
+    // bytes, and the bytes behind the caller's last buffer are not the library's to read (a buffer may end at the end of
+    // a mapping) -- nor are the bytes in front of the first valid one: a file that plan_conversions refused keeps its
+    // place in the arena's layout, and `base` then lies that far in front of the caller's memory (found by
+    // tests/sanitize/fuzz_host_abi.cpp: a refused first file + one valid scattered buffer read 300 KB before it)
+    int64_t first = -1, used = 0;
     for (int i = 0; i < r.n_bufs; ++i)
-      if (r.status[(size_t)i] == AFX_OK)
+      if (r.status[(size_t)i] == AFX_OK) {
+        if (first < 0) first = r.files[(size_t)i].raw_off;
         used = r.files[(size_t)i].raw_off + (int64_t)r.raws[i].n_frames * r.raws[i].channels * raw_bytes_per_sample(r.raws[i].format);
-    return upload_through_plan(r.plan, r.ws, r.d_raw, base, (size_t)used);
+      }
+    return upload_through_plan(r.plan, r.ws, r.d_raw + first, base + first, (size_t)(used - first));
   }
   for (int i = 0; i < r.n_bufs; ++i)
     if (r.status[(size_t)i] == AFX_OK) {

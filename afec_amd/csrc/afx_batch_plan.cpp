@@ -182,22 +182,15 @@ int choose_chunk_frames(const Planner& p) {
   for (int k = k_step; k <= 32; k += k_step) {
     int64_t nchunks = 0;
     for (int i = 0; i < p.src.n_bufs; ++i) nchunks += (b->frame_offset[i + 1] - b->frame_offset[i] + k - 1) / k;
-#if defined(AFX_X_TUNE)   // timing experiments only (never the shipped library)
-    static const double x_prologue = std::getenv("AFX_X_PROLOGUE") ? std::atof(std::getenv("AFX_X_PROLOGUE")) : -1.0;
-    const double prologue = x_prologue >= 0.0 ? x_prologue : (b->halfwave ? kHalfwavePrologue : 0.5);
-#else
     const double prologue = b->halfwave ? kHalfwavePrologue : 0.5;
-#endif
     // The 64-lane frame kernel gives every wave the same number of chunks: rounds of the wave slots x (frames per chunk
     // + lead-in).  Every kernel of the half-wave batches draws its chunks from a work queue: the slots share the work
     // (frames + lead-ins) evenly and run dry within a fraction of a chunk of each other.
     // (the 0.4: measured -- C3, 1 000 files of 82 frames: K = 6, 39.3 M frames/s against 35.8 M with the K = 22 of the
     // rounds model; the headline batch K = 32, 499 against 495 M with K = 25; the C4 share K = 10, 41.6 against 42.3 M
     // with K = 8; profiles/r04)
-#ifndef AFX_X_TAIL
-#define AFX_X_TAIL 0.4
-#endif
-    const double cost = b->halfwave ? ((double)p.frames + (double)nchunks * prologue) / (double)p.slots + AFX_X_TAIL * k
+    constexpr double kTailWeight = 0.4;
+    const double cost = b->halfwave ? ((double)p.frames + (double)nchunks * prologue) / (double)p.slots + kTailWeight * k
                                     : (double)((nchunks + p.slots - 1) / p.slots) * (k + prologue);
     if (cost < best - 1e-9 || (std::fabs(cost - best) <= 1e-9 && k > K)) { best = cost; K = k; }
   }

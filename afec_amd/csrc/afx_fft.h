@@ -8,11 +8,21 @@
 //
 // The index algebra and the conflict-free LDS map are modelled in tools/fft_dataflow_model.py; the
 // stage list with the data flow is at the top of afx_kernels.hip.
+//
+// The per-lane arithmetic (cmul, radix4, dft16) also compiles for the host: tests/host/test_fft32_math.cpp checks it
+// against a direct DFT in long double; everything that moves data between lanes is device code only.
 #pragma once
 
+#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 
 #include "afx_device.h"
+#define AFX_FFT_HD __device__ __forceinline__
+#define AFX_FFT_UNROLL _Pragma("unroll")
+#else
+#define AFX_FFT_HD inline
+#define AFX_FFT_UNROLL
+#endif
 
 namespace afx {
 namespace {
@@ -28,13 +38,13 @@ struct cx {
 };
 
 template <typename T>
-__device__ __forceinline__ cx<T> cmul(cx<T> a, cx<T> b) {
+AFX_FFT_HD cx<T> cmul(cx<T> a, cx<T> b) {
   return {a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re};
 }
 
 // forward (e^{-i}) radix-4 butterfly, in place: (a,b,c,d) -> (X0,X1,X2,X3)
 template <typename T>
-__device__ __forceinline__ void radix4(cx<T>& a, cx<T>& b, cx<T>& c, cx<T>& d) {
+AFX_FFT_HD void radix4(cx<T>& a, cx<T>& b, cx<T>& c, cx<T>& d) {
   const cx<T> t0{a.re + c.re, a.im + c.im}, t1{a.re - c.re, a.im - c.im};
   const cx<T> t2{b.re + d.re, b.im + d.im}, t3{b.re - d.re, b.im - d.im};
   a = {t0.re + t2.re, t0.im + t2.im};
@@ -45,10 +55,10 @@ __device__ __forceinline__ void radix4(cx<T>& a, cx<T>& b, cx<T>& c, cx<T>& d) {
 
 // 16-point forward DFT in registers: v[n] -> v[k]
 template <typename T>
-__device__ __forceinline__ void dft16(cx<T> (&v)[16]) {
+AFX_FFT_HD void dft16(cx<T> (&v)[16]) {
   constexpr T c1 = T(0.92387953251128673848), s1 = T(0.38268343236508978178);
   constexpr T rh = T(0.70710678118654752440);
-#pragma unroll
+AFX_FFT_UNROLL
   for (int b = 0; b < 4; ++b) radix4(v[b], v[4 + b], v[8 + b], v[12 + b]);
   // now v[4c + b] = y[b][c]; multiply by w16^(b c)
   v[4 * 1 + 1] = cmul(v[5], cx<T>{c1, -s1});
@@ -60,17 +70,19 @@ __device__ __forceinline__ void dft16(cx<T> (&v)[16]) {
   v[4 * 1 + 3] = cmul(v[7], cx<T>{s1, -c1});
   v[4 * 2 + 3] = {(v[11].im - v[11].re) * rh, -(v[11].re + v[11].im) * rh};
   v[4 * 3 + 3] = cmul(v[15], cx<T>{-c1, s1});
-#pragma unroll
+AFX_FFT_UNROLL
   for (int c = 0; c < 4; ++c) radix4(v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]);
   // v[4c + d] = X[c + 4d]: transpose the 4x4 register grid (pure renaming)
   cx<T> t[16];
-#pragma unroll
+AFX_FFT_UNROLL
   for (int c = 0; c < 4; ++c)
-#pragma unroll
+AFX_FFT_UNROLL
     for (int d = 0; d < 4; ++d) t[c + 4 * d] = v[4 * c + d];
-#pragma unroll
+AFX_FFT_UNROLL
   for (int i = 0; i < 16; ++i) v[i] = t[i];
 }
+
+#if defined(__HIPCC__)
 
 // E1/E2 through the wave's plane.  complex<float> is one 8-byte slot; complex<double> goes in two
 // passes (real parts, then imaginary parts) through the same plane.
@@ -181,6 +193,8 @@ __device__ __forceinline__ void fft1024(cx<T> (&v)[16], const cx<T>* t1, const c
   Xchg<T>::run(plane, plane_rd_addr, fft_e2_write_slot(lane), v);
   dft16(v);
 }
+
+#endif  // __HIPCC__ (cross-lane stages)
 
 }  // namespace
 }  // namespace afx

@@ -36,10 +36,7 @@ using f32x32::cx;
 
 constexpr int kHalfSlots = 1056;                      // 8-byte slots per half: 33 * 31 + 31 + 1, rounded to 32
 constexpr int kPlane32Bytes = 2 * kHalfSlots * 8;     // 16 896 per wave
-#ifndef AFX_X_WAVES32
-#define AFX_X_WAVES32 8
-#endif
-constexpr int kWaves32 = AFX_X_WAVES32;
+constexpr int kWaves32 = 8;   // (six waves with 22.5 KB of LDS each were measured: 5-10 % slower, HISTORY.md round 5)
 // raw sums per frame the statistics / full classes leave for stats32_finish_kernel: sum m, m^2, j m, j^2 m, m^3, m^4,
 // sum log(m + 1e-20), rolloff count, sum x^2 of the hop, max |x| of the hop
 
@@ -108,12 +105,7 @@ __device__ __forceinline__ double mag_sqrt_mel(double xr, double xi, double tiny
   const double x = fma(xi, xi, fma(xr, xr, tiny));
   const double r = __builtin_amdgcn_rsq(x);
   const double y = x * r;
-#if defined(AFX_X_NO_NEWTON)   // demonstration build only (profiles/r05/ceiling_demo.txt): the seed alone, ~1e-7 relative --
-  (void)three;                 // inside the 1e-4 bar on every descriptor, caught by the regression ceilings of tests/_tol.py
-  return y + y;
-#else
   return y * fma(-r, y, three);
-#endif
 }
 
 // Lanes 0 and 32 (bins 32 r) are their own partners, at another register than everybody else's: two 64-bit moves
@@ -252,30 +244,16 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
   // the FFT registers spilled those 32 registers (128 B of scratch per lane and frame pair, written and read back: 4 KiB
   // per frame each way -- which the counters showed as HBM traffic, the scratch lines do not survive in L2 next to the
   // streaming stores).
-#ifndef AFX_X_MEL_EARLY
-#define AFX_X_MEL_EARLY 4   // magnitude class: group of the untangle behind which the mel weights are asked for (-1: behind the last)
-#endif
-#ifndef AFX_X_LO_LDS
-#define AFX_X_LO_LDS 0
-#endif
+  constexpr int kMelEarly = 4;   // magnitude class: group of the untangle behind which the mel weights are asked for
   // (measured: magnitude class 2.35 -> 1.99 ms on the C4 share, full classes 23.1 -> 20.7 ms on 5.12 M frames; the
   // statistics class, which spilled 44 bytes, 16.1 -> 17.7 ms and the MFCC class 493 -> 422 M frames/s: they keep the
   // registers)
-  constexpr bool LO_LDS = (FEAT >= 2 && FEAT <= 4) || AFX_X_LO_LDS;
+  constexpr bool LO_LDS = (FEAT >= 2 && FEAT <= 4);
   // Cache policy of the classes that fetch every hop twice (round 5, A/B on the C4 share, profiles/r05/ab_cache_policy.txt):
   // the first read without the non-temporal hint -- the line is asked for again one frame later -- and the magnitude
   // stores with it (8 KiB per frame streaming through L2 would push those lines out): 2.14 -> 2.02 ms.
-#ifndef AFX_X_HOP_NT
-#define AFX_X_HOP_NT 0
-#endif
-#ifndef AFX_X_LO_NT
-#define AFX_X_LO_NT 1
-#endif
-#ifndef AFX_X_ST_NT
-#define AFX_X_ST_NT 1
-#endif
-  constexpr bool kHopNt = !LO_LDS || AFX_X_HOP_NT;   // first read of a hop
-  constexpr bool kLoNt = AFX_X_LO_NT;                // its second read, as the next frame's overlap half
+  constexpr bool kHopNt = !LO_LDS;   // first read of a hop
+  constexpr bool kLoNt = true;       // its second read, as the next frame's overlap half
   // FEAT 5: the statistics class for masks without skewness / kurtosis -- the descriptor set BASELINE.json's north star
   // names (MFCC + rms, centroid, spread, rolloff, flatness) -- keeps no third and fourth moments: four registers and two
   // operations per magnitude less.
@@ -563,16 +541,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
         asm volatile("" : "+v"(ql));
         rowm = rowd + 1024 - 2 * (ql & 31);
       };
-#if defined(AFX_X_NOSTORE)   // timing experiment only (never the shipped library): what the magnitude stores cost
-      auto store_mag = [&](double* p, double value) { asm volatile("" :: "v"(p), "v"(value)); };
-#else
-#if AFX_X_ST_NT
       auto store_mag = [&](double* p, double value) { __builtin_nontemporal_store(value > logc[kCSqrtMin] ? value : 0.0, p); };
-#else
-      auto store_mag = [&](double* p, double value) { *p = value > logc[kCSqrtMin] ? value : 0.0; };
-#endif
-
-#endif
       if (STATS) {
         int ql = lane;
         asm volatile("" : "+v"(ql));
@@ -696,17 +665,15 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           mag_rows();
           untangle(2 * g);
           untangle(2 * g + 1);
-#if AFX_X_MEL_EARLY >= 0
           // The packed mel rows, asked for in the MIDDLE of the untangle: on gfx950 stores count in vmcnt like loads and
           // retire in order, so weights asked for behind the frame's last store (where the last FFT registers die) made the
           // mel stage wait for every store of the frame.  Half-way through, the rows already untangled have freed 16
           // registers per group; the loads then wait only for the stores issued before them, which are long done when
           // the mel stage starts, and the compiler's wait count lets the later stores stay in flight.
-          if (g == AFX_X_MEL_EARLY) {
+          if (g == kMelEarly) {
 #pragma unroll
             for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
           }
-#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         // bin 512 = lane 0 of row 16 is its own partner: E = 2 Re Z, w O = -2i Im Z (the window carries the 1/2)
@@ -754,7 +721,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
       for (int r = 8; r < 12; ++r) untangle(r);
       __builtin_amdgcn_sched_barrier(0);
       }
-      if (STATS || (MAGS && AFX_X_MEL_EARLY < 0)) {   // statistics class: behind the last rows (62 registers in flight that it cannot spare earlier)
+      if (STATS) {   // statistics class: behind the last rows (62 registers in flight that it cannot spare earlier)
 #pragma unroll
         for (int i = 0; i < kMel32Pairs; ++i) mwt[i] = table_load1(mel_rs, q8, 256 * i);
       }
@@ -1060,10 +1027,7 @@ hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stre
   if (cls == 0) return scaled ? launch_frames32_class<0, true>(a, grid_blocks, stream) : launch_frames32_class<0, false>(a, grid_blocks, stream);
   if (cls == 4) return scaled ? launch_frames32_class<4, true>(a, grid_blocks, stream) : launch_frames32_class<4, false>(a, grid_blocks, stream);
   hipError_t e;
-#ifndef AFX_X_NO_CLASS5
-#define AFX_X_NO_CLASS5 0
-#endif
-  if (cls == 1 && !(a.mask & 0x30u) && !AFX_X_NO_CLASS5)   // neither skewness nor kurtosis: no third / fourth moments
+  if (cls == 1 && !(a.mask & 0x30u))   // neither skewness nor kurtosis: no third / fourth moments
     e = scaled ? launch_frames32_class<5, true>(a, grid_blocks, stream) : launch_frames32_class<5, false>(a, grid_blocks, stream);
   else if (scaled)
     e = (cls == 1) ? launch_frames32_class<1, true>(a, grid_blocks, stream)

@@ -43,15 +43,6 @@
 namespace afx {
 namespace {
 
-#ifndef AFX_WAVES_C2
-#define AFX_WAVES_C2 8
-#endif
-#ifndef AFX_WIN_GLOBAL
-#define AFX_WIN_GLOBAL 1   // double kernels: window table from global memory (1) or LDS (0)
-#endif
-#ifndef AFX_TABLE_BATCH
-#define AFX_TABLE_BATCH 0  // >0: fence the scheduler every N table reads (caps live table registers)
-#endif
 
 // feature classes the kernel is specialised for (the host picks the smallest that covers the mask)
 constexpr int kFeatC2 = 0;     // MFCC only: magnitudes of bins 0..383
@@ -76,7 +67,7 @@ struct InPair<double> {
 // LDS instruction issue, the vector-memory path is otherwise idle.
 template <typename T, int POST_ROWS>
 struct LdsMap {
-  static constexpr bool win_global = sizeof(T) == 8 && AFX_WIN_GLOBAL;
+  static constexpr bool win_global = sizeof(T) == 8;
   static constexpr int win = 0;                                                     // [16][64] cx<T>
   static constexpr int t2 = win + (win_global ? 0 : 1024 * (int)sizeof(cx<T>));     // [16][64] cx<T>
   static constexpr int post = t2 + 1024 * (int)sizeof(cx<T>);                       // [POST_ROWS][64] cx<T>
@@ -190,9 +181,6 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
         v[r] = {(T)pcm_double<SCALED>(lo[r].x, sc) * w0.re, (T)pcm_double<SCALED>(lo[r].y, sc) * w0.im};
         v[r + 8] = {(T)pcm_double<SCALED>(nxt[r].x, sc) * w1.re, (T)pcm_double<SCALED>(nxt[r].y, sc) * w1.im};
         lo[r] = nxt[r];
-#if AFX_TABLE_BATCH
-        if ((2 * r + 2) % AFX_TABLE_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
       }
       // prefetch the next frame's new hop (rows 8..15 of frame fi + 1)
       if (fi + 1 < total) {
@@ -213,9 +201,6 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
 #pragma unroll
       for (int g = 0; g < 16; ++g) {
         v[g] = cmul(v[g], t2[64 * g]);
-#if AFX_TABLE_BATCH
-        if ((g + 1) % AFX_TABLE_BATCH == 0) __builtin_amdgcn_sched_barrier(0);
-#endif
       }
       Xchg<T>::run(plane, e2r_addr, e2w, v);
 
@@ -408,7 +393,7 @@ __global__ __launch_bounds__(WAVES * 64) void frames_kernel(const FrameArgs a) {
 
 // waves per workgroup (one workgroup per CU): limited by LDS (tables + 8.5 KiB per wave <= 160 KiB)
 // and by the VGPR budget that many waves per SIMD leave
-constexpr int kWavesC2 = AFX_WAVES_C2;
+constexpr int kWavesC2 = 8;
 constexpr int kWavesOther = 8;
 
 template <typename T, typename TIn, int FEAT, int WAVES, bool SCALED>

@@ -150,19 +150,10 @@ __global__ __launch_bounds__(64) void resample_plan_kernel(unsigned char* raw, c
 // taps in the library's order: left wing i = 0, 1, .. into v, right wing into w, then (v + w) LpScl.
 // Shape of a workgroup, measured on MI355X for 12 500 one-second files (48 kHz / 96 kHz / 22.05 kHz -> 44.1 kHz; filter
 // kernel only): 1024 x 4 outputs at 4 waves per SIMD 13.7 / 24.3 / 10.6 ms; 512 x 8 15.2 / 26.4 / 12.4; 256 x 8 16.2 /
-// 26.7 / 13.0; 256 x 16 (spills) 58; one 16-lane group per record picking from global memory 62.7 (tools/ab_resample.sh).
-#ifndef AFX_RS_PER
-#define AFX_RS_PER 4
-#endif
-#ifndef AFX_RS_OCC
-#define AFX_RS_OCC 4
-#endif
-#ifndef AFX_RS_THREADS
-#define AFX_RS_THREADS 1024
-#endif
-constexpr int kRsThreads = AFX_RS_THREADS, kRsPer = AFX_RS_PER, kRsHalf = kRsPer / 2, kRsBlockOut = kRsThreads * kRsPer, kRsWindow = 4112;
+// 26.7 / 13.0; 256 x 16 (spills) 58; one 16-lane group per record picking from global memory 62.7 (HISTORY.md, round 3).
+constexpr int kRsThreads = 1024, kRsPer = 4, kRsOcc = 4, kRsHalf = kRsPer / 2, kRsBlockOut = kRsThreads * kRsPer, kRsWindow = 4112;
 
-__global__ __launch_bounds__(kRsThreads, AFX_RS_OCC) void resample_filter_kernel(unsigned char* raw, const ResampleFile* files, int n_files,
+__global__ __launch_bounds__(kRsThreads, kRsOcc) void resample_filter_kernel(unsigned char* raw, const ResampleFile* files, int n_files,
                                                                      const ResampleGroup* groups, const float* __restrict__ imp) {
   __shared__ __align__(16) float s_win[kRsWindow];
   const int tid = threadIdx.x;

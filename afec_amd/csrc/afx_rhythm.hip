@@ -208,16 +208,14 @@ __device__ __forceinline__ void onset_polar_frame(const PCM* xf, double scale, d
   wave_lds_fence();
 #pragma unroll
   for (int r = 0; r < 16; ++r) p[r].im = xg[(256 - (q + 16 * r)) & 255];
-  // AFX_POLAR_GROUP bins at a time (scheduling barriers in between): all sixteen interleaved keep more values alive than
+  // kPolarGroup bins at a time (scheduling barriers in between): all sixteen interleaved keep more values alive than
   // there are registers at three waves per SIMD (116 B of scratch).  onset_function_kernel on the C4 share: device library's
   // atan2 / sqrt 8.60 ms; these with groups of 16 / 8 / 4 / 2 bins: 8.31 / 7.90 / 7.88 / 7.73 ms (tools/ab_rhythm.sh)
-#ifndef AFX_POLAR_GROUP
-#define AFX_POLAR_GROUP 2
-#endif
+  constexpr int kPolarGroup = 2;
 #pragma unroll
-  for (int r0 = 0; r0 < 16; r0 += AFX_POLAR_GROUP) {
+  for (int r0 = 0; r0 < 16; r0 += kPolarGroup) {
 #pragma unroll
-    for (int r = r0; r < r0 + AFX_POLAR_GROUP; ++r) {
+    for (int r = r0; r < r0 + kPolarGroup; ++r) {
       const C A = u[r], B = p[r], w = ut[r * 16 + q];
       const double er = A.re + B.re, ei = A.im - B.im, orr = A.im + B.im, oi = B.re - A.re;
       const double re = er + (w.re * orr - w.im * oi);

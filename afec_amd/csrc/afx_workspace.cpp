@@ -136,10 +136,7 @@ hipError_t ws_reserve(afx_plan* plan, Workspace::Buf& b, size_t bytes) {
 // hipStreamSynchronize hanging.
 // (600: round 5, tools/thread_cpu.py on the C4 share -- 5 workers 1.84 -> 1.78 busy CPUs at 284 -> 287 k files/s, 8 workers
 // 1.99 -> 1.90; 1 000 us starts to cost throughput with few workers)
-#ifndef AFX_X_NAP_CEILING
-#define AFX_X_NAP_CEILING 600
-#endif
-constexpr int kNapCeilingUs = AFX_X_NAP_CEILING;
+constexpr int kNapCeilingUs = 600;
 hipError_t wait_for_event(Workspace* ws, hipEvent_t ev) {
   if (!ws->blocking) return hipEventSynchronize(ev);
   // naps grow from 20 us to kNapCeilingUs: what a crawl waits for takes milliseconds (an upload 1.6 ms, a batch's

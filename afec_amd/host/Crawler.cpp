@@ -308,7 +308,8 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   double PhaseCpuSeconds[3] = {0, 0, 0};   // CPU time of the threads: workers parse + staging, workers GPU round trip, writer
   std::mutex StatMutex;
   TBoundedQueue Queue((size_t)(2 * G * W));
-  std::atomic<bool> Abort(false);
+  std::atomic<bool> Abort(false);      // an error ends the crawl: nothing more is analysed or written
+  std::atomic<bool> Stopped(false);    // TCrawlOptions::mpAbortRequested: no new batches; what was analysed is written
   std::string FirstError;
 
   // ---- one batch on the GPU, with the reference's failure semantics (SampleAnalyser.cpp:368-408: a file that cannot
@@ -499,6 +500,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
       TPinned& Staging = *Lease.mp;
       for (;;) {
         if (Abort) return;
+        if (Options.mpAbortRequested && Options.mpAbortRequested->load()) { Stopped = true; return; }
         // the next FilesPerBatch files of the shard, or fewer when their bytes reach the batch's budget (long files:
         // the staging buffer, the device workspace and the result buffers all scale with the PCM of a batch)
         size_t Begin, End;
@@ -652,6 +654,7 @@ TCrawlStatistics TCrawler::Crawl(const std::vector<TCrawlFile>& Files, const TCr
   Writer.join();
   Total.mSeconds = Now() - Start;
   Total.mCpuSeconds = ProcessCpuSeconds() - CpuStart;
+  Total.mAborted = Stopped.load();
   if (std::getenv("AFEC_CRAWL_TIMING"))
     std::fprintf(stderr, "[afec crawl] %.1f ms wall; worker time summed over %d workers: parse + staging %.1f ms, GPU round trip %.1f ms\n",
                  Total.mSeconds * 1e3, G * W, PhaseSeconds[0] * 1e3, PhaseSeconds[1] * 1e3);
@@ -689,7 +692,9 @@ std::atomic<bool> gResample(true);
 std::atomic<int> gTestFailBatch(-1), gTestFailAttempts(0), gTestDeviceLost(0);
 std::atomic<int64_t> gDeviceBytesPerBatch(0);
 std::atomic<int> gFrameKernel(-1);   // afec_crawl_set_frame_kernel: -1 = TCrawlOptions' default
+std::atomic<bool> gAbortRequested(false);   // afec_crawl_request_abort
 }  // namespace
+extern "C" void afec_crawl_request_abort(void) { gAbortRequested = true; }
 extern "C" void afec_crawl_set_frame_kernel(int32_t frame_kernel) { gFrameKernel = frame_kernel; }
 extern "C" void afec_crawl_set_test_fault(int32_t batch, int32_t attempts, int32_t device_lost) {
   gTestFailBatch = batch; gTestFailAttempts = attempts; gTestDeviceLost = device_lost;
@@ -733,6 +738,7 @@ extern "C" int afec_crawl_wave_images_ex(const char* const* names, const void* c
     if (gDeviceBytesPerBatch > 0) Options.mDeviceBytesPerBatch = gDeviceBytesPerBatch;
     if (gFrameKernel >= 0) Options.mFrameKernel = gFrameKernel;
     Options.mRowDigests = row_digests != nullptr;
+    Options.mpAbortRequested = &gAbortRequested;
     {
       std::lock_guard<std::mutex> Lock(gPragmaMutex);
       Options.mDatabasePragmas = gDatabasePragmas;
@@ -741,6 +747,7 @@ extern "C" int afec_crawl_wave_images_ex(const char* const* names, const void* c
     // (the registry lock is held for the whole crawl: afec_crawl_release cannot delete a crawler that is in use, and
     // crawls through this entry point run one at a time)
     std::lock_guard<std::mutex> Lock(gCrawlerMutex);
+    gAbortRequested = false;
     afec::TCrawler* pCrawler = nullptr;
     {
       std::string Key;

@@ -16,6 +16,7 @@
 //     into the reference's `assets` table (TSqliteSampleDescriptorPool) -- or just counts them.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -82,6 +83,11 @@ struct TCrawlOptions {
   // (per-frame records, statistics, rhythm results, LoadSample's facts), computed by the worker that analysed its batch.
   // For checks that the same content gives the same row whichever device / batch it landed on (bench.py's sharded crawl)
   bool mRowDigests = false;
+  // Set from outside (another thread, a signal handler) to end the crawl early -- the reference's sAbortProcessing, which
+  // its SIGINT handler sets and every task checks before it starts (Crawler.cpp:69-73, 717-720).  Workers take no new batch
+  // once it reads true; batches already analysed are delivered and written whole, the crawl returns normally with
+  // TCrawlStatistics::mAborted set and mFiles counting what was done.  nullptr: the crawl cannot be aborted from outside.
+  const std::atomic<bool>* mpAbortRequested = nullptr;
 };
 
 // CPUs the process may use at once: the cgroup CPU bandwidth quota (v2 cpu.max, v1 cfs_quota_us / cfs_period_us) where
@@ -105,6 +111,7 @@ struct TCrawlStatistics {
   int mWorkersPerDevice = 0;                 // the worker threads per device the crawl ran with
   double mUsableHostCpus = 0;                // UsableHostCpus() when the crawl started
   std::vector<uint64_t> mRowDigests;         // TCrawlOptions::mRowDigests: [file], 0 for files that were not analysed
+  bool mAborted = false;                     // TCrawlOptions::mpAbortRequested became true before every file was taken
   double mCpuSeconds = 0;           // CPU time the process spent during the crawl (all threads): mCpuSeconds / mSeconds = busy CPUs
   // GPU_MAX_HW_QUEUES as the environment had it when the crawler was built (0: unset).  The HIP runtime reads it at its
   // first call: when the process had used HIP before, a value set here came too late (175-205 k instead of 268 k files/s)
@@ -173,6 +180,9 @@ int afec_wave_probe_file(const char* path, int64_t* props /* [7] */, void* paylo
                          int32_t error_size);
 int afec_shard_of_file(int64_t file_index, int32_t n_devices);
 void afec_crawl_release(void);
+// ends the crawl that is running through afec_crawl_wave_images / _ex early (TCrawlOptions::mpAbortRequested; the
+// reference's SIGINT handler, Crawler.cpp:69-73): safe from another thread or a signal handler; cleared when a crawl starts
+void afec_crawl_request_abort(void);
 // TCrawlOptions::mBytesPerBatch of the crawls that follow (0: the default)
 void afec_crawl_set_bytes_per_batch(int64_t bytes);
 // TCrawlOptions::mDatabasePragmas of the crawls that follow (NULL or "": none)

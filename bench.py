@@ -208,8 +208,8 @@ def make_buffers(n_buffers, seed):
 
 
 class ClockProbe:
-    """tools/clock_probe: one wave on a stream of its own samples s_memtime / s_memrealtime every ~25 us while the timed
-    launches run; stop() -> {"clock_ghz", "min_ghz_1ms", "max_ghz_1ms", "samples", "seconds", "ended_by"} or None."""
+    """tools/clock_probe: one wave on a stream of its own samples s_memtime / s_memrealtime every ~25 us while launches
+    run; stop() -> {"clock_ghz", "min_ghz_1ms", "max_ghz_1ms", "samples", "seconds", "ended_by"} or None."""
 
     def __init__(self, device, max_seconds):
         import ctypes
@@ -239,23 +239,29 @@ class ClockProbe:
         if rc != 0:
             return None
         return {"clock_ghz": out[0], "min_ghz_1ms": out[1], "max_ghz_1ms": out[2], "samples": int(out[3]), "seconds": out[4],
-                "ended_by": {1: "stop", 2: "its own time limit"}.get(int(out[5]), "?"), "wall_clock_khz": out[6],
-                "how": "one wave on its own stream, s_memtime / s_memrealtime every ~25 us during the timed launches (tools/clock_probe)"}
+                "ended_by": {1: "stop", 2: "its own time limit"}.get(int(out[5]), "?"), "wall_clock_khz": out[6]}
 
 
-def timed_with_clock(run, device, expect_seconds, use_probe=True):
-    """run() (the timed launches; returns its own result) with the clock probe beside it -> (result, clock or None).  The
-    probe ends on its own after 4 x the expected time + 0.5 s; if it did -- the launches may have queued behind it on a
-    shared hardware queue -- the timing is taken again without it and the clock is not reported."""
-    if not use_probe:
-        return run(), None
+def clock_during(run, device, expect_seconds):
+    """The shader clock the device sustains under run() -- a REPEAT of launches that have just been timed, in the same
+    process, seconds later -- sampled by the probe wave beside them.  Not during the timed region itself: the f64 frame
+    kernels fill every SIMD's register file (two waves of 256 VGPRs), so the resident probe wave displaces one
+    workgroup of the persistent grid and the pass with it runs ~4 % slower (measured: 490 against 512 M frames/s,
+    profiles/r06/clock_probe_cost.txt); the load, and with it the clock, is the same but for that one workgroup in 256.
+    -> (clock dict or None, milliseconds run() reported).  A probe that ran into its own time limit (its stream shared a
+    hardware queue with the launches, which then waited for it) is reported as no clock."""
     probe = ClockProbe(device, min(20.0, 4.0 * expect_seconds + 0.5))
-    result = run()
+    ms = run()
     clock = probe.stop()
     if clock is not None and clock["ended_by"] != "stop":
-        print("warning: the clock probe ran into its time limit; timing repeated without it", file=sys.stderr)
-        return run(), None
-    return result, clock
+        print("warning: the clock probe ran into its time limit (a shared hardware queue): no clock for this measurement", file=sys.stderr)
+        clock = None
+    if clock is not None:
+        clock["how"] = ("one wave on its own stream, s_memtime / s_memrealtime every ~25 us (tools/clock_probe) during a repeat of the timed "
+                        "launches right after them; the probe wave displaces one workgroup of the persistent grid, so it is not resident "
+                        "during the timed region itself")
+        clock["ms_per_pass_with_the_probe_resident"] = ms
+    return clock, ms
 
 
 def make_c3_files(n_files, seed):
@@ -676,8 +682,9 @@ def chain_rate(plan, workload, n_files, seed, mask_name="frame", batch_files=0, 
     est = batch.run_timed(2) / 2
     batch.run_timed(max(3, int(40.0 / est) + 1))          # the clocks settle within ~30 ms of load (profiles/r03/clock_ramp.txt)
     steps = max(10, int(100.0 / est) + 1)
-    total_ms, clock_seen = timed_with_clock(lambda: batch.run_timed(steps), device, steps * est * 1e-3, use_probe=clock)
-    ms = total_ms / steps
+    ms = batch.run_timed(steps) / steps
+    # (BatchSet: dozens of streams share the runtime's 16 hardware queues with the probe's -- its launches would wait for it)
+    clock_seen = clock_during(lambda: batch.run_timed(steps), device, steps * est * 1e-3)[0] if (clock and batch_files == 0) else None
     rate = frames / (ms * 1e-3)
     info = batch.info()
     try:
@@ -706,7 +713,7 @@ def chain_rate(plan, workload, n_files, seed, mask_name="frame", batch_files=0, 
         ceiling = 4 * 256 * ghz * 1e9 / prof["valu_cycles_per_frame"]
         out.update(traffic_ratio=prof["bytes_per_frame"] / SURVEY_C3_BYTES_PER_FRAME, valu_frac=rate / ceiling,
                    valu_frac_at_nominal_clock=rate / (4 * 256 * NOMINAL_CLOCK_GHZ * 1e9 / prof["valu_cycles_per_frame"]),
-                   valu_ceiling_frames_s=ceiling, valu_clock="sampled in this run" if clock_seen else "the profiled run's",
+                   valu_ceiling_frames_s=ceiling, valu_clock="sampled in this run (a repeat of the timed launches)" if clock_seen else "the profiled run's",
                    kernels_ms=prof.get("kernel_ms_per_step"), profile=prof["source"])
     return out
 
@@ -823,28 +830,20 @@ def main():
         batch.run()
     batch.sync()
     step_estimate_s = (time.perf_counter() - tw0) / args.warmup if args.warmup > 0 else 1.0
-    # the shader clock is sampled WHILE the timed launches run (one wave on a stream of its own, resident before the
-    # first launch): the VALU ceiling of the roofline object is priced at the clock of this very run
-    use_probe = not args.no_clock_probe
-
-    def timed_region(with_probe):
-        probe = ClockProbe(device, min(20.0, 4.0 * step_estimate_s * args.steps + 0.5)) if with_probe else None
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    ev_ms = batch.run_timed(args.steps)   # K launches bracketed by HIP events on the launch stream; syncs
+    t1 = time.perf_counter()
+    if dist is not None:
+        dist.barrier()
+    # the shader clock under this load, sampled in this very process during a repeat of the K launches (clock_during says
+    # why not during the timed region itself): the VALU ceiling of the roofline object is priced at the clock of this run
+    clock = None
+    if not args.no_clock_probe and not isinstance(batch, BatchSet):
+        clock = clock_during(lambda: batch.run_timed(args.steps), device, step_estimate_s * args.steps)[0]
         if dist is not None:
             dist.barrier()
-        t0 = time.perf_counter()
-        ms = batch.run_timed(args.steps)   # K launches bracketed by HIP events on the launch stream; syncs
-        t1 = time.perf_counter()
-        seen = probe.stop() if probe is not None else None
-        if dist is not None:
-            dist.barrier()
-        return t0, t1, ms, seen
-    t0, t1, ev_ms, clock = timed_region(use_probe)
-    # a probe that ran into its own time limit may have held the launches up (a shared hardware queue): every rank then
-    # times again without it, and no clock is reported
-    probe_expired = 1.0 if (clock is not None and clock["ended_by"] != "stop") else 0.0
-    if use_probe and reduce_max_sum(dist, probe_expired, 0)[0] > 0:
-        print("warning: the clock probe ran into its time limit; the timed region is repeated without it", file=sys.stderr)
-        t0, t1, ev_ms, clock = timed_region(False)
     seconds, frames_all = reduce_max_sum(dist, t1 - t0, frames)
     per_rank = gather_ranks(dist, {"rank": rank, "device": device, "ms_per_step": (t1 - t0) / args.steps * 1e3,
                                    "kernel_ms_per_step": ev_ms / args.steps, "frames": frames,
@@ -908,13 +907,13 @@ def main():
     c3_chain = c4_chain = c3_spectral = c4_crawler = None
     if secondaries and not args.no_chain_rates:
         try:
-            c3_chain = chain_rate(plan, "c3", 1000, 4321, device=device, clock=use_probe)
-            c3_spectral = chain_rate(plan, "c3", 1000, 4321, mask_name="all", device=device, clock=use_probe)
-            c4_chain = chain_rate(plan, "c4", 12500, 4321, device=device, clock=use_probe)
+            c3_chain = chain_rate(plan, "c3", 1000, 4321, device=device, clock=not args.no_clock_probe)
+            c3_spectral = chain_rate(plan, "c3", 1000, 4321, mask_name="all", device=device, clock=not args.no_clock_probe)
+            c4_chain = chain_rate(plan, "c4", 12500, 4321, device=device, clock=not args.no_clock_probe)
             crawler_plan = open_plan(device, local, world, precision=precision, max_analysis_ms=20000,
                                      frame_kernel=afx.FRAME_KERNEL_WAVE64)     # TSampleAnalyser's plan (afec_amd/host/Crawler.h)
             try:
-                c4_crawler = chain_rate(crawler_plan, "c4", 12500, 4321, batch_files=512, in_flight=5, device=device, clock=use_probe)
+                c4_crawler = chain_rate(crawler_plan, "c4", 12500, 4321, batch_files=512, in_flight=5, device=device, clock=not args.no_clock_probe)
             finally:
                 crawler_plan.close()
         except Exception as e:  # noqa: BLE001
@@ -1009,7 +1008,7 @@ def main():
             ceiling = 4 * 256 * ghz * 1e9 / prof["valu_cycles_per_frame"]
             nominal = 4 * 256 * NOMINAL_CLOCK_GHZ * 1e9 / prof["valu_cycles_per_frame"]
             valu = {"cycles_per_frame": prof["valu_cycles_per_frame"], "instructions_per_frame": prof["valu_instructions_per_frame"],
-                    "clock_ghz": ghz, "clock_source": "sampled during the timed launches of this run (tools/clock_probe)" if clock
+                    "clock_ghz": ghz, "clock_source": "sampled in this run, during a repeat of the timed launches (tools/clock_probe)" if clock
                     else "GRBM_GUI_ACTIVE of the profiled run (no probe in this run)",
                     "clock_ghz_profiled_run": prof["clock_ghz"], "ceiling_frames_s": ceiling, "frac": rate / ceiling,
                     "nominal_clock_ghz": NOMINAL_CLOCK_GHZ, "ceiling_frames_s_at_nominal_clock": nominal,

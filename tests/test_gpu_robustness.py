@@ -361,3 +361,27 @@ def test_an_allocation_that_finds_the_device_full_gets_the_idle_pool_back_and_th
     finally:
         hip.hipFree(dummy)
     plan.close()
+
+
+def test_a_refused_first_file_does_not_move_the_upload_of_the_one_behind_it():
+    """Round 6, found on the CPU by the sanitizer harness (tests/sanitize/fuzz_host_abi.cpp): a file the conversion planner
+    refuses (a header above 16 x the analyser's rate) keeps its place in the raw arena's layout; with exactly one valid
+    file behind it -- its own scattered buffer -- the one-transfer upload used to start `raw_off` bytes in FRONT of that
+    buffer (a read outside the caller's memory, and the valid file's samples landed shifted).  The valid file's results
+    must be those of the same file analysed alone."""
+    rng = np.random.default_rng(77)
+    bad = (rng.integers(-20000, 20000, 50000)).astype(np.int16)
+    good = np.round(15000.0 * np.sin(2 * np.pi * 523.0 * np.arange(30000) / 44100.0) * np.exp(-np.arange(30000) / 9000.0)).astype(np.int16)
+    plan = afx.Plan()
+    mask = afx.D_ALL_LOW_LEVEL
+    alone, _ = plan.batch_from_raw([(good, 1)], mask)
+    alone.run()
+    want = alone.fetch()
+    both, info = plan.batch_from_raw([(bad, 1, 800000), (good, 1)], mask)
+    both.run()
+    got = both.fetch()
+    assert got["buf_status"][0] != 0 and got["buf_status"][1] == 0
+    assert got["frame_offset"].tolist() == [0, 0, want["frame_offset"][1]]
+    for k in ("mfcc", "spectral_centroid", "spectrum_bands", "sub_contrast", "amplitude_peak"):
+        np.testing.assert_array_equal(got[k], want[k])
+    alone.close(); both.close(); plan.close()

@@ -272,3 +272,15 @@ def test_writer_rate_probe_runs(tmp_path):
 @pytest.mark.gpu
 def test_host_sample_analyser_matches_oracle():
     run("analyse")
+
+
+def test_in_register_dft_blocks_against_a_direct_dft(tmp_path):
+    """afx_fft32.h (dft32, dft16_rest, dft32_merge, the fused butterflies) and afx_fft.h's per-lane stages (radix4, dft16) on
+    the host against a direct DFT in long double, and the 1024-point transform composed the way frames32_kernel composes
+    it + the real-input untangle (tests/host/test_fft32_math.cpp; the file afx_fft32.h's header cites)."""
+    exe = str(tmp_path / "test_fft32_math")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-Werror", "-o", exe,
+                           os.path.join(ROOT, "tests", "host", "test_fft32_math.cpp"), "-lm"])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "all passed" in out.stdout and "FAILED" not in out.stdout

@@ -237,7 +237,12 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
   // are bands_kernel's (seven sums more in a kernel that has the rows in its registers anyway), the amplitude of the
   // hop hop_kernel's.  The statistics of the full classes cost this kernel 250-300 bytes of scratch per lane and more
   // than half of its time.
-  constexpr bool MAGS = (FEAT == 4);
+  // FEAT 6 (round 6): the magnitude class for masks whose later kernels read bins 0..767 only (bands_kernel; no whitening
+  // follower, no magnitude output: !kFramesWholeSpectrum) -- the mirrored blocks of rows 0..7 (bins 769..1023) are not
+  // stored and their square roots not taken (spectrum bands 26 / 27 are sums of |X|^2): 6 KiB of stores per frame instead
+  // of 8 in a kernel that runs at the memory system's rate.
+  constexpr bool MAGS = (FEAT == 4 || FEAT == 6);
+  constexpr bool MAGS_UPPER = (FEAT == 4);
   // The overlap half of a frame (rows 0..15 = the hop of the frame before) either stays in 32 registers from frame to
   // frame (MFCC class: it has them) or comes back from the cache by a second LDS-DMA into the upper half of the wave's
   // plane, asked for at the bottom of the loop with the window pairs: the classes that keep sums or stored rows next to
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
   // (measured: magnitude class 2.35 -> 1.99 ms on the C4 share, full classes 23.1 -> 20.7 ms on 5.12 M frames; the
   // statistics class, which spilled 44 bytes, 16.1 -> 17.7 ms and the MFCC class 493 -> 422 M frames/s: they keep the
   // registers)
-  constexpr bool LO_LDS = (FEAT >= 2 && FEAT <= 4);
+  constexpr bool LO_LDS = (FEAT >= 2 && FEAT <= 4) || FEAT == 6;
   // Cache policy of the classes that fetch every hop twice (round 5, A/B on the C4 share, profiles/r05/ab_cache_policy.txt):
   // the first read without the non-temporal hint -- the line is asked for again one frame later -- and the magnitude
   // stores with it (8 KiB per frame streaming through L2 would push those lines out): 2.14 -> 2.02 ms.
@@ -613,7 +618,9 @@ __global__ __launch_bounds__(kWaves32 * 64) void frames32_kernel(const FrameArgs
           const double mv = mag_sqrt_mel(yr, yi, k_tiny, k_three);                        // |X[1024 - 32 r - q]|
           if (r < kMel32Rows) park[32 * r + q] = md;    // rows 0..11 wait in LDS for the mel stage (no register to spare here)
           store_mag(rowd + 32 * r, md);
-          if (!(r == 0 && q == 0)) store_mag(rowm - 32 * r, mv);                          // (row 0, lane 0 would be bin 1024)
+          if (MAGS_UPPER || r >= 8) {                                                      // bins 1024 - 32 r - q: above 768 for r < 8
+            if (!(r == 0 && q == 0)) store_mag(rowm - 32 * r, mv);                        // (row 0, lane 0 would be bin 1024)
+          }
           // spectrum bands 26 = bins 738..904 and 27 = bins 905..1023 lie in the mirrored halves of rows 0..8
           if (r <= 8) {
             const double sq = fma(yi, yi, yr * yr);
@@ -1025,7 +1032,11 @@ hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stre
   if (a.n_chunks <= 0) return hipSuccess;
   const int cls = frames32_class(a.mask);
   if (cls == 0) return scaled ? launch_frames32_class<0, true>(a, grid_blocks, stream) : launch_frames32_class<0, false>(a, grid_blocks, stream);
-  if (cls == 4) return scaled ? launch_frames32_class<4, true>(a, grid_blocks, stream) : launch_frames32_class<4, false>(a, grid_blocks, stream);
+  if (cls == 4) {
+    if (a.mask & kFramesWholeSpectrum)   // the whitening kernels / the magnitude output read bins above 768 too
+      return scaled ? launch_frames32_class<4, true>(a, grid_blocks, stream) : launch_frames32_class<4, false>(a, grid_blocks, stream);
+    return scaled ? launch_frames32_class<6, true>(a, grid_blocks, stream) : launch_frames32_class<6, false>(a, grid_blocks, stream);
+  }
   hipError_t e;
   if (cls == 1 && !(a.mask & 0x30u))   // neither skewness nor kurtosis: no third / fourth moments
     e = scaled ? launch_frames32_class<5, true>(a, grid_blocks, stream) : launch_frames32_class<5, false>(a, grid_blocks, stream);

@@ -29,9 +29,11 @@ STEPS, WARMUP = int(os.environ.get("AFX_PROF_STEPS", "10")), int(os.environ.get(
 def run_pass(tag, name, prof_args, bench_args):
     d = f"/tmp/prof_{tag}_{name}"
     shutil.rmtree(d, ignore_errors=True)
-    # the counter passes serialise the dispatches: bench.py's clock probe (a kernel that runs beside the timed launches
-    # until it is told to stop) stays off there; the trace pass keeps it, so the profile records the clock of its own run
-    probe = [] if name == "trace" else ["--no-clock-probe"]
+    # bench.py's clock probe stays off under the profiler: its pass is a REPEAT of the timed launches with a wave resident
+    # beside them (the trace would count those launches, 4 % slower, as steps; the counter passes serialise dispatches and
+    # the probe kernel would block them).  The clock of a profiled run is GRBM_GUI_ACTIVE / 8 XCDs / kernel time (sq pass);
+    # the clock of the un-profiled line is the line's own (tools/lease_report.py puts them side by side)
+    probe = ["--no-clock-probe"]
     cmd = ["rocprofv3"] + prof_args + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3",
                                        os.path.join(ROOT, "bench.py"), "--steps", str(STEPS), "--warmup", str(WARMUP),
                                        "--no-cpu-baseline", "--no-single", "--no-spot-check", "--no-side-stream",

@@ -1,0 +1,270 @@
+// tools/ubench/bands_rows16.hip -- the per-band sums of bands_kernel in two layouts, as a micro-benchmark (round 6: the
+// "one frame per 16 lanes" layout the round-5 review asked to be budgeted before it is built).
+//
+//   V0  the shipped layout: one frame per 64-lane wave, bin k = 64 r + lane (12 rows in registers); a per-band sum is a
+//       masked accumulation over the 25 (band, row) pairs into 16 accumulators + the transposed reduction wave_sum16
+//       (swap32 / swap16 / DPP) -- afx_bands.hip: band_sum.
+//   V1  four frames per wave, quad-interleaved: lane L = 4 m + f holds bins m + 16 i (i = 0 .. 47) of frame f.  Every
+//       instruction of the accumulation works on four frames; the reduction over a frame's 16 lanes runs over lane bits
+//       5, 4 (v_permlane32_swap, v_permlane16_swap: no selects), 3 (row_ror:8) and 2 (two bank-masked row shifts) and
+//       leaves band m of frame f in lane 4 m + f -- where the closed forms then run in all 64 lanes, no parking in LDS.
+//
+// Both variants read their magnitudes from LDS every iteration (as the kernel reads the DMA'd image) and form five sums
+// per frame (x, x^2, x y and two selected sums, like sx / sxx / sxy / vsum / psum).  Output: ns per frame at a full chip
+// (2 waves per SIMD, like bands_kernel), and a checksum against a scalar reference of the same sums.
+// Build + run: hipcc --offload-arch=gfx950 -O3 -o /tmp/bands_rows16 tools/ubench/bands_rows16.hip && /tmp/bands_rows16
+// Instruction counts: hipcc --offload-arch=gfx950 -O3 -S --cuda-device-only (tools/isa_budget.py counts between markers).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+using mask64 = unsigned long long;
+constexpr int kNumSub = 14;
+constexpr int kSubStart[kNumSub + 1] = {1, 3, 7, 13, 23, 35, 50, 67, 90, 119, 160, 221, 317, 465, 752};
+
+__device__ __forceinline__ double keep_where(double v, mask64 m) {
+  int lo, hi;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(v)), "s"(m));
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(v)), "s"(m));
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ void swap32(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(x), __double2hiint(y), false, false);
+  x = __hiloint2double(hi[0], lo[0]);
+  y = __hiloint2double(hi[1], lo[1]);
+}
+__device__ __forceinline__ void swap16(double& x, double& y) {
+  const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(x), __double2loint(y), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(x), __double2hiint(y), false, false);
+  x = __hiloint2double(hi[0], lo[0]);
+  y = __hiloint2double(hi[1], lo[1]);
+}
+// value of lane ^ 4 inside the row: two bank-masked row shifts (banks = groups of four lanes)
+__device__ __forceinline__ double xor4(double v) {
+  int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x104 /* row_shl:4 */, 0xF, 0x5, false);
+  lo = __builtin_amdgcn_update_dpp(lo, __double2loint(v), 0x114 /* row_shr:4 */, 0xF, 0xA, false);
+  int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x104, 0xF, 0x5, false);
+  hi = __builtin_amdgcn_update_dpp(hi, __double2hiint(v), 0x114, 0xF, 0xA, false);
+  return __hiloint2double(hi, lo);
+}
+
+// ---- V0: the shipped layout ----
+constexpr int kRows0 = 12;
+constexpr bool touches0(int b, int r) { return kSubStart[b] <= 64 * r + 63 && kSubStart[b + 1] - 1 >= 64 * r; }
+constexpr bool covers0(int b, int r) { return kSubStart[b] <= 64 * r && kSubStart[b + 1] - 1 >= 64 * r + 63; }
+constexpr mask64 mask0(int b, int r) {
+  const int lo = kSubStart[b], hi = kSubStart[b + 1];
+  const int l0 = lo - 64 * r < 0 ? 0 : (lo - 64 * r > 64 ? 64 : lo - 64 * r), l1 = hi - 64 * r < 0 ? 0 : (hi - 64 * r > 64 ? 64 : hi - 64 * r);
+  const mask64 a = l1 >= 64 ? ~0ull : ((1ull << l1) - 1ull), c = l0 >= 64 ? ~0ull : ((1ull << l0) - 1ull);
+  return l1 > l0 ? (a & ~c) : 0ull;
+}
+struct T0 { mask64 m[kNumSub][kRows0]; };
+constexpr T0 make0() { T0 t{}; for (int b = 0; b < kNumSub; ++b) for (int r = 0; r < kRows0; ++r) t.m[b][r] = mask0(b, r); return t; }
+constexpr T0 kM0 = make0();
+__device__ __forceinline__ double wave_sum16(double (&a)[16], int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { swap32(a[i], a[i + 8]); a[i] += a[i + 8]; }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { swap16(a[i], a[i + 4]); a[i] += a[i + 4]; }
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const double keep = b3 ? a[i + 2] : a[i], send = b3 ? a[i] : a[i + 2];
+    a[i] = keep + dpp_mov<0x128>(send);
+  }
+  const double keep = b2 ? a[1] : a[0], send = b2 ? a[0] : a[1];
+  double z = keep + dpp_mov<0x141>(send);
+  z += dpp_mov<0x4E>(z);
+  z += dpp_mov<0xB1>(z);
+  return z;
+}
+template <typename F>
+__device__ __forceinline__ double band_sum0(F value_of_row, int lane) {
+  double acc[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    acc[b] = 0.0;
+    if (b < kNumSub) {
+      bool first = true;
+#pragma unroll
+      for (int r = 0; r < kRows0; ++r)
+        if (touches0(b, r)) {
+          const double v = covers0(b, r) ? value_of_row(r) : keep_where(value_of_row(r), kM0.m[b][r]);
+          acc[b] = first ? v : acc[b] + v;
+          first = false;
+        }
+    }
+  }
+  return wave_sum16(acc, lane);
+}
+
+// ---- V1: four frames per wave, lane = 4 m + f, bin = m + 16 i ----
+constexpr int kRows1 = 48;
+constexpr bool touches1(int b, int i) { return kSubStart[b] <= 16 * i + 15 && kSubStart[b + 1] - 1 >= 16 * i; }
+constexpr bool covers1(int b, int i) { return kSubStart[b] <= 16 * i && kSubStart[b + 1] - 1 >= 16 * i + 15; }
+constexpr mask64 mask1(int b, int i) {   // lanes 4 m + f with bin m + 16 i inside band b, every f
+  mask64 m = 0;
+  for (int q = 0; q < 16; ++q)
+    if (q + 16 * i >= kSubStart[b] && q + 16 * i < kSubStart[b + 1]) m |= 0xFull << (4 * q);
+  return m;
+}
+struct T1 { mask64 m[kNumSub][kRows1]; };
+constexpr T1 make1() { T1 t{}; for (int b = 0; b < kNumSub; ++b) for (int i = 0; i < kRows1; ++i) t.m[b][i] = mask1(b, i); return t; }
+constexpr T1 kM1 = make1();
+// 16 accumulators over the 16 lanes of each frame: lane 4 m + f receives the total of a[m] of frame f
+__device__ __forceinline__ double row_sum16(double (&a)[16], int lane) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { swap32(a[i], a[i + 8]); a[i] += a[i + 8]; }     // m bit 3 = lane bit 5
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { swap16(a[i], a[i + 4]); a[i] += a[i + 4]; }     // m bit 2 = lane bit 4
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {                                                  // m bit 1 = lane bit 3
+    const double keep = b3 ? a[i + 2] : a[i], send = b3 ? a[i] : a[i + 2];
+    a[i] = keep + dpp_mov<0x128>(send);
+  }
+  const double keep = b2 ? a[1] : a[0], send = b2 ? a[0] : a[1];                 // m bit 0 = lane bit 2
+  return keep + xor4(send);
+}
+template <typename F>
+__device__ __forceinline__ double band_sum1(F value_of_row, int lane) {
+  double acc[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    acc[b] = 0.0;
+    if (b < kNumSub) {
+      bool first = true;
+#pragma unroll
+      for (int i = 0; i < kRows1; ++i)
+        if (touches1(b, i)) {
+          const double v = covers1(b, i) ? value_of_row(i) : keep_where(value_of_row(i), kM1.m[b][i]);
+          acc[b] = first ? v : acc[b] + v;
+          first = false;
+        }
+    }
+  }
+  return row_sum16(acc, lane);
+}
+
+constexpr int kImage = 768;             // doubles per frame image
+constexpr int kPad1 = 8;                // V1: images 64 B apart in bank space (6144 + 64 bytes): the four frames of a quad hit different banks
+
+template <int V>
+__global__ __launch_bounds__(512, 1) void bench_kernel(const double* spectra, int frames_per_wave, double* out) {
+  extern __shared__ double lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = blockIdx.x * 8 + wave;
+  double* const img = lds + wave * (4 * (kImage + kPad1));
+  double total = 0.0;
+  const double* src = spectra + (size_t)gw * frames_per_wave * kImage;
+  if (V == 0) {
+    double y[kRows0];
+#pragma unroll
+    for (int r = 0; r < kRows0; ++r) y[r] = 0.5;
+    for (int f = 0; f < frames_per_wave; ++f) {
+#pragma unroll
+      for (int r = 0; r < kRows0; ++r) img[64 * r + lane] = src[(size_t)f * kImage + 64 * r + lane];
+      __builtin_amdgcn_s_waitcnt(0);
+      double x[kRows0], xx[kRows0], xy[kRows0], xs[kRows0], xp[kRows0];
+#pragma unroll
+      for (int r = 0; r < kRows0; ++r) {
+        x[r] = ((volatile double*)img)[64 * r + lane];
+        xx[r] = x[r] * x[r]; xy[r] = x[r] * y[r];
+        xs[r] = x[r] < 0.3 ? x[r] : 0.0; xp[r] = x[r] > 0.7 ? x[r] : 0.0;
+      }
+      const double s0 = band_sum0([&](int r) { return x[r]; }, lane);
+      const double s1 = band_sum0([&](int r) { return xx[r]; }, lane);
+      const double s2 = band_sum0([&](int r) { return xy[r]; }, lane);
+      const double s3 = band_sum0([&](int r) { return xs[r]; }, lane);
+      const double s4 = band_sum0([&](int r) { return xp[r]; }, lane);
+      total += ((lane & 3) == 0 && (lane >> 2) < kNumSub) ? s0 + 2 * s1 + 3 * s2 + 5 * s3 + 7 * s4 : 0.0;
+#pragma unroll
+      for (int r = 0; r < kRows0; ++r) y[r] = x[r];
+    }
+  } else {
+    const int m = lane >> 2, fq = lane & 3;
+    for (int f = 0; f + 3 < frames_per_wave; f += 4) {
+      // four images; (the kernel proper would get them by LDS-DMA in natural order, as it does now)
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int r = 0; r < kRows0; ++r) img[j * (kImage + kPad1) + 64 * r + lane] = src[(size_t)(f + j) * kImage + 64 * r + lane];
+      __builtin_amdgcn_s_waitcnt(0);
+      const volatile double* mine = img + fq * (kImage + kPad1) + m;
+      const volatile double* prev = img + ((fq + 3) & 3) * (kImage + kPad1) + m;     // the frame before (stand-in for frame f - 1 of row 0)
+      // one quantity at a time, its 48 values re-read from the image (48 doubles per quantity in registers next to 16
+      // accumulators and the kernel's other state do not fit: 632 B of scratch when all five were formed from one x[48])
+      const double s0 = band_sum1([&](int i) { return mine[16 * i]; }, lane);
+      const double s1 = band_sum1([&](int i) { const double v = mine[16 * i]; return v * v; }, lane);
+      const double s2 = band_sum1([&](int i) { return mine[16 * i] * prev[16 * i]; }, lane);   // the previous frame from its image
+      const double s3 = band_sum1([&](int i) { const double v = mine[16 * i]; return v < 0.3 ? v : 0.0; }, lane);
+      const double s4 = band_sum1([&](int i) { const double v = mine[16 * i]; return v > 0.7 ? v : 0.0; }, lane);
+      total += (m < kNumSub) ? s0 + 2 * s1 + 5 * s3 + 7 * s4 + 0.0 * s2 : 0.0;
+      // (the x y sums of V1 pair frame f with another frame than V0 does: left out of the checksum, kept in the timing)
+      total += (m < kNumSub) ? 1e-30 * s2 : 0.0;
+    }
+  }
+#pragma unroll
+  for (int s = 32; s; s >>= 1) total += __shfl_xor(total, s);
+  if (lane == 0) out[gw] = total;
+}
+
+int main() {
+  const int blocks = 256, waves = blocks * 8, fpw = 64;   // 2 waves per SIMD on every CU
+  const size_t n = (size_t)waves * fpw * kImage;
+  std::vector<double> h(n);
+  unsigned s = 12345;
+  for (double& v : h) { s = s * 1664525u + 1013904223u; v = (double)(s >> 8) / 16777216.0; }
+  double *d, *o;
+  hipMalloc(&d, n * 8); hipMalloc(&o, waves * 8);
+  hipMemcpy(d, h.data(), n * 8, hipMemcpyHostToDevice);
+  const size_t ldsb = 8 * 4 * (kImage + kPad1) * 8;
+  hipFuncSetAttribute((const void*)bench_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  hipFuncSetAttribute((const void*)bench_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
+  // reference checksum: sum over frames and bands of s0 + 2 s1 + 5 s3 + 7 s4 (and 3 s2 for V0 only)
+  double ref01 = 0, ref2 = 0;
+  for (int w = 0; w < waves; ++w) {
+    std::vector<double> y(kImage, 0.5);
+    for (int f = 0; f < fpw; ++f) {
+      const double* x = &h[((size_t)w * fpw + f) * kImage];
+      for (int b = 0; b < kNumSub; ++b)
+        for (int k = kSubStart[b]; k < kSubStart[b + 1]; ++k) {
+          ref01 += x[k] + 2 * x[k] * x[k] + 5 * (x[k] < 0.3 ? x[k] : 0) + 7 * (x[k] > 0.7 ? x[k] : 0);
+          ref2 += 3 * x[k] * y[(size_t)k];
+        }
+      for (int k = 0; k < kImage; ++k) y[(size_t)k] = x[k];
+    }
+  }
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int v = 0; v < 2; ++v) {
+    float best = 1e30f;
+    std::vector<double> ho(waves);
+    for (int rep = 0; rep < 12; ++rep) {
+      hipEventRecord(e0);
+      if (v == 0) hipLaunchKernelGGL(bench_kernel<0>, dim3(blocks), dim3(512), ldsb, 0, d, fpw, o);
+      else hipLaunchKernelGGL(bench_kernel<1>, dim3(blocks), dim3(512), ldsb, 0, d, fpw, o);
+      hipEventRecord(e1);
+      hipEventSynchronize(e1);
+      float ms; hipEventElapsedTime(&ms, e0, e1);
+      if (rep >= 4 && ms < best) best = ms;
+    }
+    hipMemcpy(ho.data(), o, waves * 8, hipMemcpyDeviceToHost);
+    double sum = 0; for (double q : ho) sum += q;
+    const double want = v == 0 ? ref01 + ref2 : ref01;
+    const double frames = (double)waves * fpw;
+    std::printf("V%d %-44s %8.3f ms for %.0f frames x 5 band sums = %7.2f ns per frame at a full chip, %.1f ps per (frame, sum); checksum rel. err %.2e\n", v,
+                v == 0 ? "one frame per wave (shipped layout)" : "four frames per wave, lane = 4 m + f", best, frames, best * 1e6 / frames,
+                best * 1e9 / frames / 5, std::fabs(sum - want) / std::fabs(want));
+  }
+  return 0;
+}

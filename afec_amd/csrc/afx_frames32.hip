@@ -1033,7 +1033,12 @@ hipError_t launch_frames32(const FrameArgs& a, int grid_blocks, hipStream_t stre
   const int cls = frames32_class(a.mask);
   if (cls == 0) return scaled ? launch_frames32_class<0, true>(a, grid_blocks, stream) : launch_frames32_class<0, false>(a, grid_blocks, stream);
   if (cls == 4) {
-    if (a.mask & kFramesWholeSpectrum)   // the whitening kernels / the magnitude output read bins above 768 too
+    // Class 6 (no upper spectrum) where nobody reads bins above 768 -- and where it was measured to pay: batches of 160 000
+    // frames and more (C4-shaped files: -5 % at 160 k frames, -7 % from 320 k to 5.12 M).  The 82 000 frames of BASELINE's C3
+    // (1 000 two-second files) run 15 % SLOWER on it and 80 000 frames of one-second files 3 % faster (not understood:
+    // profiles/r06/ab_class6.txt); the stored values are the same either way, so the choice is free.
+    constexpr int64_t kClass6Frames = 131072;
+    if ((a.mask & kFramesWholeSpectrum) || total_frames < kClass6Frames)
       return scaled ? launch_frames32_class<4, true>(a, grid_blocks, stream) : launch_frames32_class<4, false>(a, grid_blocks, stream);
     return scaled ? launch_frames32_class<6, true>(a, grid_blocks, stream) : launch_frames32_class<6, false>(a, grid_blocks, stream);
   }

@@ -939,7 +939,7 @@ def main():
                    "workers": W, "files_per_batch": 512}
             # the same crawl with the single writer inserting every file into the reference's sqlite `assets` table
             # (461 columns, ~68 KB of msgpack per one-second file; one transaction per batch of 512 files), database on
-            # tmpfs: the writer, not the GPU, bounds it (DESIGN.md section 7)
+            # tmpfs: the writer, not the GPU, bounds it (DESIGN.md section 6)
             shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
             with tempfile.TemporaryDirectory(dir=shm) as td:
                 sd = end_to_end("c4", 4096, device, W, 99, database=os.path.join(td, "afec-ll.db"), repeats=3, files_per_batch=512)

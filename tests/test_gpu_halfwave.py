@@ -204,7 +204,7 @@ def test_golden_full_class(forced, name):
     if not np.array_equal(x32.astype(np.float64), x):
         ref = Oracle().run(x32.astype(np.float64))
     got = forced.extract([x32], afx.D_ALL_LOW_LEVEL | afx.D_MAGNITUDE)
-    # ill-conditioned by construction (DESIGN.md section 3, tests/test_gpu_parity.py): flux and the sub-band complexity /
+    # ill-conditioned by construction (DESIGN.md section 2, tests/test_gpu_parity.py): flux and the sub-band complexity /
     # flux of an exactly flat spectrum
     if name == "impulse":
         got = {k: v for k, v in got.items() if k not in ("sub_complexity", "sub_flux", "spectral_flux")}

@@ -84,7 +84,7 @@ def test_long_uncapped_buffer_head_and_tail():
 
 
 def test_pcie_inclusive_one_shot_rate_is_reported():
-    """DESIGN.md section 7 quotes the PCIe-inclusive afx_extract_batch rate; keep it measurable."""
+    """HISTORY.md section 7 quotes the PCIe-inclusive afx_extract_batch rate; keep it measurable."""
     rng = np.random.default_rng(43)
     x = rng.uniform(-1, 1, 2048 + 1024 * 9999).astype(np.float32)
     plan = afx.Plan(max_analysis_ms=0)

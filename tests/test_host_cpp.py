@@ -255,7 +255,7 @@ def test_descriptor_database_version_rules(tmp_path):
 
 def test_writer_rate_probe_runs(tmp_path):
     """`host_test writer_rate`: the database writer alone (no GPU), rows of a one-second stereo file; the numbers are
-    quoted in DESIGN.md section 7.  Here only that it runs and that batching the commits does not change the rows."""
+    quoted in HISTORY.md section 7.  Here only that it runs and that batching the commits does not change the rows."""
     import sqlite3
     build()
     dbs = []

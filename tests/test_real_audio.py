@@ -8,7 +8,7 @@ TEnvelopeDetector / TAutocorrelation neighbours, the onset STFT front end and au
 CPU: the host WAV reader and the oracle chain against those goldens.  GPU: the files crawled through
 afec::CrawlWaveFiles into the descriptor database, EVERY low-level column of every row compared -- per-frame series
 with the reference-generated goldens, per-file statistics with TStatistics::Calc's restatement on the golden series,
-rhythm columns with the oracle (its detector part is parity-unpinned, DESIGN.md section 3)."""
+rhythm columns with the oracle (its detector part is parity-unpinned, DESIGN.md section 2)."""
 import glob
 import os
 import sqlite3
@@ -23,7 +23,7 @@ from tests._wav import parse_wav
 HERE = os.path.dirname(__file__)
 WAV_DIR = os.path.join(HERE, "golden", "wav")
 GOLD = os.path.join(HERE, "golden", "real.npz")
-ORACLE_RTOL = 1e-6     # oracle vs reference objects: another FFT algorithm (DESIGN.md section 3)
+ORACLE_RTOL = 1e-6     # oracle vs reference objects: another FFT algorithm (DESIGN.md section 2)
 
 # C-ABI / oracle series name -> descriptor base name in the database (SampleDescriptors.cpp:150-205)
 SPECTRAL_DB = {"mfcc": "cepstrum_bands", "spectral_rms": "spectral_rms", "spectral_centroid": "spectral_centroid",

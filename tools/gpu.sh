@@ -1,6 +1,6 @@
 #!/bin/bash
 # One GPU-box script for the stages a round keeps repeating (replaces round 4's fifteen gpu_r04_[a-o].sh one-offs).
-# usage (from the repo root, normally under gpurun):  [AFX_ROUND=r05] bash tools/gpu.sh <stage> [<stage> ...]
+# usage (from the repo root, normally under gpurun):  [AFX_ROUND=r06] bash tools/gpu.sh <stage> [<stage> ...]
 #   tests[=<pytest args>]        the GPU suite (default: tests -m gpu)              -> $O/pytest_gpu.log
 #   record                       the GPU suite with AFX_TOL_RECORD: the worst relative error of every descriptor over every
 #                                check_gpu() call (tests/_tol.py; ceilings not enforced)  -> $O/observed_errors.json

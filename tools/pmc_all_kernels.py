@@ -15,7 +15,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ROUND = os.environ.get("AFX_ROUND", "r04")
+ROUND = os.environ.get("AFX_ROUND", "r06")
 PASSES = ["SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY",
           "SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU",
           "SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM GRBM_GUI_ACTIVE SQ_INSTS_SMEM SQ_WAIT_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU"]
@@ -34,7 +34,7 @@ def main():
         shutil.rmtree(d, ignore_errors=True)
         cmd = ["rocprofv3", "--pmc"] + counters.split() + ["--output-format", "csv", "-d", d, "-o", "p", "--", "python3",
                                                           os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--no-cpu-baseline",
-                                                          "--no-single", "--no-spot-check", "--no-side-stream"] + bench_args
+                                                          "--no-single", "--no-spot-check", "--no-side-stream", "--no-clock-probe", "--no-sharded-crawl"] + bench_args
         subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True)
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             for r in csv.DictReader(open(f)):

@@ -9,7 +9,7 @@
 //       5, 4 (v_permlane32_swap, v_permlane16_swap: no selects), 3 (row_ror:8) and 2 (two bank-masked row shifts) and
 //       leaves band m of frame f in lane 4 m + f -- where the closed forms then run in all 64 lanes, no parking in LDS.
 //
-// Both variants read their magnitudes from LDS every iteration (as the kernel reads the DMA'd image) and form five sums
+// Both variants load their magnitudes from global memory into registers (V1: 48 doubles per lane) and form five sums
 // per frame (x, x^2, x y and two selected sums, like sx / sxx / sxy / vsum / psum).  Output: ns per frame at a full chip
 // (2 waves per SIMD, like bands_kernel), and a checksum against a scalar reference of the same sums.
 // Build + run: hipcc --offload-arch=gfx950 -O3 -o /tmp/bands_rows16 tools/ubench/bands_rows16.hip && /tmp/bands_rows16
@@ -136,56 +136,66 @@ __device__ __forceinline__ double row_sum16(double (&a)[16], int lane) {
   const double keep = b2 ? a[1] : a[0], send = b2 ? a[0] : a[1];                 // m bit 0 = lane bit 2
   return keep + xor4(send);
 }
+constexpr int first_row1(int b) { for (int i = 0; i < kRows1; ++i) if (touches1(b, i)) return i; return -1; }
+// rows as template recursion: a 14 x 48 loop nest under "#pragma unroll" was left as loops with run-time register indexing
+// (s_set_gpr_idx) and the masks in a constant table in memory
+template <int I, typename F>
+__device__ __forceinline__ void accumulate_row1(double (&acc)[16], F& value_of_row) {
+  if constexpr (I < kRows1) {
+    const double v = value_of_row(I);
+#pragma unroll
+    for (int b = 0; b < kNumSub; ++b)
+      if (touches1(b, I)) {
+        const double w = covers1(b, I) ? v : keep_where(v, kM1.m[b][I]);
+        acc[b] = (first_row1(b) == I) ? w : acc[b] + w;
+      }
+    accumulate_row1<I + 1>(acc, value_of_row);
+  }
+}
 template <typename F>
 __device__ __forceinline__ double band_sum1(F value_of_row, int lane) {
   double acc[16];
-#pragma unroll
-  for (int b = 0; b < 16; ++b) {
-    acc[b] = 0.0;
-    if (b < kNumSub) {
-      bool first = true;
-#pragma unroll
-      for (int i = 0; i < kRows1; ++i)
-        if (touches1(b, i)) {
-          const double v = covers1(b, i) ? value_of_row(i) : keep_where(value_of_row(i), kM1.m[b][i]);
-          acc[b] = first ? v : acc[b] + v;
-          first = false;
-        }
-    }
-  }
+  acc[14] = 0.0; acc[15] = 0.0;
+  accumulate_row1<0>(acc, value_of_row);
   return row_sum16(acc, lane);
 }
 
-constexpr int kImage = 768;             // doubles per frame image
-constexpr int kPad1 = 8;                // V1: images 64 B apart in bank space (6144 + 64 bytes): the four frames of a quad hit different banks
+constexpr int kImage = 768;             // doubles per frame
+constexpr int kWindow = 16;             // frames a wave cycles through
 
+// (Round 6, first attempt: V1 read its four frames from LDS images like the shipped kernel reads its one -- 4 x 6 KiB per
+// wave, 5 with the predecessor: 8 waves per CU would need 240 KB of the 160 KB, i.e. ONE wave per SIMD.  The layout only
+// works with the spectrum in registers, loaded from global memory: 48 doubles per lane.)
 template <int V>
-__global__ __launch_bounds__(512, 1) void bench_kernel(const double* spectra, int frames_per_wave, double* out) {
-  extern __shared__ double lds[];
+__global__ __launch_bounds__(256, 2) void bench_kernel(const double* spectra, int frames_per_wave, double* out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int gw = blockIdx.x * 8 + wave;
-  double* const img = lds + wave * (4 * (kImage + kPad1));
+  const int gw = blockIdx.x * 4 + wave;
   double total = 0.0;
-  const double* src = spectra + (size_t)gw * frames_per_wave * kImage;
+  // every wave walks frames_per_wave frames of a window of kWindow frames shared by 64 waves (6 MB in all: the spectra come
+  // out of the cache, as in the pipeline where the band kernel is VALU-bound -- streamed from HBM both variants measured
+  // the memory system, 3.2 TB/s)
+  const double* src = spectra + (size_t)(gw & 63) * kWindow * kImage;
   if (V == 0) {
     double y[kRows0];
 #pragma unroll
     for (int r = 0; r < kRows0; ++r) y[r] = 0.5;
     for (int f = 0; f < frames_per_wave; ++f) {
-#pragma unroll
-      for (int r = 0; r < kRows0; ++r) img[64 * r + lane] = src[(size_t)f * kImage + 64 * r + lane];
-      __builtin_amdgcn_s_waitcnt(0);
       double x[kRows0], xx[kRows0], xy[kRows0], xs[kRows0], xp[kRows0];
 #pragma unroll
+      for (int r = 0; r < kRows0; ++r) x[r] = src[(size_t)(f & (kWindow - 1)) * kImage + 64 * r + lane];
+#pragma unroll
       for (int r = 0; r < kRows0; ++r) {
-        x[r] = ((volatile double*)img)[64 * r + lane];
         xx[r] = x[r] * x[r]; xy[r] = x[r] * y[r];
         xs[r] = x[r] < 0.3 ? x[r] : 0.0; xp[r] = x[r] > 0.7 ? x[r] : 0.0;
       }
       const double s0 = band_sum0([&](int r) { return x[r]; }, lane);
+      __builtin_amdgcn_sched_barrier(0);
       const double s1 = band_sum0([&](int r) { return xx[r]; }, lane);
+      __builtin_amdgcn_sched_barrier(0);
       const double s2 = band_sum0([&](int r) { return xy[r]; }, lane);
+      __builtin_amdgcn_sched_barrier(0);
       const double s3 = band_sum0([&](int r) { return xs[r]; }, lane);
+      __builtin_amdgcn_sched_barrier(0);
       const double s4 = band_sum0([&](int r) { return xp[r]; }, lane);
       total += ((lane & 3) == 0 && (lane >> 2) < kNumSub) ? s0 + 2 * s1 + 3 * s2 + 5 * s3 + 7 * s4 : 0.0;
 #pragma unroll
@@ -194,22 +204,22 @@ __global__ __launch_bounds__(512, 1) void bench_kernel(const double* spectra, in
   } else {
     const int m = lane >> 2, fq = lane & 3;
     for (int f = 0; f + 3 < frames_per_wave; f += 4) {
-      // four images; (the kernel proper would get them by LDS-DMA in natural order, as it does now)
-      for (int j = 0; j < 4; ++j)
+      const double* mine = src + (size_t)((f + fq) & (kWindow - 1)) * kImage + m;
+      const double* prev = src + (size_t)((f + ((fq + 3) & 3)) & (kWindow - 1)) * kImage + m;     // stand-in for the frame before
+      double x[kRows1];
 #pragma unroll
-        for (int r = 0; r < kRows0; ++r) img[j * (kImage + kPad1) + 64 * r + lane] = src[(size_t)(f + j) * kImage + 64 * r + lane];
-      __builtin_amdgcn_s_waitcnt(0);
-      const volatile double* mine = img + fq * (kImage + kPad1) + m;
-      const volatile double* prev = img + ((fq + 3) & 3) * (kImage + kPad1) + m;     // the frame before (stand-in for frame f - 1 of row 0)
-      // one quantity at a time, its 48 values re-read from the image (48 doubles per quantity in registers next to 16
-      // accumulators and the kernel's other state do not fit: 632 B of scratch when all five were formed from one x[48])
-      const double s0 = band_sum1([&](int i) { return mine[16 * i]; }, lane);
-      const double s1 = band_sum1([&](int i) { const double v = mine[16 * i]; return v * v; }, lane);
-      const double s2 = band_sum1([&](int i) { return mine[16 * i] * prev[16 * i]; }, lane);   // the previous frame from its image
-      const double s3 = band_sum1([&](int i) { const double v = mine[16 * i]; return v < 0.3 ? v : 0.0; }, lane);
-      const double s4 = band_sum1([&](int i) { const double v = mine[16 * i]; return v > 0.7 ? v : 0.0; }, lane);
-      total += (m < kNumSub) ? s0 + 2 * s1 + 5 * s3 + 7 * s4 + 0.0 * s2 : 0.0;
-      // (the x y sums of V1 pair frame f with another frame than V0 does: left out of the checksum, kept in the timing)
+      for (int i = 0; i < kRows1; ++i) x[i] = mine[16 * i];
+      const double s0 = band_sum1([&](int i) { return x[i]; }, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      const double s1 = band_sum1([&](int i) { return x[i] * x[i]; }, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      const double s2 = band_sum1([&](int i) { return x[i] * prev[16 * i]; }, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      const double s3 = band_sum1([&](int i) { return x[i] < 0.3 ? x[i] : 0.0; }, lane);
+      __builtin_amdgcn_sched_barrier(0);
+      const double s4 = band_sum1([&](int i) { return x[i] > 0.7 ? x[i] : 0.0; }, lane);
+      total += (m < kNumSub) ? s0 + 2 * s1 + 5 * s3 + 7 * s4 : 0.0;
+      // (the x y sums of V1 pair a frame with another one than V0 does: left out of the checksum, kept in the timing)
       total += (m < kNumSub) ? 1e-30 * s2 : 0.0;
     }
   }
@@ -219,23 +229,20 @@ __global__ __launch_bounds__(512, 1) void bench_kernel(const double* spectra, in
 }
 
 int main() {
-  const int blocks = 256, waves = blocks * 8, fpw = 64;   // 2 waves per SIMD on every CU
-  const size_t n = (size_t)waves * fpw * kImage;
+  const int blocks = 512, waves = blocks * 4, fpw = 256;   // two workgroups of four waves per CU: 2 waves per SIMD, like bands_kernel
+  const size_t n = (size_t)64 * kWindow * kImage;
   std::vector<double> h(n);
   unsigned s = 12345;
   for (double& v : h) { s = s * 1664525u + 1013904223u; v = (double)(s >> 8) / 16777216.0; }
   double *d, *o;
   hipMalloc(&d, n * 8); hipMalloc(&o, waves * 8);
   hipMemcpy(d, h.data(), n * 8, hipMemcpyHostToDevice);
-  const size_t ldsb = 8 * 4 * (kImage + kPad1) * 8;
-  hipFuncSetAttribute((const void*)bench_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
-  hipFuncSetAttribute((const void*)bench_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb);
   // reference checksum: sum over frames and bands of s0 + 2 s1 + 5 s3 + 7 s4 (and 3 s2 for V0 only)
   double ref01 = 0, ref2 = 0;
   for (int w = 0; w < waves; ++w) {
     std::vector<double> y(kImage, 0.5);
     for (int f = 0; f < fpw; ++f) {
-      const double* x = &h[((size_t)w * fpw + f) * kImage];
+      const double* x = &h[((size_t)(w & 63) * kWindow + (f & (kWindow - 1))) * kImage];
       for (int b = 0; b < kNumSub; ++b)
         for (int k = kSubStart[b]; k < kSubStart[b + 1]; ++k) {
           ref01 += x[k] + 2 * x[k] * x[k] + 5 * (x[k] < 0.3 ? x[k] : 0) + 7 * (x[k] > 0.7 ? x[k] : 0);
@@ -251,8 +258,9 @@ int main() {
     std::vector<double> ho(waves);
     for (int rep = 0; rep < 12; ++rep) {
       hipEventRecord(e0);
-      if (v == 0) hipLaunchKernelGGL(bench_kernel<0>, dim3(blocks), dim3(512), ldsb, 0, d, fpw, o);
-      else hipLaunchKernelGGL(bench_kernel<1>, dim3(blocks), dim3(512), ldsb, 0, d, fpw, o);
+      if (v == 0) hipLaunchKernelGGL(bench_kernel<0>, dim3(blocks), dim3(256), 0, 0, d, fpw, o);
+      else hipLaunchKernelGGL(bench_kernel<1>, dim3(blocks), dim3(256), 0, 0, d, fpw, o);
+      if (hipGetLastError() != hipSuccess) { std::printf("launch failed\n"); return 1; }
       hipEventRecord(e1);
       hipEventSynchronize(e1);
       float ms; hipEventElapsedTime(&ms, e0, e1);

@@ -81,8 +81,12 @@ OBSERVED_CEILING = {
     # the sub-band and f0 entries): ragged random material reaches further than the suite's signals.
     "mfcc": 1e-5,                   # 9.8e-7 observed (fuzz; 2.6e-7 in the suite): logs of mel sums over leakage-floor bins (vector.c:350-391)
     "sub_flatness": 2e-5,           # 1.75e-6 (fuzz; 3.6e-8 in the suite): geometric means of sub-bands of 2..6 bins (Statistics.cpp:417-455)
-    "sub_contrast": 5e-7,           # 4.9e-8 (fuzz; 1.6e-9 in the suite)
-    "f0": 5e-7, "failsafe_f0": 5e-7,   # 1.25e-7 (fuzz: a parabolic interpolation over a nearly flat minimum; 2.6e-14 in the suite); the bar is 1e-6
+    "sub_contrast": 5e-7,           # 4.9e-8 (fuzz; 1.6e-9 in the suite): 10 x, no more
+    # f0 / failsafe_f0: 4 x, not 10 x -- 1.25e-7 observed (fuzz: a parabolic interpolation over a nearly flat minimum; 2.6e-14
+    # in the suite) and the bar itself is 1e-6: ten times the observed worst does not fit under it.  Randomised runs
+    # (tests/fuzz_gpu.py, bench.py's spot checks) therefore report an excess over a ceiling as a WARNING with the seed
+    # (ceiling_is_fatal=False below); the deterministic suite keeps the hard assert.
+    "f0": 5e-7, "failsafe_f0": 5e-7,
     "spectral_skewness": 1e-6, "spectral_kurtosis": 1e-6,   # 8.5e-8 (fuzz, seed 72: a kurtosis of 0.006 = mean fourth power / sigma^4 - 3,
                                                             # two terms of size 3 cancelling; 7.6e-10 otherwise)
     "spectral_rms": 2e-8, "spectral_centroid": 2e-8, "spectral_spread": 2e-8,
@@ -121,10 +125,14 @@ def over_ceiling(name, got, ref):
     return worst / OBSERVED_CEILING[name]
 
 
-def check_gpu(name, got, ref, rtol=None, atol=None, what=""):
+ceiling_warnings = []   # (what, name, worst, ceiling) of the excesses reported as warnings (ceiling_is_fatal=False)
+
+
+def check_gpu(name, got, ref, rtol=None, atol=None, what="", ceiling_is_fatal=True):
     """The HIP path against the oracle / the reference's goldens: the 1e-4 bar (check) and the regression ceiling.
     AFX_TOL_RECORD=<file>: the worst relative error per descriptor of the process is written there (json) and the
-    ceiling is not enforced -- how the ceilings were measured."""
+    ceiling is not enforced -- how the ceilings were measured.  ceiling_is_fatal=False (randomised material: the fuzz
+    soaks): an error inside the bar but above the ceiling is printed and kept in ceiling_warnings, not raised."""
     import json
     import os
     if rtol is None:
@@ -149,6 +157,12 @@ def check_gpu(name, got, ref, rtol=None, atol=None, what=""):
     ceiling = OBSERVED_CEILING[name]
     if worst > ceiling:
         i = np.unravel_index(int(np.argmax(e)), e.shape)
+        if not ceiling_is_fatal:
+            import sys
+            ceiling_warnings.append((what, name, worst, ceiling))
+            print(f"WARNING {what}{name}: relative error {worst:.3e} at {i} is inside the {rtol:g} bar but above the regression "
+                  f"ceiling {ceiling:g} (tests/_tol.py)", file=sys.stderr)
+            return
         raise AssertionError(
             f"{what}{name}: relative error {worst:.3e} at {i} is inside the {rtol:g} bar but above the regression ceiling "
             f"{ceiling:g} (10 x the worst error the shipped kernels have shown, tests/_tol.py): got "

@@ -779,7 +779,7 @@ extern "C" int afec_crawl_wave_images_ex(const char* const* names, const void* c
       }
     if (row_digests)
       for (int32_t i = 0; i < n_files; ++i) row_digests[i] = s.mRowDigests[(size_t)i];
-    if (crawl_facts) { crawl_facts[0] = (double)s.mWorkersPerDevice; crawl_facts[1] = s.mUsableHostCpus; }
+    if (crawl_facts) { crawl_facts[0] = (double)s.mWorkersPerDevice; crawl_facts[1] = s.mUsableHostCpus; crawl_facts[2] = s.mAborted ? 1.0 : 0.0; }
     return 0;
   } catch (const std::exception& e) {
     if (error && error_size > 0) std::snprintf(error, (size_t)error_size, "%s", e.what());

@@ -158,8 +158,8 @@ int afec_crawl_wave_images(const char* const* names, const void* const* images, 
                            const char* database_path, double* stats, char* error, int32_t error_size);
 // The same with the per-device figures and the row digests of a sharded crawl: device_stats (NULL or [n_devices][3]) =
 // {files, bytes of PCM uploaded, seconds until the device's last batch was delivered} per device; row_digests (NULL or
-// [n_files]) = TCrawlStatistics::mRowDigests; crawl_facts (NULL or [2]) = {worker threads per device the crawl ran with,
-// UsableHostCpus()}.  workers_per_device <= 0: TCrawlOptions' default (picked from the usable CPUs and the device count).
+// [n_files]) = TCrawlStatistics::mRowDigests; crawl_facts (NULL or [3]) = {worker threads per device the crawl ran with,
+// UsableHostCpus(), 1 when afec_crawl_request_abort ended the crawl early}.  workers_per_device <= 0: TCrawlOptions' default (picked from the usable CPUs and the device count).
 int afec_crawl_wave_images_ex(const char* const* names, const void* const* images, const int64_t* sizes, int32_t n_files,
                               const int32_t* devices, int32_t n_devices, int32_t workers_per_device, int32_t files_per_batch,
                               const char* database_path, double* stats, double* device_stats, uint64_t* row_digests,

@@ -82,7 +82,7 @@ def crawl(images, names=None, devices=(0,), workers=None, files_per_batch=512, d
     c_dev = (ctypes.c_int32 * G)(*devices)
     stats = (ctypes.c_double * (12 + G))()
     device_stats = (ctypes.c_double * (3 * G))()
-    facts = (ctypes.c_double * 2)()
+    facts = (ctypes.c_double * 3)()
     row_digests = np.zeros(n, dtype=np.uint64) if digests else None
     err = ctypes.create_string_buffer(512)
     rc = L.afec_crawl_wave_images_ex(c_names, c_images, c_sizes, n, c_dev, G, int(workers or 0), files_per_batch,
@@ -101,6 +101,7 @@ def crawl(images, names=None, devices=(0,), workers=None, files_per_batch=512, d
     out["seconds_per_device"] = [float(device_stats[3 * d + 2]) for d in range(G)]   # crawl start .. the device's last batch delivered
     out["workers_per_device"] = int(facts[0])
     out["usable_host_cpus"] = float(facts[1])
+    out["aborted"] = bool(facts[2])          # request_abort() ended the crawl early: "files" counts what was analysed
     if digests:
         out["row_digests"] = row_digests
     return out
@@ -128,6 +129,14 @@ def workers_per_device_for(n_devices):
     L.afec_workers_per_device_for.restype = ctypes.c_int32
     L.afec_workers_per_device_for.argtypes = [ctypes.c_int32]
     return int(L.afec_workers_per_device_for(int(n_devices)))
+
+
+def request_abort():
+    """Ends the crawl that is running in another thread of this process early (TCrawlOptions::mpAbortRequested -- the
+    reference's SIGINT flag, Crawler.cpp:69-73, 717-720): no new batches, what was analysed is delivered."""
+    L = lib()
+    L.afec_crawl_request_abort.restype = None
+    L.afec_crawl_request_abort()
 
 
 def release():

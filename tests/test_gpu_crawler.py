@@ -473,3 +473,49 @@ def test_a_files_row_does_not_depend_on_the_batch_it_was_crawled_in(tmp_path):
     c, d = rows_by_hash(dbs[2]), rows_by_hash(dbs[3])
     assert d == b                    # small batches: the 64-lane layout either way
     assert c != d                    # ... and AUTO's large batches took the other layout: rows that depend on the batch
+
+
+def test_an_external_abort_ends_the_crawl_early_and_leaves_whole_batches(tmp_path):
+    """The reference's SIGINT flag (Crawler.cpp:69-73, 717-720: every task checks sAbortProcessing before it starts):
+    afec_crawl_request_abort from another thread while a crawl with the database on is running -- workers take no new
+    batch, what was analysed is written (whole batches only), the call returns normally with `aborted` set.  The same
+    scenario runs under ThreadSanitizer on the mock device (tests/sanitize/tsan_crawler.cpp)."""
+    import threading
+    from afec_amd import hostlib
+    images, names, _ = make_crawl(120)
+    images, names = images * 12, [f"{k:02d}/{n}" for k in range(12) for n in names]      # ~1 550 files, batches of 8
+    db = str(tmp_path / "aborted.db")
+    clean = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=8, database=str(tmp_path / "clean.db"))
+    assert not clean["aborted"] and clean["files"] == len(images)
+    timer = threading.Timer(clean["seconds"] / 3, hostlib.request_abort)
+    timer.start()
+    st = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=8, database=db)
+    timer.join()
+    assert st["aborted"] and 0 < st["files"] < len(images), st
+    have = set(statuses(db))
+    assert len(have) == st["files"]
+    groups = [names[i:i + 8] for i in range(0, len(names), 8)]
+    counts = [sum(n in have for n in g) for g in groups]
+    assert all(c in (0, len(g)) for c, g in zip(counts, groups)), counts
+    # the next crawl is not affected by the old request
+    again = _host.crawl(images[:40], names[:40], devices=(0,), workers=2, files_per_batch=8)
+    assert not again["aborted"] and again["files"] == 40
+
+
+def test_row_digests_are_a_function_of_the_content_not_of_the_shard_or_the_batch():
+    """TCrawlOptions::mRowDigests (bench.py's sharded crawl checks its devices with it): a 64-bit digest per file over
+    everything the device returned.  The same 63 contents crawled as two shards of device 0 in batches of 16, as one shard
+    in batches of 50 and with another worker count: a content's digest is the same everywhere, different contents
+    differ, a file that cannot be read has none."""
+    assert afx.device_count() >= 1
+    images, names, _ = make_crawl(62)
+    images, names = images[:63], names[:63]
+    reps = 4
+    many, many_names = images * reps, [f"{k}/{n}" for k in range(reps) for n in names]
+    a = _host.crawl(many, many_names, devices=(0, 0), workers=2, files_per_batch=16, digests=True)
+    b = _host.crawl(many, many_names, devices=(0,), workers=3, files_per_batch=50, digests=True)
+    assert a["files_per_device"] == [126, 126] and b["files_per_device"] == [252]
+    da, db = a["row_digests"].reshape(reps, 63), b["row_digests"].reshape(reps, 63)
+    assert np.array_equal(da, np.broadcast_to(da[0], da.shape)) and np.array_equal(db, da)
+    analysed = da[0][da[0] != 0]
+    assert analysed.size >= 60 and np.unique(analysed).size == analysed.size

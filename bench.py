@@ -660,7 +660,7 @@ CHAIN_MASKS = {"frame": "every per-frame low-level descriptor (the spectral set 
                       "amplitude peak / rms: AFX_D_ALL_LOW_LEVEL) + per-file statistics"}
 
 
-def chain_rate(plan, workload, n_files, seed, mask_name="frame", batch_files=0, in_flight=5, device=0, clock=True):
+def chain_rate(plan, workload, n_files, seed, mask_name="frame", batch_files=0, in_flight=5, device=0, clock=True, clock_hint=None):
     """BASELINE configs[2] (C3: 1 000 mono 2 s files) / configs[3] (C4: one GPU's share of 100 000 stereo 1 s files) as
     the resident chain `--workload c3|c4 --mask frame|all` times it: decoded files through LoadSample (untimed: batch
     creation), then per step the per-frame descriptors of the mask + the per-file statistics (SA:814-976, 1065).
@@ -710,11 +710,15 @@ def chain_rate(plan, workload, n_files, seed, mask_name="frame", batch_files=0, 
            "traffic_ratio": None, "valu_frac": None, "kernels_ms": None, "parity_spot_check": spot}
     prof = kernel_profile("f64", mask_name, workload, "crawler" if batch_files > 0 else None)
     if prof and not prof.get("stale"):
-        ghz = clock_seen["clock_ghz"] if clock_seen else prof["clock_ghz"]
+        # (the crawler's shape: no probe beside dozens of streams, and the profile's own clock -- counters over a SUM of
+        # overlapping kernels' durations -- means nothing: the clock of the same kernels as one batch, measured just before)
+        ghz = clock_seen["clock_ghz"] if clock_seen else (clock_hint if clock_hint else prof["clock_ghz"])
         ceiling = 4 * 256 * ghz * 1e9 / prof["valu_cycles_per_frame"]
         out.update(traffic_ratio=prof["bytes_per_frame"] / SURVEY_C3_BYTES_PER_FRAME, valu_frac=rate / ceiling,
                    valu_frac_at_nominal_clock=rate / (4 * 256 * NOMINAL_CLOCK_GHZ * 1e9 / prof["valu_cycles_per_frame"]),
-                   valu_ceiling_frames_s=ceiling, valu_clock="sampled in this run (a repeat of the timed launches)" if clock_seen else "the profiled run's",
+                   valu_ceiling_frames_s=ceiling, valu_clock_ghz=ghz,
+                   valu_clock="sampled in this run (a repeat of the timed launches)" if clock_seen else
+                   ("sampled in this run on the same files as one batch" if clock_hint else "the profiled run's"),
                    kernels_ms=prof.get("kernel_ms_per_step"), profile=prof["source"])
     return out
 
@@ -914,7 +918,8 @@ def main():
             crawler_plan = open_plan(device, local, world, precision=precision, max_analysis_ms=20000,
                                      frame_kernel=afx.FRAME_KERNEL_WAVE64)     # TSampleAnalyser's plan (afec_amd/host/Crawler.h)
             try:
-                c4_crawler = chain_rate(crawler_plan, "c4", 12500, 4321, batch_files=512, in_flight=5, device=device, clock=not args.no_clock_probe)
+                c4_crawler = chain_rate(crawler_plan, "c4", 12500, 4321, batch_files=512, in_flight=5, device=device, clock=not args.no_clock_probe,
+                                        clock_hint=c4_chain.get("clock_ghz_in_run") if c4_chain else None)
             finally:
                 crawler_plan.close()
         except Exception as e:  # noqa: BLE001
@@ -987,7 +992,7 @@ def main():
         try:
             from afec_amd import hostlib
             hostlib.release()
-            sharded = sharded_crawl(1, args.files, 99, pinned_device=pinned if pinned is not None else device)
+            sharded = sharded_crawl(1, args.files, 99, pinned_device=pinned if pinned is not None else device, repeats=8)   # (as many crawls as end_to_end_host_driver took its best of)
         except Exception as e:  # noqa: BLE001
             sharded = {"error": str(e)}
 

@@ -485,12 +485,18 @@ def test_an_external_abort_ends_the_crawl_early_and_leaves_whole_batches(tmp_pat
     images, names, _ = make_crawl(120)
     images, names = images * 12, [f"{k:02d}/{n}" for k in range(12) for n in names]      # ~1 550 files, batches of 8
     db = str(tmp_path / "aborted.db")
+    _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=8, database=str(tmp_path / "cold.db"))   # sets the crawler up
     clean = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=8, database=str(tmp_path / "clean.db"))
     assert not clean["aborted"] and clean["files"] == len(images)
-    timer = threading.Timer(clean["seconds"] / 3, hostlib.request_abort)
-    timer.start()
-    st = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=8, database=db)
-    timer.join()
+    st = None
+    for attempt, part in enumerate((3, 6, 12, 24)):      # (the request must land while the crawl runs: earlier if it did not)
+        db = str(tmp_path / f"aborted{attempt}.db")
+        timer = threading.Timer(clean["seconds"] / part, hostlib.request_abort)
+        timer.start()
+        st = _host.crawl(images, names, devices=(0,), workers=1, files_per_batch=8, database=db)
+        timer.join()
+        if st["aborted"] and 0 < st["files"] < len(images):
+            break
     assert st["aborted"] and 0 < st["files"] < len(images), st
     have = set(statuses(db))
     assert len(have) == st["files"]

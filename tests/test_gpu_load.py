@@ -288,3 +288,33 @@ def test_a_files_rows_do_not_depend_on_the_batch_it_was_analysed_in(kernel):
             for k, v in stats.items():
                 np.testing.assert_array_equal(v, want[i % 4][1][k], err_msg=f"statistics {k} of file {i}")
     plan.close()
+
+
+def test_the_magnitude_class_without_the_upper_spectrum_leaves_the_same_values():
+    """frames32_kernel<6> (round 6): for the spectral set without the loop's neighbours nobody reads bins 769..1023, and
+    from 131 072 frames on the half-wave magnitude class neither stores nor roots them.  What it does store and every
+    descriptor derived from it must be the bit patterns of class 4: the same files in a batch below the threshold (class
+    4) and above it (class 6), half-wave layout pinned, every value and statistic of the first files compared."""
+    rng = np.random.default_rng(606)
+    t = np.arange(44100)
+    pool = [np.round(9000 * rng.uniform(-1, 1, 44100)).astype(np.int16),
+            np.round(12000 * np.sin(2 * np.pi * 330 * t / 44100) * np.exp(-t / 15000.0)).astype(np.int16),
+            np.round(4000 * rng.standard_normal(44100) * (t % 9000 < 2500)).astype(np.int16),
+            np.concatenate([np.zeros(15000), np.round(15000 * rng.uniform(-1, 1, 29100))]).astype(np.int16)]
+    plan = afx.Plan(frame_kernel=afx.FRAME_KERNEL_HALFWAVE)
+    mask = afx.D_ALL_LOW_LEVEL | afx.D_STATISTICS
+    results = []
+    for n_files in (40, 4200):                      # 28-37 frames per file after the trim: ~1 400 and ~150 000 frames
+        b, _ = plan.batch_from_raw([(pool[i % 4], 1) for i in range(n_files)], mask)
+        assert b.info()["frame_kernel"] == afx.FRAME_KERNEL_HALFWAVE and b.info()["feature_class"] == 4
+        assert (b.total_frames >= 131072) == (n_files == 4200), b.total_frames
+        b.run()
+        res, st = b.fetch(), b.fetch_statistics()
+        off = res["frame_offset"]
+        results.append(({k: v[off[0]:off[8]] for k, v in res.items() if k not in ("frame_offset", "buf_status")},
+                        {k: v[:8] for k, v in st.items()}))
+        b.close()
+    plan.close()
+    for part in (0, 1):
+        for k, v in results[0][part].items():
+            assert np.array_equal(np.asarray(v).view(np.uint8), np.asarray(results[1][part][k]).view(np.uint8)), k

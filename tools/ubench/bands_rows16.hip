@@ -25,10 +25,22 @@ using mask64 = unsigned long long;
 constexpr int kNumSub = 14;
 constexpr int kSubStart[kNumSub + 1] = {1, 3, 7, 13, 23, 35, 50, 67, 90, 119, 160, 221, 317, 465, 752};
 
+// hipcc of ROCm 7.2 materialises a 64-bit constant for an "s" operand of inline asm as `s_mov_b64 sN, <32-bit literal>`
+// whenever the value fits a SIGN-extended int32, and the hardware ZERO-extends that literal: a lane mask like
+// 0xfffffffff0000000 arrives as 0x00000000f0000000 (seen in this file's own first version: lanes 32..63 lost).  Such a
+// mask is passed as its complement, which is a small positive value, with the two sources of the select swapped.
+__device__ __forceinline__ constexpr bool literal_would_be_zero_extended(mask64 m) {
+  return (long long)m < -16 && (long long)m >= -(1ll << 31);
+}
 __device__ __forceinline__ double keep_where(double v, mask64 m) {
   int lo, hi;
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(v)), "s"(m));
-  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(v)), "s"(m));
+  if (literal_would_be_zero_extended(m)) {
+    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(lo) : "v"(__double2loint(v)), "s"(~m));
+    asm("v_cndmask_b32_e64 %0, %1, 0, %2" : "=v"(hi) : "v"(__double2hiint(v)), "s"(~m));
+  } else {
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(lo) : "v"(__double2loint(v)), "s"(m));
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(hi) : "v"(__double2hiint(v)), "s"(m));
+  }
   return __hiloint2double(hi, lo);
 }
 template <int CTRL>
@@ -228,6 +240,26 @@ __global__ __launch_bounds__(256, 2) void bench_kernel(const double* spectra, in
   if (lane == 0) out[gw] = total;
 }
 
+// self-check: sum of x per band of four frames, both layouts, against the host (one wave each)
+__global__ void check_kernel(const double* spectra, double* out) {
+  const int lane = threadIdx.x & 63;
+  for (int f = 0; f < 4; ++f) {      // V0: one frame at a time
+    double x[kRows0];
+#pragma unroll
+    for (int r = 0; r < kRows0; ++r) x[r] = spectra[(size_t)f * kImage + 64 * r + lane];
+    const double s0 = band_sum0([&](int r) { return x[r]; }, lane);
+    if ((lane & 3) == 0) out[16 * f + (lane >> 2)] = s0;
+  }
+  {                                   // V1: the four at once
+    const int m = lane >> 2, fq = lane & 3;
+    double x[kRows1];
+#pragma unroll
+    for (int i = 0; i < kRows1; ++i) x[i] = spectra[(size_t)fq * kImage + m + 16 * i];
+    const double s0 = band_sum1([&](int i) { return x[i]; }, lane);
+    out[64 + 16 * fq + m] = s0;
+  }
+}
+
 int main() {
   const int blocks = 512, waves = blocks * 4, fpw = 256;   // two workgroups of four waves per CU: 2 waves per SIMD, like bands_kernel
   const size_t n = (size_t)64 * kWindow * kImage;
@@ -237,6 +269,21 @@ int main() {
   double *d, *o;
   hipMalloc(&d, n * 8); hipMalloc(&o, waves * 8);
   hipMemcpy(d, h.data(), n * 8, hipMemcpyHostToDevice);
+  {
+    double* dc; hipMalloc(&dc, 128 * 8);
+    hipLaunchKernelGGL(check_kernel, dim3(1), dim3(64), 0, 0, d, dc);
+    double hc[128];
+    hipMemcpy(hc, dc, sizeof hc, hipMemcpyDeviceToHost);
+    double worst0 = 0, worst1 = 0;
+    for (int f = 0; f < 4; ++f)
+      for (int b = 0; b < kNumSub; ++b) {
+        double want = 0;
+        for (int k = kSubStart[b]; k < kSubStart[b + 1]; ++k) want += h[(size_t)f * kImage + k];
+        worst0 = std::fmax(worst0, std::fabs(hc[16 * f + b] - want) / want);
+        worst1 = std::fmax(worst1, std::fabs(hc[64 + 16 * f + b] - want) / want);
+      }
+    std::printf("self-check, per-band sums of four frames against the host: V0 worst rel. err %.2e, V1 %.2e\n", worst0, worst1);
+  }
   double checksum[2] = {0, 0};
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);

@@ -10,27 +10,31 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))   # repositor
 _lib = None
 
 
+def _bind(L):
+    """argument types of the entry points whose pointers ctypes would otherwise truncate"""
+    L.afec_wave_probe.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
+                                  ctypes.c_int64, ctypes.c_char_p, ctypes.c_int32]
+    L.afec_wave_probe_file.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p, ctypes.c_int64,
+                                       ctypes.c_char_p, ctypes.c_int32]
+    L.afec_shard_of_file.argtypes = [ctypes.c_int64, ctypes.c_int32]
+    L.afec_crawl_wave_images.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_void_p),
+                                         ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                         ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p,
+                                         ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int32]
+    L.afec_crawl_wave_images_ex.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_void_p),
+                                            ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
+                                            ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p,
+                                            ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
+                                            ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int32]
+    return L
+
+
 def lib():
     global _lib
     if _lib is None:
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "afec_amd", "csrc")], stdout=subprocess.DEVNULL)
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "afec_amd", "host")], stdout=subprocess.DEVNULL)
-        L = ctypes.CDLL(os.path.join(ROOT, "afec_amd", "lib", "libafx_host.so"))
-        L.afec_wave_probe.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
-                                      ctypes.c_int64, ctypes.c_char_p, ctypes.c_int32]
-        L.afec_wave_probe_file.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p, ctypes.c_int64,
-                                           ctypes.c_char_p, ctypes.c_int32]
-        L.afec_shard_of_file.argtypes = [ctypes.c_int64, ctypes.c_int32]
-        L.afec_crawl_wave_images.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_void_p),
-                                             ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
-                                             ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p,
-                                             ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int32]
-        L.afec_crawl_wave_images_ex.argtypes = [ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(ctypes.c_void_p),
-                                                ctypes.POINTER(ctypes.c_int64), ctypes.c_int32, ctypes.POINTER(ctypes.c_int32),
-                                                ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_char_p,
-                                                ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p,
-                                                ctypes.POINTER(ctypes.c_double), ctypes.c_char_p, ctypes.c_int32]
-        _lib = L
+        _lib = _bind(ctypes.CDLL(os.path.join(ROOT, "afec_amd", "lib", "libafx_host.so")))
     return _lib
 
 

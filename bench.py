@@ -28,6 +28,8 @@ import subprocess
 import sys
 import time
 
+T_SCRIPT_START = time.time()     # the line's "run_seconds" counts from here (the interpreter's own start-up is before it)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -1092,7 +1094,13 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
+            t_cpu = time.time()
             out["cpu_baseline"] = cpu_baseline(args.cpu_frames)
+            out["cpu_baseline"]["seconds"] = time.time() - t_cpu
+        # wall time of this whole run as rank 0 saw it (imports, input generation, the timed region, every secondary
+        # object of the line, the CPU baseline): what the driver's own clock around the command should read, minus the
+        # interpreter's start-up -- the default run has to finish within minutes
+        out["run_seconds"] = time.time() - T_SCRIPT_START
         print(json.dumps(out))
     if plan is not None:
         plan.close()

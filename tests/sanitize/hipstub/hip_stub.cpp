@@ -124,3 +124,6 @@ hipError_t hipEventQuery(hipEvent_t) { STUB_LIVE(); return hipSuccess; }
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)((double)(b->ns.load() - a->ns.load()) * 1e-6) + 1e-3f; return hipSuccess; }
 
 }  // extern "C"
+
+// for a ctypes caller (tests/test_sanitize_cpu.py loads the mock host library into Python)
+extern "C" void hipstub_set_device_count(int n) { hipstub::set_device_count(n); }

@@ -113,3 +113,6 @@ def test_the_default_line_one_gpu_sharded_crawl_agrees_with_the_end_to_end_drive
         assert cfg[key]["parity_spot_check"]["passed"], (key, cfg[key]["parity_spot_check"])
     assert cfg["c4_share_at_crawler_shape"]["frame_kernel"] == "wave64"
     assert "mt19937" in cfg["workload"]
+    # the driver's default run has to finish within minutes: every secondary object of the line included (the CPU
+    # baseline, not run here, adds its bounded ~20 s; profiles/r06/bench_default.json)
+    assert line["run_seconds"] < 150, line["run_seconds"]

@@ -76,3 +76,35 @@ def test_the_mock_restates_the_launch_rules_of_the_product_library():
         assert real._ZN3afx25load_scan_blocks_per_fileEi(n) == mock._ZN3afx25load_scan_blocks_per_fileEi(n)
     for n in (1, 4095, 4096, 4097, 10 ** 9):
         assert real._ZN3afx15resample_blocksEl(n) == mock._ZN3afx15resample_blocksEl(n)
+
+
+def test_the_bench_lines_sharded_crawl_on_eight_mock_devices(tmp_path):
+    """bench.py's config.sharded_crawl as an 8-GPU node would run it -- one process, afec_amd/hostlib.py ->
+    afec_crawl_wave_images_ex -> afec::TCrawler over devices 0..7 -- with the mock device under the same host sources
+    (build.sh's host_lib target, injected into hostlib from the test, never reachable from the product): the per-device
+    arrays the Python side sizes by the number of devices, file i -> device i mod 8, workers per device from the CPU
+    quota, and the same row digest for the same content on every device."""
+    out = subprocess.run([os.path.join(ROOT, "tests", "sanitize", "build.sh"), "plain", "host_lib"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    mock = out.stdout.decode().split()[-1]
+    script = tmp_path / "crawl8.py"
+    script.write_text(
+        "import ctypes, json, sys\n"
+        f"sys.path.insert(0, {ROOT!r})\n"
+        "import afec_amd.hostlib as hostlib\n"
+        "L = ctypes.CDLL(sys.argv[1]); L.hipstub_set_device_count(8)\n"
+        "hostlib._lib = hostlib._bind(L)\n"
+        "import bench\n"
+        "bench.afx.device_count = lambda: 8\n"
+        "print(json.dumps(bench.sharded_crawl(8, 150, 99, repeats=2)))\n")
+    import json
+    import sys
+    r = subprocess.run([sys.executable, str(script), mock], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    sc = json.loads(r.stdout.decode().splitlines()[-1])
+    assert sc["devices"] == list(range(8)) and sc["devices_visible"] == 8
+    assert sc["files"] == 1200 and sc["failed"] == 0 and sc["files_per_device"] == [150] * 8
+    assert len(sc["upload_GB_per_s_per_device"]) == 8 and all(v and v > 0 for v in sc["upload_GB_per_s_per_device"])
+    assert 1 <= sc["workers_per_device"] <= 5 and sc["workers_per_device"] == max(1, min(5, int(sc["cpu_quota"] // 8)))
+    digests = sc["row_digests"]
+    assert digests["identical_per_content"] and digests["files_per_device"] == [126] * 8 and digests["rows_per_content"] == 16

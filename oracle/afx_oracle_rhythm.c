@@ -15,7 +15,8 @@
  *            - TStatistics::Mean / Variance (already pinned, afx_oracle.c).
  *   UNPINNED - the whitening follower, the two onset functions, median removal / detection, Canny sharpening, peak,
  *              strength, contrast and the duration heuristics: TOnsetDetector / TRhythmTracker / TCannyWindow do not
- *              link here (CoreTypes' TString needs the generated iconv.h.in; TArray/TList need TMemory -> TSystem/TLog),
+ *              link here (TArray/TList need TMemory -> TSystem::InMain(): LinuxSystem.cpp includes the <sys/sysctl.h> this
+ *              glibc no longer ships; TString needs libiconv, in the reference tree only as a git-LFS pointer: oracle/Makefile),
  *              so these are restated from the sources cited below and checked only by hand-computed cases in tests/.
  *
  * Float semantics: the reference keeps the polar spectrum, the whitening output and the onset functions in `float`

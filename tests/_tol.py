@@ -79,7 +79,11 @@ OBSERVED_CEILING = {
     # 10 x the worst error seen over one run of the whole GPU suite (profiles/r05/observed_errors.json) AND three fuzz soaks
     # of random material, masks and batch shapes (profiles/r05/observed_errors_fuzz.json + the soak of seed 51, which set
     # the sub-band and f0 entries): ragged random material reaches further than the suite's signals.
-    "mfcc": 1e-5,                   # 9.8e-7 observed (fuzz; 2.6e-7 in the suite): logs of mel sums over leakage-floor bins (vector.c:350-391)
+    # mfcc: logs of mel sums over leakage-floor bins (vector.c:350-391), the one descriptor whose error random material can
+    # push far beyond the suite's (2.6e-7 there, 38 x under this ceiling): 9.8e-7 in round 5's soaks, 1.23e-5 ONCE in round
+    # 6's (seed 93, round 3327, coefficient 7 of one frame; 1.45 M frames) -- 8 x inside the bar, above this ceiling, and
+    # ten times it would not fit under the bar: the randomised runs report it as a warning (see f0 below).
+    "mfcc": 1e-5,
     "sub_flatness": 2e-5,           # 1.75e-6 (fuzz; 3.6e-8 in the suite): geometric means of sub-bands of 2..6 bins (Statistics.cpp:417-455)
     "sub_contrast": 5e-7,           # 4.9e-8 (fuzz; 1.6e-9 in the suite): 10 x, no more
     # f0 / failsafe_f0: 4 x, not 10 x -- 1.25e-7 observed (fuzz: a parabolic interpolation over a nearly flat minimum; 2.6e-14

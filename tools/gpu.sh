@@ -13,7 +13,7 @@
 #                                                                                     -> $O/lease_report.{json,txt}
 #   ab=<bench args>@<lib>,<lib>  steady per-kernel durations of builds under afec_amd/lib/<lib>/ (kernel trace only)
 #   steps=<lib>,<lib>            whole-step rates of builds on the six bench configurations, two passes
-#   fuzz=<seconds>,<seed>[,stats]  tests/fuzz_gpu.py (stats: the half-wave statistics classes)
+#   fuzz=<seconds>,<seed>[,stats|halfwave]  tests/fuzz_gpu.py (stats: the half-wave statistics classes; halfwave: random masks, half-wave kernels forced)
 #   slow                         the tests behind AFX_SLOW_TESTS=1                   -> $O/slow_tests.log
 #   soak=<seconds>               tools/crawl_soak.py
 #   small                        single_buffer / x_batchsize / x_classes / e2e accounting / shards8
@@ -77,6 +77,8 @@ for STAGE in "$@"; do
       IFS=, read -r SEC SEED KIND <<< "$ARG"
       if [ "${KIND:-}" = "stats" ]; then
         AFX_FUZZ_KERNEL=halfwave AFX_FUZZ_STATS=1 timeout $((SEC + 120)) python tests/fuzz_gpu.py $SEC $SEED > $O/fuzz_stats_seed$SEED.log 2>&1; tail -2 $O/fuzz_stats_seed$SEED.log
+      elif [ "${KIND:-}" = "halfwave" ]; then
+        AFX_FUZZ_KERNEL=halfwave timeout $((SEC + 120)) python tests/fuzz_gpu.py $SEC $SEED > $O/fuzz_halfwave_seed$SEED.log 2>&1; tail -2 $O/fuzz_halfwave_seed$SEED.log
       else
         timeout $((SEC + 120)) python tests/fuzz_gpu.py $SEC $SEED > $O/fuzz_seed$SEED.log 2>&1; tail -2 $O/fuzz_seed$SEED.log
       fi ;;

@@ -54,6 +54,41 @@ def dump(round_index, bufs, mask):
                         **{f"buf{i}": b for i, b in enumerate(bufs)})
 
 
+def draw_round(rng, stats_mode=False):
+    """Every random draw of one round, in the order the loop has always made them -- none depends on a GPU result, so a
+    round's inputs can be regenerated without a GPU (tools/fuzz_replay.py fast-forwards a seed to a round with this)."""
+    bufs = []
+    for _ in range(int(rng.integers(1, 7))):
+        n = int(rng.choice([rng.integers(0, 3000), rng.integers(2048, 40000), rng.integers(2048, 200000)]))
+        x = material(rng, n) if n else np.zeros(0)
+        bufs.append(x.astype(np.float32 if rng.random() < 0.5 else np.float64))
+    dt = bufs[0].dtype
+    bufs = [b.astype(dt) for b in bufs]
+    mask = int(rng.integers(1, 1 << 22)) & afx.D_ALL_PER_FRAME
+    if mask == 0:
+        mask = afx.D_ALL_PER_FRAME
+    if stats_mode:
+        # the statistics class of the half-wave kernel (run with AFX_FUZZ_KERNEL=halfwave): MFCC + a random subset of
+        # spectral rms / centroid / spread / skewness / kurtosis / rolloff / flatness, float32 PCM
+        mask = afx.D_MFCC | (int(rng.integers(0, 128)) << 1)
+        bufs = [b.astype(np.float32) for b in bufs]
+    out = {"bufs": bufs, "mask": mask, "statistics": False, "load_files": None, "rhythm_info": None}
+    if sum((b.size - 2048) // 1024 + 1 for b in bufs if b.size >= 2048) == 0:
+        return out          # a round without a frame ends here
+    out["statistics"] = bool(rng.random() < 0.25)
+    if rng.random() < 0.2:
+        files = []
+        for _ in range(int(rng.integers(1, 5))):
+            ch = int(rng.integers(1, 9))
+            nfr = int(rng.choice([rng.integers(1, 3000), rng.integers(2048, 60000)]))
+            y = np.stack([material(rng, nfr) * rng.uniform(0.05, 1.2) for _ in range(ch)], axis=1)
+            files.append((y, ch, int(rng.integers(0, 3))))
+        out["load_files"] = files
+    if rng.random() < 0.5 and any(b.size >= 512 for b in bufs):
+        out["rhythm_info"] = [(44100, int(rng.integers(-3000, 1)), int(b.size * rng.choice([1, 1, 2]))) for b in bufs]
+    return out
+
+
 def main():
     seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -64,21 +99,8 @@ def main():
     t0 = time.time()
     rounds = frames = bad = skipped = rhythm_frames = rhythm_gate_flips = 0
     while time.time() - t0 < seconds:
-        bufs = []
-        for _ in range(int(rng.integers(1, 7))):
-            n = int(rng.choice([rng.integers(0, 3000), rng.integers(2048, 40000), rng.integers(2048, 200000)]))
-            x = material(rng, n) if n else np.zeros(0)
-            bufs.append(x.astype(np.float32 if rng.random() < 0.5 else np.float64))
-        dt = bufs[0].dtype
-        bufs = [b.astype(dt) for b in bufs]
-        mask = int(rng.integers(1, 1 << 22)) & afx.D_ALL_PER_FRAME
-        if mask == 0:
-            mask = afx.D_ALL_PER_FRAME
-        if os.environ.get("AFX_FUZZ_STATS"):
-            # the statistics class of the half-wave kernel (run with AFX_FUZZ_KERNEL=halfwave): MFCC + a random subset of
-            # spectral rms / centroid / spread / skewness / kurtosis / rolloff / flatness, float32 PCM
-            mask = afx.D_MFCC | (int(rng.integers(0, 128)) << 1)
-            bufs = [b.astype(np.float32) for b in bufs]
+        drawn = draw_round(rng, bool(os.environ.get("AFX_FUZZ_STATS")))
+        bufs, mask = drawn["bufs"], drawn["mask"]
         res = plan.extract(bufs, mask)
         ref = np.concatenate([oracle.run(b.astype(np.float64)) for b in bufs]) if bufs else None
         nref = np.concatenate([oracle.run_neighbours(b.astype(np.float64)) for b in bufs])
@@ -129,7 +151,7 @@ def main():
                 dump(rounds, bufs, mask)
                 print(f"round {rounds} mask {mask:#x}: {e}")
         # per-file statistics of the GPU's own series (the reduction alone is compared, at 1e-9)
-        if rng.random() < 0.25:
+        if drawn["statistics"]:
             from tests import _oracle
             b = plan.batch(bufs, mask | afx.D_STATISTICS)
             b.run()
@@ -175,14 +197,10 @@ def main():
                                 dump(rounds, bufs, mask)
                                 print(f"round {rounds} statistics {name}[{w}].{sn} of buffer {i}: got {got[w, j]!r} want {want[j]!r}")
         # the LoadSample front end: random decoded files, samples / offsets / peak bit-exact against the oracle
-        if rng.random() < 0.2:
+        if drawn["load_files"] is not None:
             from tests import _oracle
             files = []
-            for _ in range(int(rng.integers(1, 5))):
-                ch = int(rng.integers(1, 9))
-                nfr = int(rng.choice([rng.integers(1, 3000), rng.integers(2048, 60000)]))
-                y = np.stack([material(rng, nfr) * rng.uniform(0.05, 1.2) for _ in range(ch)], axis=1)
-                fmt = int(rng.integers(0, 3))
+            for y, ch, fmt in drawn["load_files"]:
                 if fmt == 0:
                     data = np.clip(np.round(y * 32767), -32768, 32767).astype(np.int16).reshape(-1)
                 elif fmt == 1:
@@ -208,9 +226,9 @@ def main():
         # the rhythm tracker on the round's buffers (float64 here: the oracle sees the very same samples): onset frames
         # identical, onset functions to a few float ulps of the file's peak, scalars to 1e-5; a detection that differs
         # is reported with its margin to the threshold
-        if rng.random() < 0.5 and any(b.size >= 512 for b in bufs):
+        if drawn["rhythm_info"] is not None:
             rb = plan.batch(bufs, afx.D_RHYTHM)
-            info = [(44100, int(rng.integers(-3000, 1)), int(b.size * rng.choice([1, 1, 2]))) for b in bufs]
+            info = drawn["rhythm_info"]
             rb.set_file_info(info)
             rb.run()
             rr = rb.fetch_rhythm(onset_functions=True)

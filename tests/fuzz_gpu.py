@@ -114,6 +114,12 @@ def main():
         # almost entirely digital silence: yinfast's confidence is ~1e-14 and its arg-min picks noise).
         mags = ref[:, 1:752]
         flat_spectrum = (mags.max(axis=1) - mags.min(axis=1)) <= 1e-9 * mags.max(axis=1)
+        # ... and, for the count of strict local maxima per sub-band only, a frame in which two neighbouring bins differ by
+        # less than the FFT's own rounding (32 eps of the frame's largest bin): the far skirt of a loud tone is smooth at
+        # 1e-10 of the peak and where it turns, neighbours differ by 1e-16..1e-18 of it (seed 99, round 12373: band 13 of a
+        # frame with peak 0.175 has bins 546 / 547 at 5.06005024e-11 / 5.06005006e-11; the oracle counts 6 maxima, the
+        # half-wave kernel 7).  0.4 % of the frames.
+        near_tie = np.abs(np.diff(ref[:, 0:753], axis=1)).min(axis=1) <= 32 * 2.2e-16 * ref[:, 0:753].max(axis=1)
         # ... or whose first half is 120 dB below the frame: yinfast takes d(tau) = E1 + E2(tau) - 2 C(tau) with the
         # correlation C from an FFT of the whole frame, whose rounding is ~1e-16 of the FRAME's energy; a burst that starts
         # in the second half behind a tail at 1e-15 (seed 95, round 18824: first half rms 1.2e-15, second 0.15) leaves
@@ -127,13 +133,15 @@ def main():
             zero_counts += [cz[1024 * f + 2048] - cz[1024 * f] for f in range(nf)]
             quiet_first_half += [hop_energy[f] <= 1e-12 * (hop_energy[f] + hop_energy[f + 1]) for f in range(nf)]
         flat_yin = (np.array(zero_counts, dtype=np.int64) >= 1024) | np.array(quiet_first_half, dtype=bool)   # at least half of the frame is digital silence
-        skipped += int(flat_spectrum.sum() + flat_yin.sum())
+        skipped += int(flat_spectrum.sum() + flat_yin.sum() + (near_tie & ~flat_spectrum).sum())
         discrete_spectral = {"sub_complexity", "sub_flux", "spectral_flux", "spectral_complexity"}
         pitch_fields = {"f0", "failsafe_f0"}
         for field, (a, b) in FIELDS.items():
             if field == "mag" or field not in res:
                 continue
             keep = ~flat_spectrum if field in discrete_spectral else np.ones(ref.shape[0], bool)
+            if field == "sub_complexity":
+                keep = keep & ~near_tie
             try:
                 _tol.check_gpu(field, res[field].reshape(ref.shape[0], -1)[keep], ref[keep, a:b], *_tol.GPU_TOL[field], what=f"seed {seed} round {rounds}: ", ceiling_is_fatal=False)
             except AssertionError as e:
